@@ -1,0 +1,107 @@
+/*
+ * unopose_hip.h -- C ABI of libunopose_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the native operators on UNOPose's forward hot path.
+ * Every entry point takes plain DEVICE pointers + sizes + a HIP stream handle
+ * (hipStream_t passed as void*; NULL = the null stream) and returns 0 on
+ * success or a UNOPOSE_E* code.  No torch types cross this boundary.  Kernels
+ * are enqueued on `stream`; nothing here synchronises the host.
+ *
+ * Part 1 replaces, one for one, the nine functions of the reference's pybind
+ * module core.unopose.model.pointnet2._ext
+ * (core/unopose/model/pointnet2/_ext_src/src/bindings.cpp:11-24).  Unlike the
+ * reference host wrappers these do NOT allocate: the caller passes the output
+ * buffer (the Python shim unopose_amd/pointnet2/_ext.py allocates it exactly
+ * as the reference wrappers do, zero-filled where the reference zero-fills).
+ *
+ * Part 2 are the fused operators the reference expresses as PyTorch op
+ * sequences; each cites the Python it replaces.
+ *
+ * Layouts are the reference's: row-major, float32 data, int32 indices.
+ */
+#ifndef UNOPOSE_HIP_H
+#define UNOPOSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNOPOSE_OK 0
+#define UNOPOSE_EINVAL 1   /* bad size / null pointer */
+#define UNOPOSE_ELAUNCH 2  /* hipGetLastError() != hipSuccess after launch */
+#define UNOPOSE_ENOMEM 3   /* workspace too small */
+
+typedef void *unopose_stream_t;
+
+/* Library / device identification (no GPU work). */
+int unopose_abi_version(void);
+const char *unopose_last_error(void);
+
+/* ------------------------------------------------------------------ Part 1 */
+
+/* furthest_point_sampling(points (B,N,3), nsamples) -> idx (B,M) int32.
+ * Replaces sampling.cpp:70-91 + sampling_gpu.cu:74-234.  idx[b,0] = 0; ties
+ * are broken exactly as the reference's 512-lane shared-memory tree does
+ * (argmax d, then min (bitrev(k mod bs), k), bs = min(512, 2^floor(log2 N))).
+ * The running min-distance array stays on chip; no `tmp` buffer is needed. */
+int unopose_furthest_point_sampling(const float *xyz, int B, int N, int M,
+                                    int32_t *idx, unopose_stream_t stream);
+
+/* gather_points(points (B,C,N), idx (B,M)) -> out (B,C,M).
+ * Replaces sampling.cpp:20-44 + sampling_gpu.cu:13-36. */
+int unopose_gather_points(const float *points, const int32_t *idx, int B, int C,
+                          int N, int M, float *out, unopose_stream_t stream);
+
+/* gather_points_grad(grad_out (B,C,M), idx (B,M), N) -> grad_points (B,C,N),
+ * which MUST be zero-filled by the caller (the reference wrapper allocates
+ * zeros).  Replaces sampling.cpp:46-69 + sampling_gpu.cu:39-62. */
+int unopose_gather_points_grad(const float *grad_out, const int32_t *idx, int B,
+                               int C, int N, int M, float *grad_points,
+                               unopose_stream_t stream);
+
+/* ball_query(new_xyz (B,M,3), xyz (B,N,3), radius, nsample) -> idx (B,M,S).
+ * Replaces ball_query.cpp:13-37 + ball_query_gpu.cu:14-59.  Every element of
+ * idx is written (rows with no hit are written as zeros, which is what the
+ * reference's zero-initialised output holds). */
+int unopose_ball_query(const float *new_xyz, const float *xyz, int B, int N,
+                       int M, float radius, int nsample, int32_t *idx,
+                       unopose_stream_t stream);
+
+/* group_points(points (B,C,N), idx (B,M,S)) -> out (B,C,M,S).
+ * Replaces group_points.cpp:17-40 + group_points_gpu.cu:13-44. */
+int unopose_group_points(const float *points, const int32_t *idx, int B, int C,
+                         int N, int M, int S, float *out,
+                         unopose_stream_t stream);
+
+/* group_points_grad(grad_out (B,C,M,S), idx, N) -> grad_points (B,C,N),
+ * zero-filled by the caller.  Replaces group_points.cpp:42-65 +
+ * group_points_gpu.cu:48-80. */
+int unopose_group_points_grad(const float *grad_out, const int32_t *idx, int B,
+                              int C, int N, int M, int S, float *grad_points,
+                              unopose_stream_t stream);
+
+/* three_nn(unknown (B,n,3), known (B,m,3)) -> dist2 (B,n,3), idx (B,n,3).
+ * Replaces interpolate.cpp:20-45 + interpolate_gpu.cu:14-74. */
+int unopose_three_nn(const float *unknown, const float *known, int B, int n,
+                     int m, float *dist2, int32_t *idx, unopose_stream_t stream);
+
+/* three_interpolate(points (B,c,m), idx (B,n,3), weight (B,n,3)) -> (B,c,n).
+ * Replaces interpolate.cpp:47-74 + interpolate_gpu.cu:77-116. */
+int unopose_three_interpolate(const float *points, const int32_t *idx,
+                              const float *weight, int B, int c, int m, int n,
+                              float *out, unopose_stream_t stream);
+
+/* three_interpolate_grad(grad_out (B,c,n), idx, weight, m) -> (B,c,m),
+ * zero-filled by the caller.  Replaces interpolate.cpp:76-104 +
+ * interpolate_gpu.cu:121-159. */
+int unopose_three_interpolate_grad(const float *grad_out, const int32_t *idx,
+                                   const float *weight, int B, int c, int n,
+                                   int m, float *grad_points,
+                                   unopose_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNOPOSE_HIP_H */

@@ -1,0 +1,48 @@
+"""Seeded synthetic inputs shared by tests, smoke and bench."""
+import math
+
+import numpy as np
+import torch
+
+
+def bitrev(v, nbits):
+    r = np.zeros_like(v)
+    for b in range(nbits):
+        r |= ((v >> b) & 1) << (nbits - 1 - b)
+    return r
+
+
+def fps_closed_form(p, m):
+    """argmax of the running min-distance, ties -> min (bitrev(k mod bs), k)."""
+    p = np.asarray(p, np.float32)
+    n = len(p)
+    L = min(9, int(math.floor(math.log2(n))))
+    bs = 1 << L
+    k = np.arange(n, dtype=np.int64)
+    key = bitrev(k % bs, L).astype(np.int64) * (1 << 32) + k
+    tmp = np.full(n, 1e10, np.float32)
+    out = [0]
+    old = 0
+    for _ in range(1, m):
+        d = p - p[old]
+        d = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        tmp = np.minimum(d, tmp)
+        c = np.where(tmp == tmp.max())[0]
+        old = int(c[np.argmin(key[c])])
+        out.append(old)
+    return np.array(out, np.int32)
+
+
+def object_cloud(gen, n, with_replacement=False):
+    """Visible half of an ellipsoid surface + 1 mm noise, camera frame, metres."""
+    axes = 0.04 + 0.08 * torch.rand(3, generator=gen)
+    v = torch.randn(n, 3, generator=gen)
+    v = v / v.norm(dim=1, keepdim=True)
+    v[:, 2] = -v[:, 2].abs()
+    p = v * axes
+    t = torch.tensor([0.0, 0.0, 0.85]) + (torch.rand(3, generator=gen) - 0.5) * torch.tensor([0.2, 0.2, 0.7])
+    p = p + t + 1e-3 * torch.randn(n, 3, generator=gen)
+    if with_replacement:
+        sel = torch.randint(0, max(8, n // 5), (n,), generator=gen)
+        p = p[sel]
+    return p.float().contiguous()

@@ -1,0 +1,41 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/*.h declares."""
+import ctypes
+import glob
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    syms = []
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        syms += re.findall(r"\b(unopose_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(syms))
+
+
+def test_library_exports_every_declared_symbol():
+    from unopose_amd import build
+
+    so = build.build()
+    lib = ctypes.CDLL(so)
+    syms = _declared_symbols()
+    assert len(syms) >= 11
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/ but not exported by {so}"
+    lib.unopose_abi_version.restype = ctypes.c_int
+    assert lib.unopose_abi_version() >= 1
+
+
+def test_python_signature_table_matches_header():
+    from unopose_amd import _lib
+
+    declared = set(_declared_symbols()) - {"unopose_abi_version", "unopose_last_error", "unopose_stream_t"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+
+
+def test_product_never_imports_oracle():
+    for path in glob.glob(os.path.join(ROOT, "unopose_amd", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path

@@ -1,0 +1,87 @@
+"""ctypes binding of ``libunopose_hip.so`` (the C ABI in ``include/unopose_hip.h``).
+
+The product path has NO fallback: if the shared library is missing or an entry
+point returns non-zero, a ``RuntimeError`` is raised (the reference's wrappers
+raise ``RuntimeError`` through TORCH_CHECK, ``_ext_src/include/utils.h:10-30``).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libunopose_hip.so")
+
+_lib = None
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+# name -> argtypes (return type is always int).  Must list every symbol that
+# include/unopose_hip.h declares; tests/test_abi.py checks the two agree.
+SIGNATURES = {
+    "unopose_furthest_point_sampling": [_P, _I, _I, _I, _P, _P],
+    "unopose_gather_points": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "unopose_gather_points_grad": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "unopose_ball_query": [_P, _P, _I, _I, _I, _F, _I, _P, _P],
+    "unopose_group_points": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "unopose_group_points_grad": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "unopose_three_nn": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "unopose_three_interpolate": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "unopose_three_interpolate_grad": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+}
+
+
+def lib():
+    """Load the shared library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: the HIP extension has not been built "
+                "(run `python -m unopose_amd.build`). There is no CPU fallback."
+            )
+        L = ctypes.CDLL(SO_PATH)
+        L.unopose_abi_version.restype = _I
+        L.unopose_last_error.restype = ctypes.c_char_p
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = _I
+        _lib = L
+    return _lib
+
+
+def stream_ptr(device=None):
+    """Raw hipStream_t of torch's current stream on `device`."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def call(name, *args):
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (code {rc}): {L.unopose_last_error().decode()}")
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def check_f32(x, name):
+    if not x.is_cuda:
+        raise RuntimeError(f"{name}: CPU not supported")
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+    if x.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be a float tensor")
+
+
+def check_i32(x, name):
+    if not x.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+    if x.dtype != torch.int32:
+        raise RuntimeError(f"{name} must be an int tensor")

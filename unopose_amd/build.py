@@ -1,0 +1,69 @@
+"""Build libunopose_hip.so (gfx950) in-tree with hipcc.
+
+``python -m unopose_amd.build`` or ``unopose_amd.build.build()``.  hipcc
+cross-compiles without a GPU; the resulting ``unopose_amd/libunopose_hip.so``
+is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+SO = os.path.join(HERE, "libunopose_hip.so")
+ARCH = "gfx950"
+# -ffp-contract=off: fp32 distance expressions must round exactly as written so
+# FPS / ball_query indices are bit-identical to oracle/ (DESIGN.md "fp-contract").
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall",
+         "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(src, dst, extra=()):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in (src, *extra))
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "unopose_hip.h"))
+    jobs = []
+    objs = []
+    for f in srcs:
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ, f[:-4] + ".o")
+        objs.append(obj)
+        if force or _newer(src, obj, hdrs):
+            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if verbose and r.stderr:
+            print(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or not os.path.exists(SO):
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", SO, *objs])
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,97 @@
+// Shared helpers for the gfx950 kernels of libunopose_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/unopose_hip.h"
+
+namespace unopose {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Last error text, readable through unopose_last_error().
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return UNOPOSE_ELAUNCH;
+  }
+  return UNOPOSE_OK;
+}
+
+#define UNOPOSE_REQUIRE(cond, ...)        \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::unopose::set_error(__VA_ARGS__);  \
+      return UNOPOSE_EINVAL;              \
+    }                                     \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave64 DPP reductions (gfx9 row_shr / row_bcast) ----------------------
+// dpp_ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v, uint32_t identity) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v, float identity) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {
+  uint32_t lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)v, 0u);
+  uint32_t hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(v >> 32), 0u);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a > b ? a : b; }
+
+// max over the 16 lanes of each DPP row; valid in lane 15 of the row.
+__device__ __forceinline__ uint64_t row_max_u64(uint64_t v) {
+  v = umax64(v, dpp_u64<0x111, 0xF>(v));
+  v = umax64(v, dpp_u64<0x112, 0xF>(v));
+  v = umax64(v, dpp_u64<0x114, 0xF>(v));
+  v = umax64(v, dpp_u64<0x118, 0xF>(v));
+  return v;
+}
+// max over all 64 lanes; wave-uniform result (read from lane 63).
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+  v = row_max_u64(v);
+  v = umax64(v, dpp_u64<0x142, 0xA>(v));
+  v = umax64(v, dpp_u64<0x143, 0xC>(v));
+  uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+  uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v += dpp_f32<0x111, 0xF>(v, 0.f);
+  v += dpp_f32<0x112, 0xF>(v, 0.f);
+  v += dpp_f32<0x114, 0xF>(v, 0.f);
+  v += dpp_f32<0x118, 0xF>(v, 0.f);
+  v += dpp_f32<0x142, 0xA>(v, 0.f);
+  v += dpp_f32<0x143, 0xC>(v, 0.f);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+  const float ninf = -__builtin_inff();
+  v = fmaxf(v, dpp_f32<0x111, 0xF>(v, ninf));
+  v = fmaxf(v, dpp_f32<0x112, 0xF>(v, ninf));
+  v = fmaxf(v, dpp_f32<0x114, 0xF>(v, ninf));
+  v = fmaxf(v, dpp_f32<0x118, 0xF>(v, ninf));
+  v = fmaxf(v, dpp_f32<0x142, 0xA>(v, ninf));
+  v = fmaxf(v, dpp_f32<0x143, 0xC>(v, ninf));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ int lane_id() {
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+}  // namespace unopose
