@@ -497,3 +497,139 @@ def unopose_forward(end_points, sd, cfg, rand, ext, detail=False):
         out.update(dense_pm=dense_pm, dense_fm=dense_fm, dense_po=dense_po, dense_fo=dense_fo, radius=radius,
                    fps_idx_m=idx_m, fps_idx_o=idx_o, geo_m=geo_m, geo_o=geo_o, sparse_pm=sp_m, sparse_po=sp_o)
     return out
+
+
+# ------------------------------------------------------ state_dict layout ---
+def state_dict_spec(cfg, img_size=224):
+    """Key -> shape of UNOPose's state_dict (verified against the
+    reference modules by tests/golden/make_golden.py via strict load_state_dict)."""
+    spec = {}
+    fe = cfg.feature_extraction
+    D, depth = fe.embed_dim, fe.get("depth", 12)
+    v = "feature_extraction.rgb_net.vit"
+    P = (img_size // 14) ** 2
+    spec[v + ".cls_token"] = (1, 1, D)
+    spec[v + ".reg_token"] = (1, 4, D)
+    spec[v + ".pos_embed"] = (1, P, D)
+    spec[v + ".patch_embed.proj.weight"] = (D, 3, 14, 14)
+    spec[v + ".patch_embed.proj.bias"] = (D,)
+    for i in range(depth):
+        b = f"{v}.blocks.{i}"
+        for nm in ("norm1", "norm2"):
+            spec[f"{b}.{nm}.weight"] = (D,)
+            spec[f"{b}.{nm}.bias"] = (D,)
+        spec[b + ".attn.qkv.weight"] = (3 * D, D)
+        spec[b + ".attn.qkv.bias"] = (3 * D,)
+        spec[b + ".attn.proj.weight"] = (D, D)
+        spec[b + ".attn.proj.bias"] = (D,)
+        spec[b + ".ls1.gamma"] = (D,)
+        spec[b + ".ls2.gamma"] = (D,)
+        spec[b + ".mlp.fc1.weight"] = (4 * D, D)
+        spec[b + ".mlp.fc1.bias"] = (4 * D,)
+        spec[b + ".mlp.fc2.weight"] = (D, 4 * D)
+        spec[b + ".mlp.fc2.bias"] = (D,)
+    spec[v + ".norm.weight"] = (D,)
+    spec[v + ".norm.bias"] = (D,)
+    spec[v + ".head.weight"] = (1000, D)  # unused (timm default num_classes)
+    spec[v + ".head.bias"] = (1000,)
+    spec["feature_extraction.rgb_net.output_upscaling.weight"] = (16 * fe.out_dim, 4 * D)
+    spec["feature_extraction.rgb_net.output_upscaling.bias"] = (16 * fe.out_dim,)
+
+    H = cfg.geo_embedding.hidden_dim
+    spec["geo_embedding.embedding.div_term"] = (H // 2,)
+    for nm in ("proj_d", "proj_a"):
+        spec[f"geo_embedding.{nm}.weight"] = (H, H)
+        spec[f"geo_embedding.{nm}.bias"] = (H,)
+
+    def lin(p, o, i):
+        spec[p + ".weight"] = (o, i)
+        spec[p + ".bias"] = (o,)
+
+    def tlayer(p, d, rpe):
+        for nm in ("proj_q", "proj_k", "proj_v") + (("proj_p",) if rpe else ()):
+            lin(f"{p}.attention.attention.{nm}", d, d)
+        lin(p + ".attention.linear", d, d)
+        spec[p + ".attention.norm.weight"] = (d,)
+        spec[p + ".attention.norm.bias"] = (d,)
+        lin(p + ".output.expand", 2 * d, d)
+        lin(p + ".output.squeeze", d, 2 * d)
+        spec[p + ".output.norm.weight"] = (d,)
+        spec[p + ".output.norm.bias"] = (d,)
+
+    c = cfg.coarse_point_matching
+    p = "coarse_point_matching"
+    spec[p + ".bg_token"] = (1, 1, c.hidden_dim)
+    lin(p + ".in_proj", c.hidden_dim, c.input_dim)
+    lin(p + ".out_proj", c.out_dim, c.hidden_dim)
+    for i in range(c.nblock):
+        lin(f"{p}.score_heads.{i}", 1, c.hidden_dim)
+    for i in range(c.nblock):
+        tlayer(f"{p}.transformers.{i}.layers.0", c.hidden_dim, True)
+        tlayer(f"{p}.transformers.{i}.layers.1", c.hidden_dim, False)
+
+    f = cfg.fine_point_matching
+    p = "fine_point_matching"
+    d = f.hidden_dim
+    spec[p + ".bg_token"] = (1, 1, d)
+    lin(p + ".in_proj", d, f.input_dim)
+    lin(p + ".out_proj", f.out_dim, d)
+    lin(p + ".dis_proj", 3, 2 * d)  # never used in forward
+    for m in ("mlp1", "mlp2"):
+        chans = [6, 32, 64, 128]
+        for li in range(3):
+            q = f"{p}.PE.{m}.layer{li}"
+            spec[q + ".conv.weight"] = (chans[li + 1], chans[li], 1, 1)
+            for nm in ("weight", "bias", "running_mean", "running_var"):
+                spec[f"{q}.normlayer.bn.{nm}"] = (chans[li + 1],)
+            spec[q + ".normlayer.bn.num_batches_tracked"] = ()
+    spec[p + ".PE.mlp3.conv.weight"] = (d, 256, 1)
+    spec[p + ".PE.mlp3.conv.bias"] = (d,)
+    for i in range(f.nblock):
+        lin(f"{p}.score_heads.{i}", 1, d)
+    for i in range(f.nblock):
+        t = f"{p}.transformers.{i}"
+        tlayer(t + ".sparse_layer.layers.0", d, True)
+        tlayer(t + ".sparse_layer.layers.1", d, False)
+        spec[t + ".dense_layer.attention.attention.scale"] = (1, 1, d)
+        tlayer(t + ".dense_layer", d, False)
+    return spec
+
+
+def random_state_dict(cfg, seed=0, img_size=224, prefix=None):
+    """Seeded random weights in the reference key layout (trained-like magnitudes;
+    BN running stats randomised as SURVEY.md 8(d) prescribes).  `prefix` keeps only
+    keys under it (e.g. "coarse_point_matching")."""
+    import zlib
+
+    sd = {}
+    for k, shape in state_dict_spec(cfg, img_size).items():
+        if prefix is not None and not k.startswith(prefix):
+            continue
+        g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(k.encode())) % (2 ** 31))
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            t = torch.tensor(100, dtype=torch.int64)
+        elif leaf == "div_term":
+            n = shape[0] * 2
+            t = torch.exp(torch.arange(0, n, 2).float() * (-math.log(10000.0) / n))
+        elif leaf == "running_var":
+            t = 0.5 + torch.rand(shape, generator=g)
+        elif leaf == "running_mean":
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif leaf == "gamma":
+            t = 0.05 + 0.45 * torch.rand(shape, generator=g)
+        elif leaf in ("cls_token", "reg_token", "pos_embed", "bg_token"):
+            t = 0.02 * torch.randn(shape, generator=g)
+        elif leaf == "scale":
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif leaf == "weight" and len(shape) == 1:  # LayerNorm / BatchNorm scale
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif leaf == "bias":
+            t = 0.05 * torch.randn(shape, generator=g)
+        else:  # Linear / conv weight
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            t = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+        sd[k] = t
+    return sd

@@ -1,0 +1,415 @@
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE's own Python.
+
+Runs ONLY in the build container (needs /root/reference; never on the GPU box,
+never from tests).  It imports the reference modules as SURVEY.md App-G
+describes (detectron2 logger stub, `_ext` bound to the C oracle, timm's
+VisionTransformer stubbed by the oracle's ViT restatement -- the ViT arithmetic
+itself is therefore NOT pinned by the reference, everything around it is),
+runs them on seeded inputs, asserts that oracle/unopose_ref.py reproduces
+every output, and stores inputs + reference outputs as small .npz files.
+
+    python tests/golden/make_golden.py            # regenerate everything
+
+Only tensors are written; no reference source is copied.
+"""
+import builtins
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.dont_write_bytecode = True
+
+REF = "/root/reference"
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    builtins.__POINTNET2_SETUP__ = True
+    for name in ("detectron2", "detectron2.utils", "detectron2.utils.logger"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["detectron2.utils.logger"].log_first_n = lambda *a, **k: None
+    sys.modules["detectron2.utils.logger"].log_every_n = lambda *a, **k: None
+
+    # timm stub: VisionTransformer backed by the oracle's restatement (App-G step 5)
+    from oracle import unopose_ref as R
+
+    nn = torch.nn
+
+    class _Attn(nn.Module):
+        def __init__(self, dim, heads):
+            super().__init__()
+            self.heads = heads
+            self.qkv = nn.Linear(dim, 3 * dim)
+            self.proj = nn.Linear(dim, dim)
+
+        def forward(self, x):
+            B, N, C = x.shape
+            qkv = self.qkv(x).reshape(B, N, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+            a = torch.softmax((qkv[0] * (C // self.heads) ** -0.5) @ qkv[1].transpose(-2, -1), dim=-1) @ qkv[2]
+            return self.proj(a.transpose(1, 2).reshape(B, N, C))
+
+    class _LS(nn.Module):
+        def __init__(self, dim):
+            super().__init__()
+            self.gamma = nn.Parameter(torch.ones(dim))
+
+        def forward(self, x):
+            return x * self.gamma
+
+    class _Mlp(nn.Module):
+        def __init__(self, dim):
+            super().__init__()
+            self.fc1 = nn.Linear(dim, 4 * dim)
+            self.fc2 = nn.Linear(4 * dim, dim)
+
+        def forward(self, x):
+            return self.fc2(torch.nn.functional.gelu(self.fc1(x)))
+
+    class _Block(nn.Module):
+        def __init__(self, dim, heads, norm_layer):
+            super().__init__()
+            self.norm1, self.attn, self.ls1 = norm_layer(dim), _Attn(dim, heads), _LS(dim)
+            self.norm2, self.mlp, self.ls2 = norm_layer(dim), _Mlp(dim), _LS(dim)
+
+        def forward(self, x):
+            x = x + self.ls1(self.attn(self.norm1(x)))
+            return x + self.ls2(self.mlp(self.norm2(x)))
+
+    class _PatchEmbed(nn.Module):
+        def __init__(self, dim, patch, img):
+            super().__init__()
+            self.proj = nn.Conv2d(3, dim, patch, patch)
+            self.num_patches = (img // patch) ** 2
+
+        def forward(self, x):
+            return self.proj(x).flatten(2).transpose(1, 2)
+
+    class VisionTransformer(nn.Module):
+        """Module-shaped stand-in with timm 0.9.12's attribute names and state_dict keys
+        (reg_tokens=4, no_embed_class=True path only), so the reference's subclass forward
+        (oneref_feature_extraction.py:28-42) runs on it and `load_state_dict(strict=True)`
+        checks the key layout of SURVEY.md App-C."""
+
+        def __init__(self, patch_size=14, embed_dim=768, depth=12, num_heads=12, init_values=None, reg_tokens=0,
+                     no_embed_class=False, norm_layer=None, img_size=224, **kw):
+            super().__init__()
+            assert reg_tokens == 4 and no_embed_class
+            self.patch_embed = _PatchEmbed(embed_dim, patch_size, img_size)
+            self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+            self.reg_token = nn.Parameter(torch.zeros(1, reg_tokens, embed_dim))
+            self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches, embed_dim))
+            self.norm_pre = nn.Identity()
+            self.blocks = nn.Sequential(*[_Block(embed_dim, num_heads, norm_layer) for _ in range(depth)])
+            self.norm = norm_layer(embed_dim)
+            self.head = nn.Linear(embed_dim, 1000)
+
+        def _pos_embed(self, x):
+            x = x + self.pos_embed
+            return torch.cat([self.cls_token.expand(x.shape[0], -1, -1), self.reg_token.expand(x.shape[0], -1, -1), x], 1)
+
+    timm = types.ModuleType("timm")
+    timm.models = types.ModuleType("timm.models")
+    timm.models.vision_transformer = types.ModuleType("timm.models.vision_transformer")
+    timm.models.vision_transformer.VisionTransformer = VisionTransformer
+    sys.modules["timm"] = timm
+    sys.modules["timm.models"] = timm.models
+    sys.modules["timm.models.vision_transformer"] = timm.models.vision_transformer
+
+    import core.unopose.model.pointnet2.pointnet2_utils as pu
+    from oracle.pointnet2_oracle import ext
+
+    pu._ext = ext
+    return pu
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def close(a, b, tol, what):
+    a, b = torch.as_tensor(a).float(), torch.as_tensor(b).float()
+    err = (a - b).abs().max().item()
+    assert err <= tol, f"{what}: oracle vs reference max abs err {err} > {tol}"
+    print(f"  {what}: oracle == reference (max abs err {err:.2e})")
+
+
+def sub_sd(sd, prefix):
+    n = len(prefix) + 1
+    return {k[n:]: v for k, v in sd.items() if k.startswith(prefix + ".")}
+
+
+def main():
+    pu = import_reference()
+    from oracle import unopose_ref as R
+    from oracle.pointnet2_oracle import ext
+    from helpers import object_cloud, constructed_similarity
+
+    import core.unopose.model.transformer as T
+    import core.unopose.utils.model_utils as U
+    from core.unopose.model.oneref_predator_coarse_point_matching import CoarsePointMatchingOneRef
+    from core.unopose.model.oneref_predator_fine_point_matching import FinePointMatchingOneRef, PositionalEncoding
+
+    torch.set_grad_enabled(False)
+    cfg = R.default_cfg()
+    sd = R.random_state_dict(cfg, seed=0)
+    g = torch.Generator().manual_seed(1234)
+
+    def norm_cloud(n, repl=False):
+        p = object_cloud(g, n, with_replacement=repl)
+        c = p.mean(0, keepdim=True)
+        return (p / (p - c).norm(dim=1).max()).contiguous()
+
+    # ---------------------------------------------------------------- a8 global LRF
+    print("lrf_global")
+    pts = torch.stack([object_cloud(g, 300), object_cloud(g, 300, True)])
+    cen = pts.mean(1, keepdim=True)
+    r = torch.norm(pts - cen, dim=2).max(1)[0]
+    ref = U.LRF(r)(cen.transpose(1, 2), pts.transpose(1, 2)).transpose(1, 2).contiguous()
+    close(R.get_batch_lrf(pts), ref, 2e-5, "get_batch_lrf")
+    save("lrf_global", pts=pts, out=ref)
+
+    # ---------------------------------------------------------------- a5/a6 QueryAndLRFGroup
+    print("query_lrf_group")
+    xyz = torch.stack([norm_cloud(256), norm_cloud(256, True)])
+    for rad, ns in ((0.2, 32), (0.4, 64)):
+        grp = pu.QueryAndLRFGroup(rad, ns, use_xyz=True, use_feature=False)
+        ref = grp(xyz.contiguous(), xyz.contiguous(), xyz.transpose(1, 2).contiguous())
+        mine = R.query_and_lrf_group(xyz, rad, ns, ext)
+        close(mine, ref, 5e-4, f"query_and_lrf_group r={rad}")
+        save(f"query_lrf_group_r{rad}_ns{ns}", xyz=xyz, radius=np.float32(rad), nsample=ns, out=ref)
+
+    # ---------------------------------------------------------------- a7 PositionalEncoding
+    print("positional_encoding")
+    fcfg = cfg.fine_point_matching
+    pe = PositionalEncoding(256, r1=0.2, r2=0.4, nsample1=32, nsample2=64, use_lrf=True, use_xyz=True).eval()
+    pe.load_state_dict(sub_sd(sd, "fine_point_matching.PE"), strict=True)
+    ref = pe(xyz)
+    pcfg = R.Cfg(dict(fcfg, pe_radius1=0.2, pe_radius2=0.4, nsample1=32, nsample2=64))
+    close(R.positional_encoding(xyz, sd, "fine_point_matching.PE", pcfg, ext), ref, 2e-3, "positional_encoding")
+    save("positional_encoding", xyz=xyz, r1=np.float32(0.2), r2=np.float32(0.4), ns1=32, ns2=64, out=ref)
+
+    # ---------------------------------------------------------------- a11 geo embedding
+    print("geo_embedding")
+    geo = T.GeometricStructureEmbedding(cfg.geo_embedding).eval()
+    geo.load_state_dict(sub_sd(sd, "geo_embedding"), strict=True)
+    gp = torch.cat([torch.ones(2, 1, 3), torch.stack([norm_cloud(23), norm_cloud(23)])], 1)
+    d_idx, a_idx = geo.get_embedding_indices(gp)
+    ref = geo(gp)
+    md, ma = R.geo_embedding_indices(gp, cfg.geo_embedding)
+    close(md, d_idx, 1e-5, "geo d_indices")
+    close(ma, a_idx, 1e-4, "geo a_indices")
+    close(R.geo_embedding(gp, sd, "geo_embedding", cfg.geo_embedding), ref, 1e-4, "geo_embedding")
+    save("geo_embedding", points=gp, d_idx=d_idx, a_idx=a_idx, out=ref)
+    geo0, geo1 = ref[0:1], ref[1:2]
+
+    # ---------------------------------------------------------------- a12/a13/a14 layers
+    print("transformer layers")
+    f0 = torch.randn(1, 24, 256, generator=g)
+    f1 = torch.randn(1, 24, 256, generator=g)
+    gt = T.GeometricTransformer(["self", "cross"], 256, 4, dropout=None, activation_fn="ReLU").eval()
+    tp = "coarse_point_matching.transformers.0"
+    gt.load_state_dict(sub_sd(sd, tp), strict=True)
+    r_self = gt.layers[0](f0, f0, geo0)[0]
+    r_cross = gt.layers[1](f0, f1)[0]
+    r0, r1 = gt(f0, geo0, f1, geo1)
+    close(R.transformer_layer(f0, f0, sd, tp + ".layers.0", embed=geo0), r_self, 2e-5, "RPE self layer")
+    close(R.transformer_layer(f0, f1, sd, tp + ".layers.1"), r_cross, 2e-5, "cross layer")
+    m0, m1 = R.geometric_transformer(f0, geo0, f1, geo1, sd, tp)
+    close(m0, r0, 5e-5, "geometric_transformer f0")
+    close(m1, r1, 5e-5, "geometric_transformer f1")
+    save("transformer_layers", points=gp, f0=f0, f1=f1, rpe_self=r_self, cross=r_cross, gt0=r0, gt1=r1)
+
+    print("sparse_to_dense")
+    s2d = T.SparseToDenseTransformer(256, ["self", "cross"], num_heads=4, focusing_factor=3).eval()
+    sp = "fine_point_matching.transformers.0"
+    s2d.load_state_dict(sub_sd(sd, sp), strict=True)
+    d0 = torch.randn(1, 101, 256, generator=g)
+    d1 = torch.randn(1, 101, 256, generator=g)
+    i0 = torch.randint(0, 100, (1, 23), generator=g, dtype=torch.int32)
+    i1 = torch.randint(0, 100, (1, 23), generator=g, dtype=torch.int32)
+    i0[0, 0] = 0
+    ref_lin = s2d.dense_layer(d0[:, 1:].contiguous(), f0[:, 1:].contiguous())
+    close(R.linear_transformer_layer(d0[:, 1:].contiguous(), f0[:, 1:].contiguous(), sd, sp + ".dense_layer"), ref_lin,
+          5e-5, "linear transformer layer")
+    rd0, rd1 = s2d(d0, geo0, i0, d1, geo1, i1)
+    md0, md1 = R.sparse_to_dense_transformer(d0, geo0, i0, d1, geo1, i1, sd, sp, ext)
+    close(md0, rd0, 1e-4, "sparse_to_dense f0")
+    close(md1, rd1, 1e-4, "sparse_to_dense f1")
+    save("sparse_to_dense", points=gp, d0=d0, d1=d1, i0=i0, i1=i1, sparse0=f0, linear=ref_lin, out0=rd0, out1=rd1)
+
+    # ---------------------------------------------------------------- a18 procrustes
+    print("weighted_procrustes")
+    src = torch.randn(64, 40, 3, generator=g)
+    Rg = torch.linalg.qr(torch.randn(64, 3, 3, generator=g))[0]
+    Rg = Rg * torch.sign(torch.det(Rg)).reshape(-1, 1, 1)
+    refp = src @ Rg.transpose(1, 2) + torch.randn(64, 1, 3, generator=g) + 0.01 * torch.randn(64, 40, 3, generator=g)
+    w = torch.rand(64, 40, generator=g)
+    w[w < 0.3] = 0
+    Rr, tr = U.weighted_procrustes(src, refp, w.clone(), weight_thresh=0.001)
+    Rm, tm = R.weighted_procrustes(src, refp, w, thresh=0.001)
+    close(Rm, Rr, 1e-5, "procrustes R")
+    close(tm, tr, 1e-5, "procrustes t")
+    src3 = torch.randn(500, 3, 3, generator=g)
+    ref3 = src3 @ Rg[:1].transpose(1, 2) + 0.02 * torch.randn(500, 3, 3, generator=g)
+    R3, t3 = U.WeightedProcrustes()(src3, ref3, None)
+    Rm3, tm3 = R.weighted_procrustes(src3, ref3, None, thresh=0.5)
+    close(Rm3, R3, 1e-5, "procrustes (3 points) R")
+    save("weighted_procrustes", src=src, ref=refp, w=w, R=Rr, t=tr, src3=src3, ref3=ref3, R3=R3, t3=t3)
+
+    # ---------------------------------------------------------------- a17 / a20 pose heads
+    print("coarse Rt (constructed similarity)")
+    B, N = 2, 196
+    p2 = torch.stack([norm_cloud(N), norm_cloud(N)])
+    Rg2 = Rg[:B]
+    tg2 = 0.1 * torch.randn(B, 3, generator=g)
+    perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)])
+    # p1 = R p2 + t on matched rows, some rows unmatched (background)
+    p1 = torch.gather(p2, 1, perm.unsqueeze(2).expand(-1, -1, 3)) @ Rg2.transpose(1, 2) + tg2.unsqueeze(1)
+    p1 = p1 + 0.003 * torch.randn(B, N, 3, generator=g)
+    atten, score = constructed_similarity(perm, N, g, n_bg=40)
+    rand = torch.rand(B, 18000, generator=g)
+    _orig_rand = torch.rand
+    torch.rand = lambda *a, **k: rand.clone()
+    try:
+        Rr, tr, sr = U.compute_coarse_Rt_overlap(atten, score, p1, p2, None, 6000, 300)
+    finally:
+        torch.rand = _orig_rand
+    Rm, tm, sm, det = R.compute_coarse_rt_overlap(atten, score, p1, p2, rand, 6000, 300, detail=True)
+    close(Rm, Rr, 1e-5, "coarse R")
+    close(tm, tr, 1e-5, "coarse t")
+    close(sm, sr, 1e-3, "coarse pose score")
+    err = (Rr - Rg2).abs().max().item()
+    print(f"  coarse R vs ground truth: {err:.3e}")
+    save("coarse_rt", atten=atten, score=score, p1=p1, p2=p2, rand=rand, R=Rr, t=tr, pose_score=sr,
+         hyp_idx=det["idx"].to(torch.int32), R_gt=Rg2, t_gt=tg2)
+
+    print("fine Rt (constructed similarity)")
+    N = 300
+    p2 = torch.stack([norm_cloud(N), norm_cloud(N)])
+    perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)])
+    p1 = torch.gather(p2, 1, perm.unsqueeze(2).expand(-1, -1, 3)) @ Rg2.transpose(1, 2) + tg2.unsqueeze(1)
+    p1 = p1 + 0.003 * torch.randn(B, N, 3, generator=g)
+    atten, score = constructed_similarity(perm, N, g, n_bg=60)
+    Rr, tr, sr = U.compute_fine_Rt_overlap(atten, score, p1, p2, None)
+    Rm, tm, sm = R.compute_fine_rt_overlap(atten, score, p1, p2)
+    close(Rm, Rr, 1e-5, "fine R")
+    close(tm, tr, 1e-5, "fine t")
+    close(sm, sr, 1e-5, "fine pose score")
+    print(f"  fine R vs ground truth: {(Rr - Rg2).abs().max().item():.3e}")
+    save("fine_rt", atten=atten, score=score, p1=p1, p2=p2, R=Rr, t=tr, pose_score=sr, R_gt=Rg2, t_gt=tg2)
+
+    # ---------------------------------------------------------------- a16 coarse matcher module
+    print("coarse matcher (module, random weights)")
+    cm = CoarsePointMatchingOneRef(cfg.coarse_point_matching).eval()
+    cm.load_state_dict(sub_sd(sd, "coarse_point_matching"), strict=True)
+    B, n = 1, 196
+    sp1, sp2 = norm_cloud(n)[None], norm_cloud(n)[None]
+    sf1 = torch.randn(B, n, 256, generator=g)
+    sf2 = sf1[:, torch.randperm(n, generator=g)] + 0.1 * torch.randn(B, n, 256, generator=g)
+    l1 = torch.cat([torch.ones(B, 1, 3), R.get_batch_lrf(sp1)], 1)
+    l2 = torch.cat([torch.ones(B, 1, 3), R.get_batch_lrf(sp2)], 1)
+    ge1, ge2 = geo(l1), geo(l2)
+    rand = torch.rand(B, 18000, generator=g)
+    torch.rand = lambda *a, **k: rand.clone()
+    try:
+        ep = cm(sp1, sf1, ge1, sp2, sf2, ge2, torch.ones(B), {})
+    finally:
+        torch.rand = _orig_rand
+    Rm, tm, sm, det = R.coarse_point_matching(sp1, sf1, ge1, sp2, sf2, ge2, sd, "coarse_point_matching",
+                                              cfg.coarse_point_matching, rand, detail=True)
+    close(Rm, ep["init_R"], 1e-4, "coarse module R")
+    close(tm, ep["init_t"], 1e-4, "coarse module t")
+    save("coarse_matcher", p1=sp1, f1=sf1, lrf1=l1, p2=sp2, f2=sf2, lrf2=l2, rand=rand, R=ep["init_R"], t=ep["init_t"],
+         pose_score=ep["init_pose_score"], atten=det["atten"], score=det["score"])
+
+    # ---------------------------------------------------------------- a19 fine matcher module
+    print("fine matcher (module, random weights, 512 dense points)")
+    fm = FinePointMatchingOneRef(cfg.fine_point_matching).eval()
+    fm.load_state_dict(sub_sd(sd, "fine_point_matching"), strict=True)
+    nd = 512
+    dp1, dp2 = norm_cloud(nd)[None], norm_cloud(nd)[None]
+    df1 = torch.randn(1, nd, 256, generator=g)
+    df2 = torch.randn(1, nd, 256, generator=g)
+    fi1 = ext.furthest_point_sampling(dp1, 196)
+    fi2 = ext.furthest_point_sampling(dp2, 196)
+    ep = {"init_R": ep["init_R"], "init_t": ep["init_t"]}
+    R0, t0 = ep["init_R"].clone(), ep["init_t"].clone()
+    ep = fm(dp1, df1, ge1, fi1, dp2, df2, ge2, fi2, torch.ones(1), ep)
+    Rm, tm, sm, det = R.fine_point_matching(dp1, df1, ge1, fi1, dp2, df2, ge2, fi2, R0, t0, sd, "fine_point_matching",
+                                            cfg.fine_point_matching, ext, detail=True)
+    close(Rm, ep["pred_R"], 1e-4, "fine module R")
+    close(tm, ep["pred_t"], 1e-4, "fine module t")
+    save("fine_matcher", p1=dp1, f1=df1, lrf1=l1, i1=fi1, p2=dp2, f2=df2, lrf2=l2, i2=fi2, init_R=R0, init_t=t0,
+         R=ep["pred_R"], t=ep["pred_t"], pose_score=ep["pred_pose_score"],
+         f1_out=det["f1"][:, :64], f2_out=det["f2"][:, :64], score=det["score"],
+         atten_rowsum=det["atten"].sum(2), atten_colsum=det["atten"].sum(1))
+
+    # ---------------------------------------------------------------- pos-embed resampling
+    print("interpolate_pos_embed")
+    pos = torch.randn(1, 37 * 37, 8, generator=g)
+
+    class _M:
+        pass
+
+    m = _M()
+    m.patch_embed = _M()
+    m.patch_embed.num_patches = 256
+    m.pos_embed = torch.zeros(1, 256, 8)
+    ck = {"pos_embed": pos.clone()}
+    U.interpolate_pos_embed(m, ck)
+    save("interpolate_pos_embed", src=pos, out=ck["pos_embed"])
+
+    # ---------------------------------------------------------------- a10 + a22 full forward
+    print("UNOPose.forward (full size, B=1, random weights, ViT = oracle restatement)")
+    from core.unopose.model.oneref_grf_predator_pose_estimation_model import UNOPose
+
+    cfg_ref = R.default_cfg(feature_extraction=dict(freeze_vit=False))
+    model = UNOPose(cfg_ref).eval()
+    model.load_state_dict(sd, strict=True)  # pins the whole key layout (App-C)
+    q = object_cloud(g, 2048)
+    tcloud = object_cloud(g, 5000)
+    end_points = dict(
+        pts=q[None], tem1_pts=tcloud[None],
+        rgb=torch.randn(1, 3, 224, 224, generator=g), tem1_rgb=torch.randn(1, 3, 224, 224, generator=g),
+        rgb_choose=torch.randint(0, 224 * 224, (1, 2048), generator=g),
+        tem1_choose=torch.randint(0, 224 * 224, (1, 5000), generator=g),
+    )
+    rand = torch.rand(1, 18000, generator=g)
+    torch.rand = lambda *a, **k: rand.clone()
+    try:
+        out = model(dict(end_points))
+    finally:
+        torch.rand = _orig_rand
+    mine = R.unopose_forward(end_points, sd, cfg_ref, rand, ext, detail=True)
+    taps_ref = model.feature_extraction.rgb_net.vit(end_points["rgb"])
+    taps_mine = R.vit_taps(end_points["rgb"], sd, "feature_extraction.rgb_net.vit")
+    for a, b in zip(taps_mine, taps_ref):
+        close(a, b, 1e-4, "ViT taps (functional oracle vs module stand-in; NOT timm)")
+    for k in ("init_R", "init_t", "pred_R", "pred_t"):
+        close(mine[k], out[k], 2e-4, f"forward {k}")
+    # ViT_AE post-processing alone (reference code around the stubbed ViT)
+    dense = model.feature_extraction.get_img_feats(end_points["rgb"], end_points["rgb_choose"])
+    close(mine["dense_fm"], dense, 1e-4, "ViT_AE post-processing + pixel gather")
+    save("forward_full", **{k: v for k, v in end_points.items()}, rand=rand,
+         **{k: out[k] for k in ("init_R", "init_t", "init_pose_score", "pred_R", "pred_t", "pred_pose_score")},
+         fps_idx_m=mine["fps_idx_m"], fps_idx_o=mine["fps_idx_o"], radius=mine["radius"],
+         dense_fm_head=dense[:, :64])
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

@@ -46,3 +46,28 @@ def object_cloud(gen, n, with_replacement=False):
         sel = torch.randint(0, max(8, n // 5), (n,), generator=gen)
         p = p[sel]
     return p.float().contiguous()
+
+
+def constructed_similarity(perm, N, gen, n_bg=40, hi=8.0, noise=1.5):
+    """A (B,N+1,N+1) similarity (cosine / temp scale) whose row 1+i matches column
+    1+perm[b,i]; the last `n_bg` rows (and their partner columns) match the
+    background token 0 instead.  Returns (atten, score (B,2N) in (0,1)).
+    Needed because random weights give all-background assignments."""
+    B = perm.shape[0]
+    atten = noise * (torch.rand(B, N + 1, N + 1, generator=gen) * 2 - 1)
+    score = torch.empty(B, 2 * N)
+    for b in range(B):
+        s1 = 0.8 + 0.19 * torch.rand(N, generator=gen)
+        s2 = 0.8 + 0.19 * torch.rand(N, generator=gen)
+        for i in range(N):
+            j = int(perm[b, i])
+            if i < N - n_bg:
+                atten[b, 1 + i, 1 + j] = hi + torch.rand((), generator=gen)
+            else:
+                atten[b, 1 + i, 0] = hi + torch.rand((), generator=gen)
+                atten[b, 0, 1 + j] = hi + torch.rand((), generator=gen)
+                s1[i] = 0.05 + 0.1 * torch.rand((), generator=gen)
+                s2[j] = 0.05 + 0.1 * torch.rand((), generator=gen)
+        score[b, :N] = s1
+        score[b, N:] = s2
+    return atten, score

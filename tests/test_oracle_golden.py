@@ -1,0 +1,125 @@
+"""CPU: oracle/unopose_ref.py against the golden fixtures captured from the reference
+(tests/golden/make_golden.py).  Does not read /root/reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unopose_ref as R
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    return {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return R.random_state_dict(R.default_cfg(), seed=0, prefix=None)
+
+
+@pytest.fixture(scope="module")
+def cfg():
+    return R.default_cfg()
+
+
+def close(a, b, tol):
+    assert (a.float() - b.float()).abs().max().item() <= tol
+
+
+def test_lrf_global():
+    z = load("lrf_global")
+    close(R.get_batch_lrf(z["pts"]), z["out"], 2e-5)
+
+
+@pytest.mark.parametrize("name", ["query_lrf_group_r0.2_ns32", "query_lrf_group_r0.4_ns64"])
+def test_query_lrf_group(oracle_ext, name):
+    z = load(name)
+    close(R.query_and_lrf_group(z["xyz"], z["radius"], z["nsample"], oracle_ext), z["out"], 5e-4)
+
+
+def test_positional_encoding(oracle_ext, sd, cfg):
+    z = load("positional_encoding")
+    pcfg = R.Cfg(dict(cfg.fine_point_matching, pe_radius1=z["r1"], pe_radius2=z["r2"], nsample1=z["ns1"], nsample2=z["ns2"]))
+    close(R.positional_encoding(z["xyz"], sd, "fine_point_matching.PE", pcfg, oracle_ext), z["out"], 2e-3)
+
+
+def test_geo_embedding(sd, cfg):
+    z = load("geo_embedding")
+    d, a = R.geo_embedding_indices(z["points"], cfg.geo_embedding)
+    close(d, z["d_idx"], 1e-5)
+    close(a, z["a_idx"], 1e-4)
+    close(R.geo_embedding(z["points"], sd, "geo_embedding", cfg.geo_embedding), z["out"], 1e-4)
+
+
+def test_transformer_layers(sd, cfg):
+    z = load("transformer_layers")
+    geo = R.geo_embedding(z["points"], sd, "geo_embedding", cfg.geo_embedding)
+    tp = "coarse_point_matching.transformers.0"
+    close(R.transformer_layer(z["f0"], z["f0"], sd, tp + ".layers.0", embed=geo[0:1]), z["rpe_self"], 5e-5)
+    close(R.transformer_layer(z["f0"], z["f1"], sd, tp + ".layers.1"), z["cross"], 5e-5)
+    m0, m1 = R.geometric_transformer(z["f0"], geo[0:1], z["f1"], geo[1:2], sd, tp)
+    close(m0, z["gt0"], 1e-4)
+    close(m1, z["gt1"], 1e-4)
+
+
+def test_sparse_to_dense(oracle_ext, sd, cfg):
+    z = load("sparse_to_dense")
+    geo = R.geo_embedding(z["points"], sd, "geo_embedding", cfg.geo_embedding)
+    sp = "fine_point_matching.transformers.0"
+    close(R.linear_transformer_layer(z["d0"][:, 1:].contiguous(), z["sparse0"][:, 1:].contiguous(), sd, sp + ".dense_layer"),
+          z["linear"], 1e-4)
+    m0, m1 = R.sparse_to_dense_transformer(z["d0"], geo[0:1], z["i0"], z["d1"], geo[1:2], z["i1"], sd, sp, oracle_ext)
+    close(m0, z["out0"], 2e-4)
+    close(m1, z["out1"], 2e-4)
+
+
+def test_weighted_procrustes():
+    z = load("weighted_procrustes")
+    Rm, tm = R.weighted_procrustes(z["src"], z["ref"], z["w"], thresh=0.001)
+    close(Rm, z["R"], 1e-5)
+    close(tm, z["t"], 1e-5)
+    Rm, tm = R.weighted_procrustes(z["src3"], z["ref3"], None, thresh=0.5)
+    close(Rm, z["R3"], 1e-5)
+    close(tm, z["t3"], 1e-5)
+
+
+def test_coarse_rt():
+    z = load("coarse_rt")
+    Rm, tm, sm, det = R.compute_coarse_rt_overlap(z["atten"], z["score"], z["p1"], z["p2"], z["rand"], detail=True)
+    assert torch.equal(det["idx"].to(torch.int32), z["hyp_idx"])
+    close(Rm, z["R"], 1e-5)
+    close(tm, z["t"], 1e-5)
+    close(sm, z["pose_score"], 1e-3)
+    close(Rm, z["R_gt"], 5e-3)  # the constructed problem is actually solved
+
+
+def test_fine_rt():
+    z = load("fine_rt")
+    Rm, tm, sm = R.compute_fine_rt_overlap(z["atten"], z["score"], z["p1"], z["p2"])
+    close(Rm, z["R"], 1e-5)
+    close(tm, z["t"], 1e-5)
+    close(sm, z["pose_score"], 1e-5)
+    close(Rm, z["R_gt"], 5e-3)
+
+
+def test_coarse_matcher(sd, cfg):
+    z = load("coarse_matcher")
+    g1 = R.geo_embedding(z["lrf1"], sd, "geo_embedding", cfg.geo_embedding)
+    g2 = R.geo_embedding(z["lrf2"], sd, "geo_embedding", cfg.geo_embedding)
+    Rm, tm, sm, det = R.coarse_point_matching(z["p1"], z["f1"], g1, z["p2"], z["f2"], g2, sd, "coarse_point_matching",
+                                              cfg.coarse_point_matching, z["rand"], detail=True)
+    close(det["atten"], z["atten"], 1e-3)
+    close(det["score"], z["score"], 1e-4)
+    close(Rm, z["R"], 1e-4)
+    close(tm, z["t"], 1e-4)
+
+
+def test_state_dict_layout_counts(sd):
+    n_coarse = sum(v.numel() for k, v in sd.items() if k.startswith("coarse_point_matching"))
+    n_fine = sum(v.numel() for k, v in sd.items()
+                 if k.startswith("fine_point_matching") and "running" not in k and "tracked" not in k)
+    assert n_coarse == 3492611 and n_fine == 5163782
