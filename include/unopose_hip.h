@@ -101,6 +101,30 @@ int unopose_three_interpolate_grad(const float *grad_out, const int32_t *idx,
                                    int m, float *grad_points,
                                    unopose_stream_t stream);
 
+/* ------------------------------------------------------------------ Part 2 */
+
+/* Global local-reference-frame coordinates of a cloud: pts (B,N,3) -> out (B,N,3).
+ * Replaces UNOPose.get_batch_lrf + LRF.forward
+ * (core/unopose/model/oneref_grf_predator_pose_estimation_model.py:78-93,
+ *  core/unopose/utils/model_utils.py:766-823).  use_ref_rad != 0 -> r = 1. */
+int unopose_lrf_global(const float *pts, int B, int N, int use_ref_rad,
+                       float *out, unopose_stream_t stream);
+
+/* QueryAndLRFGroup.forward with use_xyz=True, use_feature=False, new_xyz == xyz:
+ * xyz (B,N,3) -> out (B,6,N,S), channels [p_k - c (3), R^T (p_k - c)/radius (3)].
+ * Fuses ball_query + group_points + LRF_batch
+ * (core/unopose/model/pointnet2/pointnet2_utils.py:429-481, 522-584). */
+int unopose_query_lrf_group(const float *xyz, int B, int N, float radius,
+                            int nsample, float *out, unopose_stream_t stream);
+
+/* weighted_procrustes(src (M,N,3), ref (M,N,3), w (M,N) or NULL) -> R (M,3,3),
+ * t (M,3) with ref ~ R src + t.  Replaces
+ * core/unopose/utils/model_utils.py:667-743 (torch.svd -> register Jacobi). */
+int unopose_weighted_procrustes(const float *src, const float *ref,
+                                const float *w, int M, int N, float thresh,
+                                float eps, float *R, float *t,
+                                unopose_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

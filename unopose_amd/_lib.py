@@ -30,6 +30,9 @@ SIGNATURES = {
     "unopose_three_nn": [_P, _P, _I, _I, _I, _P, _P, _P],
     "unopose_three_interpolate": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "unopose_three_interpolate_grad": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "unopose_lrf_global": [_P, _I, _I, _I, _P, _P],
+    "unopose_query_lrf_group": [_P, _I, _I, _F, _I, _P, _P],
+    "unopose_weighted_procrustes": [_P, _P, _P, _I, _I, _F, _F, _P, _P, _P],
 }
 
 

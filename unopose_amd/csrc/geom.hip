@@ -1,0 +1,369 @@
+// Geometry operators of UNOPose's forward hot path for gfx950, C ABI part 2:
+//   * unopose_lrf_global        -- LRF.forward + get_batch_lrf
+//                                  (utils/model_utils.py:766-823, model/..._pose_estimation_model.py:78-93)
+//   * unopose_query_lrf_group   -- QueryAndLRFGroup.forward = ball_query + group + LRF_batch
+//                                  (pointnet2/pointnet2_utils.py:429-481, 522-584) in ONE kernel:
+//                                  the neighbour list never leaves LDS.
+//   * unopose_weighted_procrustes -- weighted_procrustes (utils/model_utils.py:667-743)
+// All 3x3 eigen / singular problems are solved by Jacobi rotations in registers
+// (jacobi3.h) instead of torch.svd.
+#include "common.h"
+#include "jacobi3.h"
+
+namespace unopose {
+
+__device__ __forceinline__ float block_sum_256(float v, float *red /*[4]*/) {
+  v = wave_sum_f32(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max_256(float v, float *red) {
+  v = wave_max_f32(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// Frame construction shared by the global and the per-point LRF, given
+//   z  : sign-resolved normal,  acc : sum_i alpha_i beta_i v_i  (model_utils.py:804-812)
+__device__ __forceinline__ void finish_frame(Vec3 z, Vec3 acc, Vec3 &xp, Vec3 &yp) {
+  const float n = sqrtf(dot(acc, acc)) + 1e-10f;
+  xp = scale(acc, 1.f / n);
+  yp = cross(xp, z);
+}
+
+// ------------------------------------------------------------ global LRF ----
+__global__ __launch_bounds__(256) void lrf_global_kernel(const float *__restrict__ pts, int N,
+                                                         float *__restrict__ out, int use_ref_rad) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const float *P = pts + (size_t)blockIdx.x * N * 3;
+  float *O = out + (size_t)blockIdx.x * N * 3;
+  float sx = 0, sy = 0, sz = 0;
+  for (int i = tid; i < N; i += 256) {
+    sx += P[i * 3 + 0];
+    sy += P[i * 3 + 1];
+    sz += P[i * 3 + 2];
+  }
+  const float inv_n = 1.f / (float)N;
+  const float cx = block_sum_256(sx, red) * inv_n;
+  const float cy = block_sum_256(sy, red) * inv_n;
+  const float cz = block_sum_256(sz, red) * inv_n;
+
+  float a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0, rmax = 0;
+  for (int i = tid; i < N; i += 256) {
+    const float x = cx - P[i * 3 + 0], y = cy - P[i * 3 + 1], z = cz - P[i * 3 + 2];
+    a00 += x * x; a01 += x * y; a02 += x * z; a11 += y * y; a12 += y * z; a22 += z * z;
+    rmax = fmaxf(rmax, sqrtf(x * x + y * y + z * z));
+  }
+  a00 = block_sum_256(a00, red) * inv_n;
+  a01 = block_sum_256(a01, red) * inv_n;
+  a02 = block_sum_256(a02, red) * inv_n;
+  a11 = block_sum_256(a11, red) * inv_n;
+  a12 = block_sum_256(a12, red) * inv_n;
+  a22 = block_sum_256(a22, red) * inv_n;
+  const float r = use_ref_rad ? 1.f : block_max_256(rmax, red);
+
+  Vec3 e0, e1, z0;
+  float l0, l1, l2;
+  eig_sym3(a00, a01, a02, a11, a12, a22, e0, e1, z0, l0, l1, l2);
+
+  float vote = 0;
+  for (int i = tid; i < N; i += 256) {
+    const float x = cx - P[i * 3 + 0], y = cy - P[i * 3 + 1], z = cz - P[i * 3 + 2];
+    const float pr = z0.x * x + z0.y * y + z0.z * z;
+    vote += (pr > 1e-3f ? 1.f : 0.f) - (pr < -1e-3f ? 1.f : 0.f);
+  }
+  vote = block_sum_256(vote, red);
+  const Vec3 zp = vote < 0.f ? scale(z0, -1.f) : z0;
+
+  float vx = 0, vy = 0, vz = 0;
+  for (int i = tid; i < N; i += 256) {
+    const Vec3 xn = v3(P[i * 3 + 0] - cx, P[i * 3 + 1] - cy, P[i * 3 + 2] - cz);
+    const float nrm = dot(zp, xn);
+    const Vec3 vi = sub(xn, scale(zp, nrm));
+    float alpha = r - sqrtf(dot(xn, xn));
+    alpha *= alpha;
+    const float ab = alpha * (nrm * nrm);
+    vx += ab * vi.x; vy += ab * vi.y; vz += ab * vi.z;
+  }
+  vx = block_sum_256(vx, red);
+  vy = block_sum_256(vy, red);
+  vz = block_sum_256(vz, red);
+  Vec3 xp, yp;
+  finish_frame(zp, v3(vx, vy, vz), xp, yp);
+  for (int i = tid; i < N; i += 256) {
+    const Vec3 q = v3((P[i * 3 + 0] - cx) / r, (P[i * 3 + 1] - cy) / r, (P[i * 3 + 2] - cz) / r);
+    O[i * 3 + 0] = dot(xp, q);
+    O[i * 3 + 1] = dot(yp, q);
+    O[i * 3 + 2] = dot(zp, q);
+  }
+}
+
+// -------------------------------------- fused ball_query + group + LRF ------
+// One wavefront per centre.  LDS: SoA copy of the cloud + one neighbour list per wave.
+// out (B,6,N,S): channels 0-2 = p_k - c (un-normalised), 3-5 = R^T (p_k - c) / radius
+// (pointnet2_utils.py:567 channel order).
+__global__ __launch_bounds__(256) void query_lrf_group_kernel(const float *__restrict__ xyz, int N, float radius,
+                                                              int S, int cpw, float *__restrict__ out) {
+  extern __shared__ float4 smem4[];
+  float *sx = reinterpret_cast<float *>(smem4);
+  float *sy = sx + N, *sz = sy + N;
+  int *nbr_all = reinterpret_cast<int *>(sz + N);
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int *nbr = nbr_all + wave * S;
+  const float *P = xyz + (size_t)b * N * 3;
+  for (int e = tid; e < N * 3; e += 256) {
+    const float v = P[e];
+    const int p = e / 3, comp = e - p * 3;
+    (comp == 0 ? sx : comp == 1 ? sy : sz)[p] = v;
+  }
+  __syncthreads();
+  const float r2 = radius * radius;
+  const float inv_r = 1.f / radius;  // NB reference divides; see below (division kept for parity)
+  (void)inv_r;
+  const size_t chan = (size_t)N * S;
+  float *O = out + (size_t)b * 6 * chan;
+
+  for (int ci = 0; ci < cpw; ++ci) {
+    const int j = (blockIdx.x * 4 + wave) * cpw + ci;
+    if (j >= N) break;  // wave-uniform
+    const float cx = sx[j], cy = sy[j], cz = sz[j];
+    // ---- ball query: first S hits in index order, tail padded with the first hit
+    int cnt = 0, first = 0;
+    for (int k0 = 0; k0 < N && cnt < S; k0 += 64) {
+      const int k = k0 + lane;
+      bool hit = false;
+      if (k < N) {
+        const float x = sx[k], y = sy[k], z = sz[k];
+        const float d2 = (cx - x) * (cx - x) + (cy - y) * (cy - y) + (cz - z) * (cz - z);
+        hit = d2 < r2;
+      }
+      const unsigned long long mask = __ballot(hit);
+      if (mask) {
+        const int pre =
+            (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        const int pos = cnt + pre;
+        if (hit && pos < S) nbr[pos] = k;
+        if (cnt == 0) first = k0 + __builtin_ctzll(mask);
+        cnt += __builtin_popcountll(mask);
+      }
+    }
+    for (int l = min(cnt, S) + lane; l < S; l += 64) nbr[l] = first;  // cnt == 0 -> index 0 (zero row)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- covariance of x = c - p_k over the S (padded) neighbours
+    float a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+    for (int l = lane; l < S; l += 64) {
+      const int k = nbr[l];
+      const float x = cx - sx[k], y = cy - sy[k], z = cz - sz[k];
+      a00 += x * x; a01 += x * y; a02 += x * z; a11 += y * y; a12 += y * z; a22 += z * z;
+    }
+    const float inv_s = 1.f / (float)S;
+    a00 = wave_sum_f32(a00) * inv_s;
+    a01 = wave_sum_f32(a01) * inv_s;
+    a02 = wave_sum_f32(a02) * inv_s;
+    a11 = wave_sum_f32(a11) * inv_s;
+    a12 = wave_sum_f32(a12) * inv_s;
+    a22 = wave_sum_f32(a22) * inv_s;
+    Vec3 e0, e1, z0;
+    float l0, l1, l2;
+    eig_sym3(a00, a01, a02, a11, a12, a22, e0, e1, z0, l0, l1, l2);
+
+    int vote = 0;
+    for (int l0i = 0; l0i < S; l0i += 64) {
+      const int l = l0i + lane;
+      float pr = 0.f;
+      if (l < S) {
+        const int k = nbr[l];
+        pr = z0.x * (cx - sx[k]) + z0.y * (cy - sy[k]) + z0.z * (cz - sz[k]);
+      }
+      vote += __builtin_popcountll(__ballot(pr > 1e-3f)) - __builtin_popcountll(__ballot(pr < -1e-3f));
+    }
+    const Vec3 zp = vote < 0 ? scale(z0, -1.f) : z0;
+
+    float vx = 0, vy = 0, vz = 0;
+    for (int l = lane; l < S; l += 64) {
+      const int k = nbr[l];
+      const Vec3 xn = v3(sx[k] - cx, sy[k] - cy, sz[k] - cz);
+      const float nrm = dot(zp, xn);
+      const Vec3 vi = sub(xn, scale(zp, nrm));
+      float alpha = radius - sqrtf(dot(xn, xn));
+      alpha *= alpha;
+      const float ab = alpha * (nrm * nrm);
+      vx += ab * vi.x; vy += ab * vi.y; vz += ab * vi.z;
+    }
+    vx = wave_sum_f32(vx);
+    vy = wave_sum_f32(vy);
+    vz = wave_sum_f32(vz);
+    Vec3 xp, yp;
+    finish_frame(zp, v3(vx, vy, vz), xp, yp);
+
+    float *row = O + (size_t)j * S;
+    for (int l = lane; l < S; l += 64) {
+      const int k = nbr[l];
+      const Vec3 d = v3(sx[k] - cx, sy[k] - cy, sz[k] - cz);
+      const Vec3 q = v3(d.x / radius, d.y / radius, d.z / radius);
+      row[l] = d.x;
+      row[chan + l] = d.y;
+      row[2 * chan + l] = d.z;
+      row[3 * chan + l] = dot(xp, q);
+      row[4 * chan + l] = dot(yp, q);
+      row[5 * chan + l] = dot(zp, q);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// -------------------------------------------------- weighted Procrustes -----
+// R, t with ref ~ R src + t (model_utils.py:667-743).  One wavefront per problem.
+__global__ __launch_bounds__(256) void procrustes_wave_kernel(const float *__restrict__ src,
+                                                              const float *__restrict__ ref,
+                                                              const float *__restrict__ w, int M, int N, float thresh,
+                                                              float eps, float *__restrict__ Rout,
+                                                              float *__restrict__ tout) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float *S = src + (size_t)m * N * 3;
+  const float *Rf = ref + (size_t)m * N * 3;
+  const float *W = w ? w + (size_t)m * N : nullptr;
+  float ws = 0;
+  for (int i = lane; i < N; i += 64) {
+    float wi = W ? W[i] : 1.f;
+    wi = wi < thresh ? 0.f : wi;
+    ws += wi;
+  }
+  const float inv = 1.f / (wave_sum_f32(ws) + eps);
+  float s0 = 0, s1 = 0, s2 = 0, r0 = 0, r1 = 0, r2 = 0;
+  for (int i = lane; i < N; i += 64) {
+    float wi = W ? W[i] : 1.f;
+    wi = (wi < thresh ? 0.f : wi) * inv;
+    s0 += S[i * 3 + 0] * wi; s1 += S[i * 3 + 1] * wi; s2 += S[i * 3 + 2] * wi;
+    r0 += Rf[i * 3 + 0] * wi; r1 += Rf[i * 3 + 1] * wi; r2 += Rf[i * 3 + 2] * wi;
+  }
+  s0 = wave_sum_f32(s0); s1 = wave_sum_f32(s1); s2 = wave_sum_f32(s2);
+  r0 = wave_sum_f32(r0); r1 = wave_sum_f32(r1); r2 = wave_sum_f32(r2);
+  float h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = lane; i < N; i += 64) {
+    float wi = W ? W[i] : 1.f;
+    wi = (wi < thresh ? 0.f : wi) * inv;
+    const float a0 = S[i * 3 + 0] - s0, a1 = S[i * 3 + 1] - s1, a2 = S[i * 3 + 2] - s2;
+    const float b0 = wi * (Rf[i * 3 + 0] - r0), b1 = wi * (Rf[i * 3 + 1] - r1), b2 = wi * (Rf[i * 3 + 2] - r2);
+    h[0] += a0 * b0; h[1] += a0 * b1; h[2] += a0 * b2;
+    h[3] += a1 * b0; h[4] += a1 * b1; h[5] += a1 * b2;
+    h[6] += a2 * b0; h[7] += a2 * b1; h[8] += a2 * b2;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) h[i] = wave_sum_f32(h[i]);
+  float R[9];
+  kabsch_from_H(h, R);
+  if (lane == 0) {
+    float *Ro = Rout + (size_t)m * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Ro[i] = R[i];
+    float *to = tout + (size_t)m * 3;
+    to[0] = r0 - (R[0] * s0 + R[1] * s1 + R[2] * s2);
+    to[1] = r1 - (R[3] * s0 + R[4] * s1 + R[5] * s2);
+    to[2] = r2 - (R[6] * s0 + R[7] * s1 + R[8] * s2);
+  }
+}
+
+// One THREAD per problem for tiny N (the 3-point hypotheses of the coarse stage).
+template <int NP>
+__global__ __launch_bounds__(256) void procrustes_thread_kernel(const float *__restrict__ src,
+                                                                const float *__restrict__ ref,
+                                                                const float *__restrict__ w, int M, float thresh,
+                                                                float eps, float *__restrict__ Rout,
+                                                                float *__restrict__ tout) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const float *S = src + (size_t)m * NP * 3;
+  const float *Rf = ref + (size_t)m * NP * 3;
+  float wi[NP], ws = 0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    float x = w ? w[(size_t)m * NP + i] : 1.f;
+    wi[i] = x < thresh ? 0.f : x;
+    ws += wi[i];
+  }
+  const float inv = 1.f / (ws + eps);
+  float s0 = 0, s1 = 0, s2 = 0, r0 = 0, r1 = 0, r2 = 0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    wi[i] *= inv;
+    s0 += S[i * 3 + 0] * wi[i]; s1 += S[i * 3 + 1] * wi[i]; s2 += S[i * 3 + 2] * wi[i];
+    r0 += Rf[i * 3 + 0] * wi[i]; r1 += Rf[i * 3 + 1] * wi[i]; r2 += Rf[i * 3 + 2] * wi[i];
+  }
+  float h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const float a0 = S[i * 3 + 0] - s0, a1 = S[i * 3 + 1] - s1, a2 = S[i * 3 + 2] - s2;
+    const float b0 = wi[i] * (Rf[i * 3 + 0] - r0), b1 = wi[i] * (Rf[i * 3 + 1] - r1),
+                b2 = wi[i] * (Rf[i * 3 + 2] - r2);
+    h[0] += a0 * b0; h[1] += a0 * b1; h[2] += a0 * b2;
+    h[3] += a1 * b0; h[4] += a1 * b1; h[5] += a1 * b2;
+    h[6] += a2 * b0; h[7] += a2 * b1; h[8] += a2 * b2;
+  }
+  float R[9];
+  kabsch_from_H(h, R);
+  float *Ro = Rout + (size_t)m * 9;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Ro[i] = R[i];
+  float *to = tout + (size_t)m * 3;
+  to[0] = r0 - (R[0] * s0 + R[1] * s1 + R[2] * s2);
+  to[1] = r1 - (R[3] * s0 + R[4] * s1 + R[5] * s2);
+  to[2] = r2 - (R[6] * s0 + R[7] * s1 + R[8] * s2);
+}
+
+}  // namespace unopose
+
+using namespace unopose;
+
+extern "C" {
+
+int unopose_lrf_global(const float *pts, int B, int N, int use_ref_rad, float *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(pts && out, "lrf_global: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && N >= 1, "lrf_global: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  hipLaunchKernelGGL(lrf_global_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pts, N, out, use_ref_rad);
+  return check_launch("lrf_global");
+}
+
+int unopose_query_lrf_group(const float *xyz, int B, int N, float radius, int nsample, float *out,
+                            unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(xyz && out, "query_lrf_group: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && N >= 1 && nsample >= 1 && B <= 65535, "query_lrf_group: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  const size_t lds = ((size_t)3 * N + 4 * (size_t)nsample) * 4;
+  UNOPOSE_REQUIRE(lds <= 64 * 1024, "query_lrf_group: N=%d nsample=%d exceed the 64 KiB LDS tile", N, nsample);
+  const long centres = (long)B * N;
+  int cpw = centres >= 65536 ? 8 : centres >= 16384 ? 4 : centres >= 4096 ? 2 : 1;
+  dim3 grid(cdiv(N, 4 * cpw), B);
+  hipLaunchKernelGGL(query_lrf_group_kernel, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius, nsample, cpw,
+                     out);
+  return check_launch("query_lrf_group");
+}
+
+int unopose_weighted_procrustes(const float *src, const float *ref, const float *w, int M, int N, float thresh,
+                                float eps, float *R, float *t, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(src && ref && R && t, "weighted_procrustes: null pointer");
+  UNOPOSE_REQUIRE(M >= 0 && N >= 1, "weighted_procrustes: bad sizes");
+  if (M == 0) return UNOPOSE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 3) {
+    hipLaunchKernelGGL(procrustes_thread_kernel<3>, dim3(cdiv(M, 256)), dim3(256), 0, s, src, ref, w, M, thresh, eps,
+                       R, t);
+  } else {
+    hipLaunchKernelGGL(procrustes_wave_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, src, ref, w, M, N, thresh, eps, R,
+                       t);
+  }
+  return check_launch("weighted_procrustes");
+}
+
+}  // extern "C"
