@@ -1,0 +1,362 @@
+"""Building blocks of the MI355X UNOPose model.
+
+Parameter containers mirror the reference's module tree so ``state_dict`` keys are
+identical; the arithmetic is re-expressed around fused HIP
+operators (``unopose_amd.ops``) where the reference uses op-by-op PyTorch.
+References: T = core/unopose/model/transformer.py, F = .../oneref_feature_extraction.py,
+Fi = .../oneref_predator_fine_point_matching.py, U = core/unopose/utils/model_utils.py.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+# ------------------------------------------------------------------ ViT -----
+class _Attention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.heads = heads
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, T, C = x.shape
+        qkv = self.qkv(x)
+        o = ops.vit_attention(qkv, self.heads)  # (B,T,C): softmax(q k^T / sqrt(hd)) v per head
+        return self.proj(o)
+
+
+class _LayerScale(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.full((dim,), 1e-5))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, ratio=4):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, ratio * dim)
+        self.fc2 = nn.Linear(ratio * dim, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim, heads)
+        self.ls1 = _LayerScale(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim)
+        self.ls2 = _LayerScale(dim)
+
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x)) * self.ls1.gamma
+        return x + self.mlp(self.norm2(x)) * self.ls2.gamma
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, dim, patch):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, patch, patch)
+
+
+class ViT(nn.Module):
+    """DINOv2 ViT (reg4, no_embed_class) with timm 0.9.12's state_dict keys; forward returns the four
+    tapped, final-normed token maps like the reference subclass (F:24-42).  Accepts any S % 14 == 0 as
+    long as ``pos_embed`` has (S/14)^2 rows (the reference is fixed to 224: F:62-63)."""
+
+    def __init__(self, embed_dim=768, depth=12, num_heads=12, patch_size=14, img_size=224, reg_tokens=4):
+        super().__init__()
+        self.patch_size, self.depth = patch_size, depth
+        self.patch_embed = _PatchEmbed(embed_dim, patch_size)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.reg_token = nn.Parameter(torch.zeros(1, reg_tokens, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, (img_size // patch_size) ** 2, embed_dim))
+        self.blocks = nn.ModuleList([_Block(embed_dim, num_heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.head = nn.Linear(embed_dim, 1000)  # unused; kept so released checkpoints load strictly
+
+    def forward(self, x):
+        B = x.shape[0]
+        p = self.patch_size
+        # patch conv 14x14/14 as one GEMM: (B, P, 3*14*14) @ W^T
+        gh, gw = x.shape[2] // p, x.shape[3] // p
+        patches = x.reshape(B, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, 3 * p * p)
+        w = self.patch_embed.proj.weight.reshape(self.patch_embed.proj.weight.shape[0], -1)
+        x = F.linear(patches, w, self.patch_embed.proj.bias)
+        x = x + self.pos_embed
+        x = torch.cat([self.cls_token.expand(B, -1, -1).to(x.dtype), self.reg_token.expand(B, -1, -1).to(x.dtype), x], 1)
+        n = self.depth // 4
+        taps = {self.depth - 1, self.depth - n - 1, self.depth - 2 * n - 1, self.depth - 3 * n - 1}
+        outs = []
+        for i, blk in enumerate(self.blocks):
+            x = blk(x)
+            if i in taps:
+                outs.append(self.norm(x))
+        return outs
+
+
+def interpolate_pos_embed(pos_embed_ckpt, new_side):
+    """Non-antialiased bicubic resampling of a square patch pos-embed (U:105-134). (1,P0,C)->(1,P1,C)."""
+    P0, C = pos_embed_ckpt.shape[-2:]
+    s0 = int(P0 ** 0.5)
+    if s0 == new_side:
+        return pos_embed_ckpt
+    t = pos_embed_ckpt.reshape(-1, s0, s0, C).permute(0, 3, 1, 2)
+    t = F.interpolate(t, size=(new_side, new_side), mode="bicubic", align_corners=False)
+    return t.permute(0, 2, 3, 1).flatten(1, 2)
+
+
+class ViT_AE(nn.Module):
+    """F:45-236 (``up_type="linear"``, pyramid features).  ``pixel_features`` never materialises the
+    (B,256,S,S) map: bilinear interpolation commutes with the pixel gather."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        assert cfg.up_type == "linear" and cfg.use_pyramid_feat, "only the configured variant is built"
+        assert "reg4" in cfg.vit_type and "patch14" in cfg.vit_type
+        dims = {"vit_small": (384, 12, 6), "vit_base": (768, 12, 12), "vit_large": (1024, 24, 16)}
+        D, depth, heads = dims[cfg.vit_type[:cfg.vit_type.index("_patch")]]
+        assert D == cfg.embed_dim
+        self.out_dim = cfg.out_dim
+        self.img_size = cfg.get("img_size", 224)
+        self.vit = ViT(D, depth, heads, 14, self.img_size)
+        self.output_upscaling = nn.Linear(4 * D, 16 * cfg.out_dim, bias=True)
+        if cfg.get("pretrained", False):
+            self.load_dinov2(cfg.vit_ckpt)
+
+    def load_dinov2(self, path):
+        """F:173-192: checkpoint = {"model": timm_state_dict}; pos_embed resampled as the reference does."""
+        ck = torch.load(path, map_location="cpu")["model"]
+        sd = self.vit.state_dict()
+        for k in ("head.weight", "head.bias"):
+            if k in ck and ck[k].shape != sd[k].shape:
+                del ck[k]
+        if "pos_embed" in ck:
+            ck["pos_embed"] = interpolate_pos_embed(ck["pos_embed"], self.img_size // 14)
+        self.vit.load_state_dict(ck, strict=False)
+
+    def lowres_map(self, x):
+        """(B,3,S,S) -> channels-last low-res feature map (B, 4S/14, 4S/14, 256)."""
+        B, _, H, W = x.shape
+        side = H // 14
+        outs = self.vit(x)
+        z = torch.cat([o[:, 5:, :] for o in outs], dim=2)
+        z = self.output_upscaling(z).reshape(B, side, side, 4, 4, self.out_dim)
+        return z.permute(0, 1, 3, 2, 4, 5).reshape(B, 4 * side, 4 * side, self.out_dim), (H, W)
+
+    def pixel_features(self, x, choose):
+        low, (H, W) = self.lowres_map(x)
+        return ops.bilinear_sample_pixels(low, choose, H, W)
+
+
+class ViTEncoderOneRef(nn.Module):
+    def __init__(self, cfg, npoint=None):
+        super().__init__()
+        self.npoint = npoint
+        self.rgb_net = ViT_AE(cfg)
+
+
+# ------------------------------------------------------- transformer --------
+class SinusoidalPositionalEmbedding(nn.Module):
+    def __init__(self, d_model):
+        super().__init__()
+        self.d_model = d_model
+        div = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        self.register_buffer("div_term", div)
+
+
+class GeometricStructureEmbedding(nn.Module):
+    """T:287-350."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.sigma_d, self.sigma_a, self.angle_k = cfg.sigma_d, cfg.sigma_a, cfg.angle_k
+        self.factor_a = 180.0 / (self.sigma_a * math.pi)
+        self.embedding = SinusoidalPositionalEmbedding(cfg.hidden_dim)
+        self.proj_d = nn.Linear(cfg.hidden_dim, cfg.hidden_dim)
+        self.proj_a = nn.Linear(cfg.hidden_dim, cfg.hidden_dim)
+        self.reduction_a = cfg.reduction_a
+        if self.reduction_a not in ("max", "mean"):
+            raise ValueError(f"Unsupported reduction mode: {self.reduction_a}.")
+
+    def forward(self, points):
+        return ops.geo_embedding(points, self)
+
+
+class _MHA(nn.Module):
+    def __init__(self, d, rpe):
+        super().__init__()
+        self.proj_q = nn.Linear(d, d)
+        self.proj_k = nn.Linear(d, d)
+        self.proj_v = nn.Linear(d, d)
+        if rpe:
+            self.proj_p = nn.Linear(d, d)
+
+
+class _AttentionLayer(nn.Module):
+    def __init__(self, d, rpe):
+        super().__init__()
+        self.attention = _MHA(d, rpe)
+        self.linear = nn.Linear(d, d)
+        self.norm = nn.LayerNorm(d)
+
+
+class _AttentionOutput(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.expand = nn.Linear(d, 2 * d)
+        self.squeeze = nn.Linear(2 * d, d)
+        self.norm = nn.LayerNorm(d)
+
+    def forward(self, x):
+        return self.norm(x + self.squeeze(F.relu(self.expand(x))))
+
+
+class TransformerLayer(nn.Module):
+    """T:196-227 (cross, ``rpe=False``) and T:444-466 (RPE self-attention, ``rpe=True``); 4 heads."""
+
+    def __init__(self, d, rpe, heads=4):
+        super().__init__()
+        self.heads = heads
+        self.attention = _AttentionLayer(d, rpe)
+        self.output = _AttentionOutput(d)
+
+    def forward(self, x, mem, embed=None):
+        a = self.attention
+        h = ops.token_attention(x, mem, a.attention, self.heads, embed)
+        x = a.norm(a.linear(h) + x)
+        return self.output(x)
+
+
+class GeometricTransformer(nn.Module):
+    """T:469-514 with blocks ["self","cross"], sequential cross order (T:507-508)."""
+
+    def __init__(self, d, heads=4):
+        super().__init__()
+        self.layers = nn.ModuleList([TransformerLayer(d, True, heads), TransformerLayer(d, False, heads)])
+
+    def forward(self, f0, e0, f1, e1):
+        f0 = self.layers[0](f0, f0, e0)
+        f1 = self.layers[0](f1, f1, e1)
+        f0 = self.layers[1](f0, f1)
+        f1 = self.layers[1](f1, f0)
+        return f0, f1
+
+
+class _LinearAttention(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.proj_q = nn.Linear(d, d)
+        self.proj_k = nn.Linear(d, d)
+        self.proj_v = nn.Linear(d, d)
+        self.scale = nn.Parameter(torch.zeros(1, 1, d))
+
+
+class _LinearAttentionLayer(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.attention = _LinearAttention(d)
+        self.linear = nn.Linear(d, d)
+        self.norm = nn.LayerNorm(d)
+
+
+class LinearTransformerLayer(nn.Module):
+    """T:517-612 focused linear attention, dense <- sparse."""
+
+    def __init__(self, d, heads=4, focusing_factor=3):
+        super().__init__()
+        self.heads, self.focusing_factor = heads, focusing_factor
+        self.attention = _LinearAttentionLayer(d)
+        self.output = _AttentionOutput(d)
+
+    def forward(self, x, mem):
+        a = self.attention
+        h = ops.focused_linear_attention(x, mem, a.attention, self.heads, self.focusing_factor)
+        x = a.norm(a.linear(h) + x)
+        return self.output(x)
+
+
+class SparseToDenseTransformer(nn.Module):
+    """T:615-671 (with_bg_token, replace_bg_token)."""
+
+    def __init__(self, d, heads=4, focusing_factor=3):
+        super().__init__()
+        self.sparse_layer = GeometricTransformer(d, heads)
+        self.dense_layer = LinearTransformerLayer(d, heads, focusing_factor)
+
+    @staticmethod
+    def _sample(dense, fps_idx):
+        # T:655-662: rows are gathered from the tensor that STILL holds the bg token at row 0 with
+        # indices of the bg-free cloud (off-by-one preserved for parity with trained weights, App-E.2)
+        return torch.cat([dense[:, 0:1], ops.gather_rows(dense, fps_idx)], dim=1)
+
+    def forward(self, d0, e0, i0, d1, e1, i1):
+        f0, f1 = self.sparse_layer(self._sample(d0, i0), e0, self._sample(d1, i1), e1)
+        n0 = self.dense_layer(d0[:, 1:], f0[:, 1:])
+        n1 = self.dense_layer(d1[:, 1:], f1[:, 1:])
+        return torch.cat([f0[:, 0:1], n0], 1), torch.cat([f1[:, 0:1], n1], 1)
+
+
+# -------------------------------------------------------------- PE ----------
+class _BN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.bn = nn.BatchNorm2d(c)
+
+
+class _ConvBN(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 1, bias=False)
+        self.normlayer = _BN(cout)
+
+    def folded(self):
+        """Eval-mode BN folded into the 1x1 conv: y = relu(W' x + b')."""
+        bn = self.normlayer.bn
+        s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        return self.conv.weight.reshape(self.conv.weight.shape[0], -1) * s[:, None], bn.bias - bn.running_mean * s
+
+
+class _SharedMLP(nn.Module):
+    def __init__(self, chans):
+        super().__init__()
+        for i in range(len(chans) - 1):
+            self.add_module(f"layer{i}", _ConvBN(chans[i], chans[i + 1]))
+        self.n = len(chans) - 1
+
+    def layers(self):
+        return [getattr(self, f"layer{i}") for i in range(self.n)]
+
+
+class _Conv1d(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv1d(cin, cout, 1, bias=True)
+
+
+class PositionalEncoding(nn.Module):
+    """Fi:138-178: two-scale QueryAndLRFGroup -> SharedMLP[6,32,64,128] -> max over neighbours -> Conv1d."""
+
+    def __init__(self, out_dim, r1, r2, nsample1, nsample2):
+        super().__init__()
+        self.r1, self.r2, self.ns1, self.ns2 = r1, r2, nsample1, nsample2
+        self.mlp1 = _SharedMLP([6, 32, 64, 128])
+        self.mlp2 = _SharedMLP([6, 32, 64, 128])
+        self.mlp3 = _Conv1d(256, out_dim)
+
+    def forward(self, pts):
+        pts = pts.float()
+        f1 = ops.pe_group_mlp_max(pts, self.r1, self.ns1, self.mlp1)  # (B,N,128)
+        f2 = ops.pe_group_mlp_max(pts, self.r2, self.ns2, self.mlp2)
+        feat = torch.cat([f1, f2], dim=2).float()
+        w = self.mlp3.conv.weight.reshape(self.mlp3.conv.weight.shape[0], -1)
+        with torch.autocast("cuda", enabled=False):  # Fi:163-165 forces fp32 for the whole PE
+            return F.linear(feat, w.float(), self.mlp3.conv.bias.float())

@@ -1,0 +1,170 @@
+"""UNOPose for MI355X: same constructor / ``forward(end_points)`` / state_dict contract as
+core/unopose/model/oneref_grf_predator_pose_estimation_model.py:11-76 (M), with
+C = oneref_predator_coarse_point_matching.py, Fi = oneref_predator_fine_point_matching.py,
+F = oneref_feature_extraction.py, U = utils/model_utils.py.  Inference only (eval branch)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .config import to_cfg
+from .modules import (GeometricStructureEmbedding, GeometricTransformer, PositionalEncoding,
+                      SparseToDenseTransformer, ViTEncoderOneRef)
+
+
+def _scores(scores, n1):
+    """C:68-76 / Fi:91-99 -- only `score` is consumed at eval time."""
+    s1, s2 = scores[:, 1:(n1 + 1)], scores[:, (n1 + 2):]
+    return torch.clamp(torch.sigmoid(torch.cat((s1, s2), dim=1).squeeze(-1).float()), 0, 1)
+
+
+class CoarsePointMatchingOneRef(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.nblock = cfg.nblock
+        self.in_proj = nn.Linear(cfg.input_dim, cfg.hidden_dim)
+        self.out_proj = nn.Linear(cfg.hidden_dim, cfg.out_dim)
+        self.bg_token = nn.Parameter(torch.randn(1, 1, cfg.hidden_dim) * 0.02)
+        self.score_heads = nn.ModuleList([nn.Linear(cfg.hidden_dim, 1) for _ in range(self.nblock)])
+        self.transformers = nn.ModuleList([GeometricTransformer(cfg.hidden_dim, 4) for _ in range(self.nblock)])
+
+    def forward(self, p1, f1, geo1, p2, f2, geo2, radius, end_points):
+        if self.training:
+            raise NotImplementedError("training path is out of scope (SURVEY.md 8(f-4))")
+        B, n1 = f1.shape[:2]
+        f1 = self.in_proj(f1)
+        f2 = self.in_proj(f2)
+        bg = self.bg_token.expand(B, -1, -1).to(f1.dtype)
+        f1 = torch.cat([bg, f1], dim=1)
+        f2 = torch.cat([bg, f2], dim=1)
+        for blk in self.transformers:
+            f1, f2 = blk(f1, geo1, f2, geo2)
+        scores = self.score_heads[self.nblock - 1](torch.cat((f1, f2), dim=1))
+        atten = ops.feature_similarity(self.out_proj(f1), self.out_proj(f2), self.cfg.temp)
+        score = _scores(scores, n1)
+        n1p, n2p = self.cfg.nproposal1, self.cfg.nproposal2
+        rand = end_points.get("coarse_rand")
+        if rand is None:  # the reference draws inside forward (U:462)
+            rand = torch.rand(B, n1p * 3, device=p1.device)
+        init_R, init_t, init_score = ops.coarse_pose(atten, score, p1, p2, rand, n1p, n2p)
+        end_points["init_pose_score"] = init_score
+        end_points["init_R"] = init_R
+        end_points["init_t"] = init_t
+        return end_points
+
+
+class FinePointMatchingOneRef(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.nblock = cfg.nblock
+        d = cfg.hidden_dim
+        self.in_proj = nn.Linear(cfg.input_dim, d)
+        self.out_proj = nn.Linear(d, cfg.out_dim)
+        self.dis_proj = nn.Linear(2 * d, 3)  # present in released checkpoints, unused by forward
+        self.bg_token = nn.Parameter(torch.randn(1, 1, d) * 0.02)
+        assert cfg.use_lrf and cfg.use_xyz and not cfg.get("use_feature", False), "only the configured PE variant"
+        self.PE = PositionalEncoding(d, cfg.pe_radius1, cfg.pe_radius2, cfg.get("nsample1", 32), cfg.get("nsample2", 64))
+        self.score_heads = nn.ModuleList([nn.Linear(d, 1) for _ in range(self.nblock)])
+        self.transformers = nn.ModuleList(
+            [SparseToDenseTransformer(d, 4, cfg.focusing_factor) for _ in range(self.nblock)])
+
+    def forward(self, p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points):
+        if self.training:
+            raise NotImplementedError("training path is out of scope (SURVEY.md 8(f-4))")
+        B, n1 = p1.shape[:2]
+        if "init_R" in end_points and "init_t" in end_points:
+            p1_ = (p1 - end_points["init_t"].unsqueeze(1)) @ end_points["init_R"]
+        else:
+            p1_ = p1
+        f1 = self.in_proj(f1) + self.PE(p1_).to(f1.dtype)
+        f2 = self.in_proj(f2) + self.PE(p2).to(f2.dtype)
+        bg = self.bg_token.expand(B, -1, -1).to(f1.dtype)
+        f1 = torch.cat([bg, f1], dim=1)
+        f2 = torch.cat([bg, f2], dim=1)
+        for blk in self.transformers:
+            f1, f2 = blk(f1, geo1, fps_idx1, f2, geo2, fps_idx2)
+        scores = self.score_heads[self.nblock - 1](torch.cat((f1, f2), dim=1))
+        atten = ops.feature_similarity(self.out_proj(f1), self.out_proj(f2), self.cfg.temp)
+        score = _scores(scores, n1)
+        R, t, s = ops.fine_pose(atten, score, p1, p2)
+        end_points["pred_R"] = R
+        end_points["pred_t"] = t * (radius.reshape(-1, 1) + 1e-6)
+        end_points["pred_pose_score"] = s
+        return end_points
+
+
+class UNOPose(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        cfg = to_cfg(cfg)
+        self.cfg = cfg
+        self.coarse_npoint = cfg.coarse_npoint
+        self.fine_npoint = cfg.fine_npoint
+        self.use_ref_rad = cfg.get("use_ref_rad", False)
+        self.test_coarse_only = cfg.get("test_coarse_only", False)
+        self.feature_extraction = ViTEncoderOneRef(cfg.feature_extraction, self.fine_npoint)
+        self.geo_embedding = GeometricStructureEmbedding(cfg.geo_embedding)
+        self.coarse_point_matching = CoarsePointMatchingOneRef(cfg.coarse_point_matching)
+        self.fine_point_matching = FinePointMatchingOneRef(cfg.fine_point_matching)
+
+    # ---- F:245-298 -------------------------------------------------------------------------------
+    def _features(self, end_points):
+        rgb, choose = end_points["rgb"], end_points["rgb_choose"]
+        assert choose.size(1) == self.fine_npoint
+        net = self.feature_extraction.rgb_net
+        dense_pm = end_points["pts"]
+        if "dense_po" in end_points and "dense_fo" in end_points:  # precomputed reference (F:252-263)
+            dense_fm = net.pixel_features(rgb, choose)
+            dense_po, dense_fo = end_points["dense_po"].clone(), end_points["dense_fo"].clone()
+            radius = torch.norm(dense_po - dense_po.mean(1, keepdim=True), dim=2).max(1)[0]
+            dense_pm = dense_pm / (radius.reshape(-1, 1, 1) + 1e-6)
+            dense_po = dense_po / (radius.reshape(-1, 1, 1) + 1e-6)
+            return dense_pm, dense_fm, dense_po, dense_fo, radius
+        tem_rgb, tem_choose, tem_pts = end_points["tem1_rgb"], end_points["tem1_choose"], end_points["tem1_pts"]
+        radius = torch.norm(tem_pts - tem_pts.mean(1, keepdim=True), dim=2).max(1)[0]
+        dense_pm = dense_pm / (radius.reshape(-1, 1, 1) + 1e-6)
+        tem_n = tem_pts / (radius.reshape(-1, 1, 1) + 1e-6)
+        # FPS of the reference cloud only needs points: issue it before the ViT so it overlaps
+        idx_o = ops.furthest_point_sample(tem_n, self.fine_npoint)
+        # both crops through the ViT as ONE batch of 2B images
+        B = rgb.shape[0]
+        low, (H, W) = net.lowres_map(torch.cat([rgb, tem_rgb], 0))
+        dense_fm = ops.bilinear_sample_pixels(low[:B], choose, H, W)
+        # only the FPS-selected reference pixels are ever interpolated (gather commutes with sampling)
+        sel_choose = torch.gather(tem_choose, 1, idx_o.long())
+        dense_fo = ops.bilinear_sample_pixels(low[B:], sel_choose, H, W)
+        dense_po = ops.gather_rows(tem_n, idx_o)
+        return dense_pm, dense_fm, dense_po, dense_fo, radius
+
+    def _sample_wlrf(self, pts, pts_lrf, feats, npoint):
+        """U:156-177 (gathers done in (B,N,C) layout)."""
+        idx = ops.furthest_point_sample(pts, npoint)
+        return ops.gather_rows(pts.float(), idx), ops.gather_rows(pts_lrf, idx), ops.gather_rows(feats, idx), idx
+
+    def forward(self, end_points):
+        if self.training:
+            raise NotImplementedError("training path is out of scope (SURVEY.md 8(f-4))")
+        dense_pm, dense_fm, dense_po, dense_fo, radius = self._features(end_points)
+        dense_pm_lrf = ops.lrf_global(end_points["pts"], self.use_ref_rad)
+        # NB (App-E.1): LRF of the FULL tem1 cloud (5000 rows) gathered below with indices into the
+        # FPS-2048 subset, exactly as the reference does (M:30, U:167-171).
+        dense_po_lrf = ops.lrf_global(end_points["tem1_pts"], self.use_ref_rad) if "tem1_pts" in end_points \
+            else ops.lrf_global(end_points["dense_po"], self.use_ref_rad)
+        B = dense_pm.size(0)
+        bg_point = torch.ones(B, 1, 3, device=dense_pm.device)
+        sparse_pm, sparse_pm_lrf, sparse_fm, fps_idx_m = self._sample_wlrf(dense_pm, dense_pm_lrf, dense_fm,
+                                                                         self.coarse_npoint)
+        geo_m = self.geo_embedding(torch.cat([bg_point, sparse_pm_lrf], dim=1))
+        sparse_po, sparse_po_lrf, sparse_fo, fps_idx_o = self._sample_wlrf(dense_po, dense_po_lrf, dense_fo,
+                                                                         self.coarse_npoint)
+        geo_o = self.geo_embedding(torch.cat([bg_point, sparse_po_lrf], dim=1))
+        end_points = self.coarse_point_matching(sparse_pm, sparse_fm, geo_m, sparse_po, sparse_fo, geo_o, radius,
+                                                end_points)
+        if self.test_coarse_only:
+            end_points["pred_R"] = end_points["init_R"]
+            end_points["pred_t"] = end_points["init_t"] * (radius.reshape(-1, 1) + 1e-6)
+            end_points["pred_pose_score"] = end_points["init_pose_score"]
+            return end_points
+        return self.fine_point_matching(dense_pm, dense_fm, geo_m, fps_idx_m, dense_po, dense_fo, geo_o, fps_idx_o,
+                                        radius, end_points)

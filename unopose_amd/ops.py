@@ -50,3 +50,229 @@ def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
         call("unopose_weighted_procrustes", ptr(src), ptr(ref), ptr(weights) if weights is not None else None, M, N,
              float(weight_thresh), float(eps), ptr(R), ptr(t), stream_ptr())
     return R, t
+
+
+# =============================================================================
+# Dense-math operators.  Plain GEMMs go through torch (rocBLAS / hipBLASLt) as the
+# brief allows; everything with structure (attention, sampling, assignment, pose
+# hypotheses) is moved into hand-written HIP kernels one by one -- each function
+# below names its current implementation.
+# =============================================================================
+import math
+
+import torch.nn.functional as F
+
+from .pointnet2 import _ext
+
+
+def gather_rows(feats, idx):
+    """out[b,j,:] = feats[b, idx[b,j], :]  (the (B,N,C)-layout twin of gather_operation; avoids the two
+    transpose copies around every reference call, model_utils.py:146-149, transformer.py:658)."""
+    B, N, C = feats.shape
+    return torch.gather(feats, 1, idx.long().unsqueeze(2).expand(-1, -1, C))
+
+
+def vit_attention(qkv, heads):
+    """timm Attention core: qkv (B,T,3C) -> (B,T,C).  [torch bmm + softmax for now]"""
+    B, T, C3 = qkv.shape
+    C = C3 // 3
+    hd = C // heads
+    q, k, v = qkv.reshape(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    a = torch.softmax((q * hd ** -0.5) @ k.transpose(-2, -1), dim=-1, dtype=torch.float32).to(v.dtype) @ v
+    return a.transpose(1, 2).reshape(B, T, C)
+
+
+def bilinear_sample_pixels(low, choose, H, W):
+    """F.interpolate(map, (H,W), bilinear, align_corners=False) followed by the pixel gather of
+    get_chosen_pixel_feats (oneref_feature_extraction.py:229, model_utils.py:215-227), fused: only the
+    chosen pixels are ever interpolated.  low (B,h,w,C) channels-last, choose (B,Np) int64 -> (B,Np,C)."""
+    B, h, w, C = low.shape
+    ys = torch.div(choose, W, rounding_mode="floor")
+    xs = choose - ys * W
+
+    def src(dst, n_in, n_out):
+        s = (dst.float() + 0.5) * (n_in / n_out) - 0.5
+        s = s.clamp(min=0.0)
+        i0 = s.floor().long().clamp(max=n_in - 1)
+        i1 = torch.where(i0 < n_in - 1, i0 + 1, i0)
+        l1 = s - i0.float()
+        return i0, i1, l1
+
+    y0, y1, ly = src(ys, h, H)
+    x0, x1, lx = src(xs, w, W)
+    flat = low.reshape(B, h * w, C)
+
+    def g(yy, xx):
+        return torch.gather(flat, 1, (yy * w + xx).unsqueeze(2).expand(-1, -1, C)).float()
+
+    lx, ly = lx.unsqueeze(2), ly.unsqueeze(2)
+    top = (1 - lx) * g(y0, x0) + lx * g(y0, x1)
+    bot = (1 - lx) * g(y1, x0) + lx * g(y1, x1)
+    return (1 - ly) * top + ly * bot
+
+
+def pairwise_distance(x, y):
+    """model_utils.py:230-257."""
+    xy = x @ y.transpose(-1, -2)
+    return ((x ** 2).sum(-1).unsqueeze(-1) - 2 * xy + (y ** 2).sum(-1).unsqueeze(-2)).clamp(min=0.0)
+
+
+def geo_embedding(points, m):
+    """GeometricStructureEmbedding.forward (transformer.py:303-350).  [torch composite for now]"""
+    points = points.float()
+    B, N, _ = points.shape
+    with torch.autocast("cuda", enabled=False):
+        dist = torch.sqrt(pairwise_distance(points, points))
+        k = m.angle_k
+        knn = dist.topk(k=k + 1, dim=2, largest=False)[1][:, :, 1:]
+        knn_pts = torch.gather(points.unsqueeze(1).expand(B, N, N, 3), 2, knn.unsqueeze(3).expand(B, N, k, 3))
+        ref = (knn_pts - points.unsqueeze(2)).unsqueeze(2).expand(B, N, N, k, 3)
+        anc = (points.unsqueeze(1) - points.unsqueeze(2)).unsqueeze(3).expand(B, N, N, k, 3)
+        sin_v = torch.linalg.norm(torch.cross(ref, anc, dim=-1), dim=-1)
+        cos_v = (ref * anc).sum(-1)
+        a_idx = torch.atan2(sin_v, cos_v) * m.factor_a
+        d_idx = dist / m.sigma_d
+        div = m.embedding.div_term
+
+        def sinus(idx):
+            om = idx.unsqueeze(-1) * div
+            return torch.stack([torch.sin(om), torch.cos(om)], dim=-1).reshape(*idx.shape, -1)
+
+        sd, sa = sinus(d_idx), sinus(a_idx)
+    d_emb = m.proj_d(sd)
+    a_emb = m.proj_a(sa)
+    a_emb = a_emb.max(dim=3)[0] if m.reduction_a == "max" else a_emb.mean(dim=3)
+    return d_emb + a_emb
+
+
+def token_attention(x, mem, att, heads, embed=None):
+    """MultiHeadAttention / RPEMultiHeadAttention core (transformer.py:130-148, 386-405): returns the
+    concatenated heads (B,n,C) before the output Linear.  The RPE term q.proj_p(E) is folded:
+    q.(W_p e + b_p) = (q W_p).e + q.b_p  (SURVEY.md App-F), so no (B,4,n,m,64) tensor exists.
+    [torch einsum for now]"""
+    B, n, C = x.shape
+    hd = C // heads
+    q = att.proj_q(x).reshape(B, n, heads, hd)
+    k = att.proj_k(mem).reshape(B, -1, heads, hd)
+    v = att.proj_v(mem).reshape(B, -1, heads, hd)
+    s = torch.einsum("bnhc,bmhc->bhnm", q, k)
+    if embed is not None:
+        wp = att.proj_p.weight.reshape(heads, hd, C)  # rows of W_p grouped by head
+        qp = torch.einsum("bnhc,hcd->bnhd", q, wp.to(q.dtype))  # (B,n,h,C)
+        s = s + torch.einsum("bnhd,bnmd->bhnm", qp, embed.to(q.dtype))
+        s = s + torch.einsum("bnhc,hc->bhn", q, att.proj_p.bias.reshape(heads, hd).to(q.dtype)).unsqueeze(-1)
+    p = torch.softmax(s.float() / hd ** 0.5, dim=-1).to(v.dtype)
+    return torch.einsum("bhnm,bmhc->bnhc", p, v).reshape(B, n, C)
+
+
+def focused_linear_attention(xq, xkv, att, heads, focusing):
+    """LinearAttention.forward (transformer.py:533-568), kv branch (the shape test at :560 is static)."""
+    q, k, v = att.proj_q(xq), att.proj_k(xkv), att.proj_v(xkv)
+    dt = v.dtype
+    q, k = q.float(), k.float()
+    scale = F.softplus(att.scale.float())
+    q = (F.relu(q) + 1e-6) / scale
+    k = (F.relu(k) + 1e-6) / scale
+    qn, kn = q.norm(dim=-1, keepdim=True), k.norm(dim=-1, keepdim=True)
+    q, k = q ** focusing, k ** focusing
+    q = q / q.norm(dim=-1, keepdim=True) * qn
+    k = k / k.norm(dim=-1, keepdim=True) * kn
+    B, i, C = q.shape
+    j = k.shape[1]
+    hd = C // heads
+    q = q.reshape(B, i, heads, hd)
+    k = k.reshape(B, j, heads, hd)
+    v = v.reshape(B, j, heads, hd)
+    z = 1 / (torch.einsum("bihc,bhc->bih", q, k.sum(dim=1)) + 1e-6)
+    if i * j * (hd + hd) > hd * hd * (i + j):
+        kv = torch.einsum("bjhc,bjhd->bhcd", k.to(dt), v)
+        x = torch.einsum("bihc,bhcd->bihd", q.to(dt), kv).float() * z.unsqueeze(-1)
+    else:
+        qk = torch.einsum("bihc,bjhc->bhij", q.to(dt), k.to(dt))
+        x = torch.einsum("bhij,bjhd->bihd", qk, v).float() * z.unsqueeze(-1)
+    return x.reshape(B, i, C).to(dt)
+
+
+def pe_group_mlp_max(pts, radius, nsample, mlp, chunk=4):
+    """QueryAndLRFGroup -> SharedMLP -> max over neighbours (fine matcher PE, Fi:167-174).
+    [HIP fused ball-query+group+LRF, then torch GEMMs with BN folded, chunked over the batch]"""
+    outs = []
+    folded = [l.folded() for l in mlp.layers()]
+    with torch.autocast("cuda", enabled=False):
+        for b0 in range(0, pts.shape[0], chunk):
+            x = query_lrf_group(pts[b0:b0 + chunk], radius, nsample)  # (b,6,N,S)
+            x = x.permute(0, 2, 3, 1)
+            for w, b in folded:
+                x = F.relu(F.linear(x, w.float(), b.float()))
+            outs.append(x.max(dim=2)[0])
+    return torch.cat(outs, 0)
+
+
+def furthest_point_sample(pts, npoint):
+    return _ext.furthest_point_sampling(_c(pts.float()), npoint)
+
+
+def feature_similarity(f1, f2, temp):
+    """compute_feature_similarity, cosine + normalize (model_utils.py:260-282)."""
+    return (F.normalize(f1.float(), p=2, dim=2) @ F.normalize(f2.float(), p=2, dim=2).transpose(1, 2)) / temp
+
+
+def soft_assignment(atten, score1, score2):
+    """Mutual softmax x overlap scores + bg-aware labels (model_utils.py:434-446, 538-547)."""
+    B = atten.shape[0]
+    one = torch.ones(B, 1, device=atten.device)
+    s1 = torch.cat((one, score1), 1)[:, :, None]
+    s2 = torch.cat((one, score2), 1)[:, None, :]
+    a = torch.softmax(atten, dim=2) * torch.softmax(atten, dim=1) * s1 * s2
+    label1 = a[:, 1:, :].max(dim=2)[1]
+    label2 = a[:, :, 1:].max(dim=1)[1]
+    return a, label1, label2
+
+
+def coarse_pose(atten, score, pts1, pts2, rand, n1p=6000, n2p=300):
+    """compute_coarse_Rt_overlap (model_utils.py:411-490); `rand` (B,3*n1p) is the uniform draw the
+    reference makes inside forward (:462).  [torch composite + HIP 3-point Procrustes]"""
+    B, N1, _ = pts1.shape
+    N2 = pts2.shape[1]
+    atten, pts1, pts2 = atten.float(), pts1.float(), pts2.float()
+    a, l1, l2 = soft_assignment(atten, score[:, :N1].float(), score[:, N2:].float())
+    w1, w2 = (l1 > 0).float(), (l2 > 0).float()
+    ps = (a[:, 1:, 1:] * w1.unsqueeze(2) * w2.unsqueeze(1)).reshape(B, N1 * N2) ** 1.5
+    # torch's CPU cumsum accumulates float32 input in double; mirror that so searchsorted agrees
+    cs = torch.cumsum(ps.double(), dim=1).float()
+    cs = cs / (cs[:, -1].unsqueeze(1) + 1e-8)
+    idx = torch.searchsorted(cs, rand.contiguous())
+    i1 = torch.clamp(idx.div(N2, rounding_mode="floor"), max=N1 - 1)
+    i2 = torch.clamp(idx % N2, max=N2 - 1)
+    p1 = torch.gather(pts1, 1, i1.unsqueeze(2).expand(-1, -1, 3)).reshape(B * n1p, 3, 3)
+    p2 = torch.gather(pts2, 1, i2.unsqueeze(2).expand(-1, -1, 3)).reshape(B * n1p, 3, 3)
+    rs, ts = weighted_procrustes(p2, p1, None, 0.5)
+    rs, ts = rs.reshape(B, n1p, 3, 3), ts.reshape(B, n1p, 1, 3)
+    p1, p2 = p1.reshape(B, n1p, 3, 3), p2.reshape(B, n1p, 3, 3)
+    dis = torch.norm((p1 - ts) @ rs - p2, dim=3).mean(2)
+    top = torch.topk(dis, n2p, dim=1, largest=False)[1]
+    rs2 = torch.gather(rs, 1, top.reshape(B, n2p, 1, 1).expand(-1, -1, 3, 3))
+    ts2 = torch.gather(ts, 1, top.reshape(B, n2p, 1, 1).expand(-1, -1, 1, 3))
+    tp = (pts1.unsqueeze(1) - ts2) @ rs2  # (B,n2p,N1,3)
+    d = torch.sqrt(pairwise_distance(tp, pts2.unsqueeze(1))).min(3)[0]  # (B,n2p,N1)
+    sc = w1.unsqueeze(1).sum(2) / ((d * w1.unsqueeze(1)).sum(2) + 1e-8)
+    pose_score, best = sc.max(1)
+    R = torch.gather(rs2, 1, best.reshape(B, 1, 1, 1).expand(-1, -1, 3, 3)).squeeze(1)
+    t = torch.gather(ts2, 1, best.reshape(B, 1, 1, 1).expand(-1, -1, 1, 3)).squeeze(2).squeeze(1)
+    return R, t, pose_score
+
+
+def fine_pose(atten, score, pts1, pts2, dis_thres=0.15):
+    """compute_fine_Rt_overlap (model_utils.py:527-566).  [torch composite + HIP weighted Procrustes]"""
+    atten, pts1, pts2 = atten.float(), pts1.float(), pts2.float()
+    N1 = pts1.shape[1]
+    a, l1, l2 = soft_assignment(atten, score[:, :N1].float(), score[:, N1:].float())
+    a = a[:, 1:, 1:] * (l1 > 0).float().unsqueeze(2) * (l2 > 0).float().unsqueeze(1)
+    rows = a.sum(2)
+    pred = (a / (rows.unsqueeze(2) + 1e-6)) @ pts2
+    R, t = weighted_procrustes(pred, pts1, rows, 0.001)
+    pp = (pts1 - t.unsqueeze(1)) @ R
+    dis = torch.sqrt(pairwise_distance(pp, pts2)).min(2)[0]
+    mask = (l1 > 0).float()
+    ps = ((dis < dis_thres).float() * mask).sum(1) / (mask.sum(1) + 1e-8)
+    return R, t, ps * mask.mean(1)
