@@ -495,7 +495,8 @@ def unopose_forward(end_points, sd, cfg, rand, ext, detail=False):
     out.update(pred_R=R, pred_t=t * (radius.reshape(-1, 1) + 1e-6), pred_pose_score=s)
     if detail:
         out.update(dense_pm=dense_pm, dense_fm=dense_fm, dense_po=dense_po, dense_fo=dense_fo, radius=radius,
-                   fps_idx_m=idx_m, fps_idx_o=idx_o, geo_m=geo_m, geo_o=geo_o, sparse_pm=sp_m, sparse_po=sp_o)
+                   fps_idx_m=idx_m, fps_idx_o=idx_o, geo_m=geo_m, geo_o=geo_o, sparse_pm=sp_m, sparse_po=sp_o,
+                   sparse_pm_lrf=sp_m_lrf, sparse_po_lrf=sp_o_lrf, sparse_fm=sf_m, sparse_fo=sf_o)
     return out
 
 
@@ -595,10 +596,17 @@ def state_dict_spec(cfg, img_size=224):
     return spec
 
 
-def random_state_dict(cfg, seed=0, img_size=224, prefix=None):
+def random_state_dict(cfg, seed=0, img_size=224, prefix=None, tame=None):
     """Seeded random weights in the reference key layout (trained-like magnitudes;
     BN running stats randomised as SURVEY.md 8(d) prescribes).  `prefix` keeps only
-    keys under it (e.g. "coarse_point_matching")."""
+    keys under it (e.g. "coarse_point_matching").
+
+    `tame` (e.g. 0.1) makes the weights behave like a TRAINED matcher on congruent
+    inputs so that end-to-end R/t are well conditioned (pure random weights give
+    all-background assignments and a chaotic argmax): the token-mixing
+    projections (attention.linear, output.squeeze, PE.mlp3) are scaled by `tame`, so
+    identical input features stay identical through the blocks, and the overlap
+    score heads get bias +2 / weights x0.2 (overlap scores ~0.9)."""
     import zlib
 
     sd = {}
@@ -631,5 +639,11 @@ def random_state_dict(cfg, seed=0, img_size=224, prefix=None):
             for s in shape[1:]:
                 fan_in *= s
             t = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+        if tame is not None:
+            if k.endswith("attention.linear.weight") or k.endswith("output.squeeze.weight") \
+                    or k.endswith("PE.mlp3.conv.weight"):
+                t = t * tame
+            elif "score_heads" in k:
+                t = t * 0 + 2.0 if leaf == "bias" else t * 0.2
         sd[k] = t
     return sd

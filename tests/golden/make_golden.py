@@ -312,52 +312,6 @@ def main():
     print(f"  fine R vs ground truth: {(Rr - Rg2).abs().max().item():.3e}")
     save("fine_rt", atten=atten, score=score, p1=p1, p2=p2, R=Rr, t=tr, pose_score=sr, R_gt=Rg2, t_gt=tg2)
 
-    # ---------------------------------------------------------------- a16 coarse matcher module
-    print("coarse matcher (module, random weights)")
-    cm = CoarsePointMatchingOneRef(cfg.coarse_point_matching).eval()
-    cm.load_state_dict(sub_sd(sd, "coarse_point_matching"), strict=True)
-    B, n = 1, 196
-    sp1, sp2 = norm_cloud(n)[None], norm_cloud(n)[None]
-    sf1 = torch.randn(B, n, 256, generator=g)
-    sf2 = sf1[:, torch.randperm(n, generator=g)] + 0.1 * torch.randn(B, n, 256, generator=g)
-    l1 = torch.cat([torch.ones(B, 1, 3), R.get_batch_lrf(sp1)], 1)
-    l2 = torch.cat([torch.ones(B, 1, 3), R.get_batch_lrf(sp2)], 1)
-    ge1, ge2 = geo(l1), geo(l2)
-    rand = torch.rand(B, 18000, generator=g)
-    torch.rand = lambda *a, **k: rand.clone()
-    try:
-        ep = cm(sp1, sf1, ge1, sp2, sf2, ge2, torch.ones(B), {})
-    finally:
-        torch.rand = _orig_rand
-    Rm, tm, sm, det = R.coarse_point_matching(sp1, sf1, ge1, sp2, sf2, ge2, sd, "coarse_point_matching",
-                                              cfg.coarse_point_matching, rand, detail=True)
-    close(Rm, ep["init_R"], 1e-4, "coarse module R")
-    close(tm, ep["init_t"], 1e-4, "coarse module t")
-    save("coarse_matcher", p1=sp1, f1=sf1, lrf1=l1, p2=sp2, f2=sf2, lrf2=l2, rand=rand, R=ep["init_R"], t=ep["init_t"],
-         pose_score=ep["init_pose_score"], atten=det["atten"], score=det["score"])
-
-    # ---------------------------------------------------------------- a19 fine matcher module
-    print("fine matcher (module, random weights, 512 dense points)")
-    fm = FinePointMatchingOneRef(cfg.fine_point_matching).eval()
-    fm.load_state_dict(sub_sd(sd, "fine_point_matching"), strict=True)
-    nd = 512
-    dp1, dp2 = norm_cloud(nd)[None], norm_cloud(nd)[None]
-    df1 = torch.randn(1, nd, 256, generator=g)
-    df2 = torch.randn(1, nd, 256, generator=g)
-    fi1 = ext.furthest_point_sampling(dp1, 196)
-    fi2 = ext.furthest_point_sampling(dp2, 196)
-    ep = {"init_R": ep["init_R"], "init_t": ep["init_t"]}
-    R0, t0 = ep["init_R"].clone(), ep["init_t"].clone()
-    ep = fm(dp1, df1, ge1, fi1, dp2, df2, ge2, fi2, torch.ones(1), ep)
-    Rm, tm, sm, det = R.fine_point_matching(dp1, df1, ge1, fi1, dp2, df2, ge2, fi2, R0, t0, sd, "fine_point_matching",
-                                            cfg.fine_point_matching, ext, detail=True)
-    close(Rm, ep["pred_R"], 1e-4, "fine module R")
-    close(tm, ep["pred_t"], 1e-4, "fine module t")
-    save("fine_matcher", p1=dp1, f1=df1, lrf1=l1, i1=fi1, p2=dp2, f2=df2, lrf2=l2, i2=fi2, init_R=R0, init_t=t0,
-         R=ep["pred_R"], t=ep["pred_t"], pose_score=ep["pred_pose_score"],
-         f1_out=det["f1"][:, :64], f2_out=det["f2"][:, :64], score=det["score"],
-         atten_rowsum=det["atten"].sum(2), atten_colsum=det["atten"].sum(1))
-
     # ---------------------------------------------------------------- pos-embed resampling
     print("interpolate_pos_embed")
     pos = torch.randn(1, 37 * 37, 8, generator=g)
@@ -373,41 +327,76 @@ def main():
     U.interpolate_pos_embed(m, ck)
     save("interpolate_pos_embed", src=pos, out=ck["pos_embed"])
 
-    # ---------------------------------------------------------------- a10 + a22 full forward
-    print("UNOPose.forward (full size, B=1, random weights, ViT = oracle restatement)")
+    # ---------------------------------------------------------------- a10 + a16 + a19 + a22
+    # End-to-end on CONGRUENT pairs with "tamed" (trained-like) weights: the networks actually solve
+    # these, so R / t are well conditioned and a 1e-4 comparison is meaningful.
     from core.unopose.model.oneref_grf_predator_pose_estimation_model import UNOPose
+    from helpers import congruent_pair
 
-    cfg_ref = R.default_cfg(feature_extraction=dict(freeze_vit=False))
-    model = UNOPose(cfg_ref).eval()
-    model.load_state_dict(sd, strict=True)  # pins the whole key layout (App-C)
-    q = object_cloud(g, 2048)
-    tcloud = object_cloud(g, 5000)
-    end_points = dict(
-        pts=q[None], tem1_pts=tcloud[None],
-        rgb=torch.randn(1, 3, 224, 224, generator=g), tem1_rgb=torch.randn(1, 3, 224, 224, generator=g),
-        rgb_choose=torch.randint(0, 224 * 224, (1, 2048), generator=g),
-        tem1_choose=torch.randint(0, 224 * 224, (1, 5000), generator=g),
-    )
-    rand = torch.rand(1, 18000, generator=g)
+    sdt = R.random_state_dict(cfg, seed=0, tame=0.1)
+
+    def run_forward(tag, nq, nt, seed):
+        print(f"UNOPose.forward [{tag}] nq={nq} nt={nt} (B=1, tamed weights, ViT = own restatement)")
+        cfg_ref = R.default_cfg(fine_npoint=nq, feature_extraction=dict(freeze_vit=False))
+        model = UNOPose(cfg_ref).eval()
+        model.load_state_dict(sdt, strict=True)  # pins the whole key layout (App-C)
+        gg = torch.Generator().manual_seed(seed)
+        end_points, R_gt, t_gt = congruent_pair(gg, nq=nq, nt=nt, noise=5e-4)
+        rand = torch.rand(1, 18000, generator=gg)
+        torch.rand = lambda *a, **k: rand.clone()
+        try:
+            out = model(dict(end_points))
+        finally:
+            torch.rand = _orig_rand
+        mine = R.unopose_forward(end_points, sdt, cfg_ref, rand, ext, detail=True)
+        for k in ("init_R", "init_t", "pred_R", "pred_t"):
+            close(mine[k], out[k], 1e-5, f"forward {k}")
+        print(f"  pred_R vs ground truth {(out['pred_R'][0] - R_gt).abs().max().item():.2e}, "
+              f"pred_t {(out['pred_t'][0] - t_gt).abs().max().item():.2e}, "
+              f"score {out['pred_pose_score'].item():.3f}")
+        taps_ref = model.feature_extraction.rgb_net.vit(end_points["rgb"])
+        taps_mine = R.vit_taps(end_points["rgb"], sdt, "feature_extraction.rgb_net.vit")
+        for a, b in zip(taps_mine, taps_ref):
+            close(a, b, 1e-4, "ViT taps (functional oracle vs module stand-in; NOT timm)")
+        dense = model.feature_extraction.get_img_feats(end_points["rgb"], end_points["rgb_choose"])
+        close(mine["dense_fm"], dense, 1e-4, "ViT_AE post-processing + pixel gather")
+        save(f"forward_{tag}", **{k: v for k, v in end_points.items()}, rand=rand, R_gt=R_gt, t_gt=t_gt,
+             **{k: out[k] for k in ("init_R", "init_t", "init_pose_score", "pred_R", "pred_t", "pred_pose_score")},
+             fps_idx_m=mine["fps_idx_m"], fps_idx_o=mine["fps_idx_o"], radius=mine["radius"],
+             dense_fm_head=dense[:, :64])
+        return model, mine, out, rand
+
+    run_forward("full", 2048, 5000, 77)
+    model, mine, out, rand = run_forward("cfg1", 1024, 2500, 78)
+
+    print("coarse / fine matcher modules on the cfg1 intermediates")
+    sp_m, sp_o = mine["sparse_pm"], mine["sparse_po"]
+    lrf_m = torch.cat([torch.ones(1, 1, 3), mine["sparse_pm_lrf"]], 1)
+    lrf_o = torch.cat([torch.ones(1, 1, 3), mine["sparse_po_lrf"]], 1)
+    geo.load_state_dict(sub_sd(sdt, "geo_embedding"), strict=True)
+    ge1, ge2 = geo(lrf_m), geo(lrf_o)
+    close(ge1, mine["geo_m"], 1e-6, "geo embedding of the forward")
     torch.rand = lambda *a, **k: rand.clone()
     try:
-        out = model(dict(end_points))
+        ep = model.coarse_point_matching(sp_m, mine["sparse_fm"], ge1, sp_o, mine["sparse_fo"], ge2, mine["radius"], {})
     finally:
         torch.rand = _orig_rand
-    mine = R.unopose_forward(end_points, sd, cfg_ref, rand, ext, detail=True)
-    taps_ref = model.feature_extraction.rgb_net.vit(end_points["rgb"])
-    taps_mine = R.vit_taps(end_points["rgb"], sd, "feature_extraction.rgb_net.vit")
-    for a, b in zip(taps_mine, taps_ref):
-        close(a, b, 1e-4, "ViT taps (functional oracle vs module stand-in; NOT timm)")
-    for k in ("init_R", "init_t", "pred_R", "pred_t"):
-        close(mine[k], out[k], 2e-4, f"forward {k}")
-    # ViT_AE post-processing alone (reference code around the stubbed ViT)
-    dense = model.feature_extraction.get_img_feats(end_points["rgb"], end_points["rgb_choose"])
-    close(mine["dense_fm"], dense, 1e-4, "ViT_AE post-processing + pixel gather")
-    save("forward_full", **{k: v for k, v in end_points.items()}, rand=rand,
-         **{k: out[k] for k in ("init_R", "init_t", "init_pose_score", "pred_R", "pred_t", "pred_pose_score")},
-         fps_idx_m=mine["fps_idx_m"], fps_idx_o=mine["fps_idx_o"], radius=mine["radius"],
-         dense_fm_head=dense[:, :64])
+    close(ep["init_R"], out["init_R"], 1e-6, "coarse module == forward")
+    save("coarse_matcher", p1=sp_m, f1=mine["sparse_fm"], lrf1=lrf_m, p2=sp_o, f2=mine["sparse_fo"], lrf2=lrf_o,
+         rand=rand, R=ep["init_R"], t=ep["init_t"], pose_score=ep["init_pose_score"])
+    ep2 = {"init_R": ep["init_R"].clone(), "init_t": ep["init_t"].clone()}
+    ep2 = model.fine_point_matching(mine["dense_pm"], mine["dense_fm"], ge1, mine["fps_idx_m"], mine["dense_po"],
+                                    mine["dense_fo"], ge2, mine["fps_idx_o"], mine["radius"], ep2)
+    close(ep2["pred_R"], out["pred_R"], 1e-6, "fine module == forward")
+    Rm, tm, sm, det = R.fine_point_matching(mine["dense_pm"], mine["dense_fm"], ge1, mine["fps_idx_m"],
+                                            mine["dense_po"], mine["dense_fo"], ge2, mine["fps_idx_o"],
+                                            ep["init_R"], ep["init_t"], sdt, "fine_point_matching",
+                                            cfg.fine_point_matching, ext, detail=True)
+    save("fine_matcher", p1=mine["dense_pm"], f1=mine["dense_fm"], lrf1=lrf_m, i1=mine["fps_idx_m"],
+         p2=mine["dense_po"], f2=mine["dense_fo"], lrf2=lrf_o, i2=mine["fps_idx_o"], init_R=ep["init_R"],
+         init_t=ep["init_t"], radius=mine["radius"], R=ep2["pred_R"], t=ep2["pred_t"],
+         pose_score=ep2["pred_pose_score"], f1_out=det["f1"][:, :64], f2_out=det["f2"][:, :64], score=det["score"],
+         atten_rowmax=det["atten"].max(2)[0], atten_colmax=det["atten"].max(1)[0])
     print("done")
 
 

@@ -106,16 +106,32 @@ def test_fine_rt():
     close(Rm, z["R_gt"], 5e-3)
 
 
-def test_coarse_matcher(sd, cfg):
+@pytest.fixture(scope="module")
+def sdt():
+    return R.random_state_dict(R.default_cfg(), seed=0, tame=0.1)
+
+
+def test_coarse_matcher(sdt, cfg):
     z = load("coarse_matcher")
-    g1 = R.geo_embedding(z["lrf1"], sd, "geo_embedding", cfg.geo_embedding)
-    g2 = R.geo_embedding(z["lrf2"], sd, "geo_embedding", cfg.geo_embedding)
-    Rm, tm, sm, det = R.coarse_point_matching(z["p1"], z["f1"], g1, z["p2"], z["f2"], g2, sd, "coarse_point_matching",
-                                              cfg.coarse_point_matching, z["rand"], detail=True)
-    close(det["atten"], z["atten"], 1e-3)
-    close(det["score"], z["score"], 1e-4)
-    close(Rm, z["R"], 1e-4)
-    close(tm, z["t"], 1e-4)
+    g1 = R.geo_embedding(z["lrf1"], sdt, "geo_embedding", cfg.geo_embedding)
+    g2 = R.geo_embedding(z["lrf2"], sdt, "geo_embedding", cfg.geo_embedding)
+    Rm, tm, sm = R.coarse_point_matching(z["p1"], z["f1"], g1, z["p2"], z["f2"], g2, sdt, "coarse_point_matching",
+                                         cfg.coarse_point_matching, z["rand"])
+    close(Rm, z["R"], 1e-5)
+    close(tm, z["t"], 1e-5)
+
+
+def test_forward_cfg1_end_to_end(oracle_ext, sdt):
+    """BASELINE configs[0]: single pair, 1024 points, CPU forward -- oracle vs the reference's outputs."""
+    z = load("forward_cfg1")
+    cfg1 = R.default_cfg(fine_npoint=1024)
+    ep = {k: z[k] for k in ("pts", "tem1_pts", "rgb", "tem1_rgb", "rgb_choose", "tem1_choose")}
+    out = R.unopose_forward(ep, sdt, cfg1, z["rand"], oracle_ext, detail=True)
+    assert torch.equal(out["fps_idx_m"], z["fps_idx_m"]) and torch.equal(out["fps_idx_o"], z["fps_idx_o"])
+    for k in ("init_R", "init_t", "pred_R", "pred_t"):
+        close(out[k], z[k], 1e-5)
+    close(out["pred_R"][0], z["R_gt"], 5e-3)  # and the pose is actually right
+    close(out["pred_t"][0], z["t_gt"], 5e-3)
 
 
 def test_state_dict_layout_counts(sd):
