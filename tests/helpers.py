@@ -73,36 +73,4 @@ def constructed_similarity(perm, N, gen, n_bg=40, hi=8.0, noise=1.5):
     return atten, score
 
 
-def random_rotation(gen, max_deg=50.0):
-    axis = torch.randn(3, generator=gen)
-    axis = axis / axis.norm()
-    ang = math.radians(max_deg) * torch.rand((), generator=gen).item()
-    K = torch.tensor([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
-    return torch.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * (K @ K)
-
-
-def congruent_pair(gen, nq=2048, nt=5000, S=224, noise=0.0):
-    """A (query, reference) pair that random-weight networks can actually solve: both clouds are the
-    SAME surface under two poses and every surface point keeps ONE pixel in ONE shared crop, so
-    corresponding points carry identical image features.  Returns the end_points dict (B=1) and the
-    ground-truth relative pose (R, t) with p_query = R p_ref + t."""
-    axes = 0.05 + 0.06 * torch.rand(3, generator=gen)
-    v = torch.randn(nt, 3, generator=gen)
-    v = v / v.norm(dim=1, keepdim=True)
-    v[:, 2] = -v[:, 2].abs()
-    obj = v * axes  # visible half of an ellipsoid, object frame
-    # pixel of a surface point: its (x,y) in the object frame mapped onto the crop
-    uv = ((obj[:, :2] / axes[:2]) * 0.48 + 0.5) * (S - 1)
-    pix = (uv[:, 1].round().long().clamp(0, S - 1) * S + uv[:, 0].round().long().clamp(0, S - 1))
-    Rq, Rr = random_rotation(gen, 25.0), random_rotation(gen, 25.0)
-    tq = torch.tensor([0.02, -0.03, 0.8]) + 0.05 * torch.randn(3, generator=gen)
-    tr = torch.tensor([-0.04, 0.01, 0.7]) + 0.05 * torch.randn(3, generator=gen)
-    sel = torch.randperm(nt, generator=gen)[:nq]
-    q = obj[sel] @ Rq.T + tq + noise * torch.randn(nq, 3, generator=gen)
-    r = obj @ Rr.T + tr + noise * torch.randn(nt, 3, generator=gen)
-    img = torch.randn(1, 3, S, S, generator=gen)
-    ep = dict(pts=q[None].contiguous(), tem1_pts=r[None].contiguous(), rgb=img, tem1_rgb=img.clone(),
-              rgb_choose=pix[sel][None].contiguous(), tem1_choose=pix[None].contiguous())
-    R = Rq @ Rr.T
-    t = tq - R @ tr
-    return ep, R, t
+from unopose_amd.synthetic import congruent_pair, random_rotation  # noqa: E402,F401
