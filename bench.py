@@ -91,7 +91,7 @@ def cpu_baseline_leg(img):
     from oracle.pointnet2_oracle import ext as oext
     from unopose_amd.synthetic import congruent_pair
 
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(32, os.cpu_count()))
     g = torch.Generator().manual_seed(1)
     ep, _, _ = congruent_pair(g, 2048, 5000, img, 5e-4)
     cfg = R.default_cfg()
@@ -101,7 +101,7 @@ def cpu_baseline_leg(img):
     with torch.no_grad():
         R.unopose_forward(ep, sd, cfg, rand, oext)
     dt = time.perf_counter() - t0
-    return dict(value=1.0 / dt, unit="pairs/s", cores=os.cpu_count(), kind="port",
+    return dict(value=1.0 / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"1 pair (2048 query / 5000 reference points, {img}x{img} crops), 1 forward, fp32, "
                        f"torch {torch.get_num_threads()} threads + C `_ext` port")
 
