@@ -125,6 +125,19 @@ int unopose_weighted_procrustes(const float *src, const float *ref,
                                 float eps, float *R, float *t,
                                 unopose_stream_t stream);
 
+/* GeometricStructureEmbedding.forward (core/unopose/model/transformer.py:303-350):
+ * points (B,n,3) -> out (B,n,n,256), float32 or bfloat16 (out_bf16).  hidden_dim = 256,
+ * angle_k = 3.  Weights are passed as bfloat16 bit patterns, row-major [out][in]:
+ * w*_hi = bf16(W), w*_lo = bf16(W - float(w*_hi)) (only read when split != 0: hi/lo split
+ * keeps fp32-class accuracy on the bf16 matrix cores).  bias_sum = proj_d.bias + proj_a.bias,
+ * div_term = the 128 sinusoid frequencies, knn_ws = B*n*3 int32 of scratch. */
+int unopose_geo_embedding(const float *points, int B, int n, const void *wd_hi,
+                          const void *wd_lo, const void *wa_hi, const void *wa_lo,
+                          const float *bias_sum, const float *div_term,
+                          float sigma_d, float factor_a, int reduce_mean, int split,
+                          int out_bf16, int32_t *knn_ws, void *out,
+                          unopose_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

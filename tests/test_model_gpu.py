@@ -151,3 +151,24 @@ def test_forward_end_to_end_golden(tamed, tag, n):
     assert err(out["pred_pose_score"], z["pred_pose_score"]) < 1e-3
     assert ((out["init_pose_score"] - z["init_pose_score"]).abs() / z["init_pose_score"]).max().item() < 2e-2
     assert err(out["pred_R"][0], z["R_gt"]) < 5e-3 and err(out["pred_t"][0], z["t_gt"]) < 5e-3
+
+
+@torch.no_grad()
+def test_geo_embedding_kernel_full_size_fp32_and_bf16(model):
+    """Fused HIP embedding vs the op-by-op torch composite at n = 197 (196 coarse points + bg), both
+    precisions: fp32 output / hi-lo split operands (tolerance 1e-4 off the diagonal) and the
+    autocast(bf16) variant (bf16 operands and output: ~3 significant digits)."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    pts = torch.cat([torch.ones(3, 1, 3), torch.rand(3, 196, 3, generator=g) * 1.2 - 0.6], 1).cuda()
+    ref = ops.geo_embedding_torch(pts, model.geo_embedding)
+    out = ops.geo_embedding(pts, model.geo_embedding)
+    assert out.dtype == torch.float32
+    off, diag = _offdiag_err(out, ref)
+    assert off < 1e-4 and diag < 2e-2, (off, diag)
+    outb = ops.geo_embedding(pts, model.geo_embedding, out_dtype=torch.bfloat16)
+    assert outb.dtype == torch.bfloat16
+    off, diag = _offdiag_err(outb, ref)
+    assert off < 6e-2, off
+    assert (outb.float() - ref).abs().mean().item() < 6e-3

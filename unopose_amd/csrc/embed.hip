@@ -1,0 +1,229 @@
+// Geometric structure embedding for gfx950 (C ABI part 2).
+//
+// Replaces GeometricStructureEmbedding.forward (core/unopose/model/transformer.py:303-350):
+//   E[b,i,j,:] = proj_d(sinus(|p_i-p_j|/sigma_d)) + max_k proj_a(sinus(angle(p_knn(i,k)-p_i, p_j-p_i)*factor_a))
+// The reference materialises the (B,n,n,k,256) sinusoidal tensor and runs two Linear layers over it
+// (20.35 GFLOP and ~0.5 GB of temporaries per cloud).  Here one kernel generates the sinusoids of a tile
+// of 32 (i,j) pairs straight into LDS in MFMA A-operand layout (never touching HBM), contracts them with
+// the two 256x256 weight matrices on the matrix cores (v_mfma_f32_32x32x16_bf16) and applies the
+// max-over-k / bias epilogue on the accumulators, so HBM sees only the (B,n,n,256) result once.
+//
+// Tiling (wave64, 8 waves / workgroup): M-tile = 32 pairs x 4 "sets" (distance, angle k=0..2), each set
+// is one 32x256 A matrix; wave w owns output channels [32w, 32w+32) for all four sets, so max over k is
+// an element-wise max of three accumulator registers (C/D layout is identical across the sets).
+// SPLIT=true keeps fp32-class accuracy on the bf16 matrix cores by splitting both operands into
+// hi + lo bf16 parts (3 MFMAs per product, ~2^-16 relative error); SPLIT=false is the autocast(bf16) path.
+#include "common.h"
+
+namespace unopose {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// sin and cos of |x| <~ 1e3 with ~1e-7 absolute error: 3-term Cody-Waite reduction by pi/2 + cephes
+// single-precision minimax polynomials on [-pi/4, pi/4].
+__device__ __forceinline__ void sincos_cw(float x, float &s, float &c) {
+  const float k = rintf(x * 0.636619772367581343f);
+  float r = fmaf(-k, 1.5707963705062866f, x);  // pi/2 = hi + mid + lo (each a float)
+  r = fmaf(-k, -4.371138828673793e-08f, r);
+  r = fmaf(-k, -1.7151245100058819e-15f, r);
+  const float z = r * r;
+  const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float cp =
+      fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+           fmaf(-0.5f, z, 1.0f));
+  const int q = ((int)k) & 3;
+  const float s0 = (q & 1) ? cp : sp;
+  const float c0 = (q & 1) ? sp : cp;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// k nearest neighbours (self excluded) of every point of a small cloud: knn (B,n,3).
+__global__ __launch_bounds__(256) void geo_knn_kernel(const float *__restrict__ pts, int n,
+                                                      int32_t *__restrict__ knn) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float *P = pts + (size_t)b * n * 3;
+  const float x = P[i * 3], y = P[i * 3 + 1], z = P[i * 3 + 2];
+  float d0 = 3e38f, d1 = 3e38f, d2 = 3e38f;
+  int i0 = 0, i1 = 0, i2 = 0;
+  for (int j = 0; j < n; ++j) {
+    if (j == i) continue;
+    const float dx = P[j * 3] - x, dy = P[j * 3 + 1] - y, dz = P[j * 3 + 2] - z;
+    const float d = dx * dx + dy * dy + dz * dz;
+    if (d < d0) { d2 = d1; i2 = i1; d1 = d0; i1 = i0; d0 = d; i0 = j; }
+    else if (d < d1) { d2 = d1; i2 = i1; d1 = d; i1 = j; }
+    else if (d < d2) { d2 = d; i2 = j; }
+  }
+  int32_t *K = knn + ((size_t)b * n + i) * 3;
+  K[0] = i0; K[1] = i1; K[2] = i2;
+}
+
+constexpr int GE_PAIRS = 32;   // pairs per workgroup tile
+constexpr int GE_DIM = 256;    // hidden_dim
+constexpr int GE_THREADS = 512;
+
+__device__ __forceinline__ int ge_swz(int row, int kbyte) {
+  // 512-byte rows; XOR the 16-byte slot index with (row & 15): conflict-free ds_read_b128 for the
+  // 32x32x16 A-operand access pattern (16 distinct rows per LDS lane group)
+  return row * 512 + (kbyte ^ ((row & 15) << 4));
+}
+
+template <bool SPLIT, bool OUT_BF16>
+__global__ __launch_bounds__(GE_THREADS) void geo_embed_kernel(
+    const float *__restrict__ pts, const int32_t *__restrict__ knn, const u16 *__restrict__ wd_hi,
+    const u16 *__restrict__ wd_lo, const u16 *__restrict__ wa_hi, const u16 *__restrict__ wa_lo,
+    const float *__restrict__ bias, const float *__restrict__ div_term, int n, float sigma_d, float factor_a,
+    int reduce_mean, void *__restrict__ out_) {
+  extern __shared__ float4 smem4[];
+  char *Ahi = reinterpret_cast<char *>(smem4);           // [4 sets][32 rows][512 B]
+  char *Alo = Ahi + 4 * GE_PAIRS * 512;                  // only when SPLIT
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nn = n * n;
+  const int pair0 = blockIdx.x * GE_PAIRS;
+  const float *P = pts + (size_t)b * n * 3;
+  const int32_t *KNN = knn + (size_t)b * n * 3;
+
+  // ---------------- phase 1: sinusoids of 4 x 32 index values -> LDS (bf16, A-operand layout)
+  const float div0 = div_term[lane], div1 = div_term[lane + 64];
+  for (int c = wave; c < 4 * GE_PAIRS; c += GE_THREADS / 64) {
+    const int set = c >> 5, row = c & 31;
+    const int pair = min(pair0 + row, nn - 1);
+    const int i = pair / n, j = pair - i * n;
+    const float xi = P[i * 3], yi = P[i * 3 + 1], zi = P[i * 3 + 2];
+    const float ax = P[j * 3] - xi, ay = P[j * 3 + 1] - yi, az = P[j * 3 + 2] - zi;  // anchor = p_j - p_i
+    float idx;
+    if (set == 0) {
+      idx = sqrtf(ax * ax + ay * ay + az * az) / sigma_d;
+    } else {
+      const int q = KNN[i * 3 + set - 1];
+      const float rx = P[q * 3] - xi, ry = P[q * 3 + 1] - yi, rz = P[q * 3 + 2] - zi;  // ref = p_knn - p_i
+      const float cx = ry * az - rz * ay, cy = rz * ax - rx * az, cz = rx * ay - ry * ax;
+      const float sinv = sqrtf(cx * cx + cy * cy + cz * cz);
+      // torch.sum starts from +0, so an all-(-0) dot product (i == j, anchor = 0) is +0 there: keep
+      // atan2(0, +0) = 0 rather than atan2(0, -0) = pi
+      const float cosv = 0.0f + (rx * ax + ry * ay + rz * az);
+      idx = atan2f(sinv, cosv) * factor_a;
+    }
+    float s0, c0, s1, c1;
+    sincos_cw(idx * div0, s0, c0);
+    sincos_cw(idx * div1, s1, c1);
+    // channel 2t = sin(w_t), 2t+1 = cos(w_t)  (transformer.py:278-282)
+    const int rbase = (set * GE_PAIRS + row);
+    const u16 h0 = f2bf(s0), h1 = f2bf(c0), h2 = f2bf(s1), h3 = f2bf(c1);
+    *reinterpret_cast<uint32_t *>(Ahi + ge_swz(rbase, lane * 4)) = (uint32_t)h0 | ((uint32_t)h1 << 16);
+    *reinterpret_cast<uint32_t *>(Ahi + ge_swz(rbase, (lane + 64) * 4)) = (uint32_t)h2 | ((uint32_t)h3 << 16);
+    if (SPLIT) {
+      const u16 l0 = f2bf(s0 - bf2f(h0)), l1 = f2bf(c0 - bf2f(h1)), l2 = f2bf(s1 - bf2f(h2)),
+                l3 = f2bf(c1 - bf2f(h3));
+      *reinterpret_cast<uint32_t *>(Alo + ge_swz(rbase, lane * 4)) = (uint32_t)l0 | ((uint32_t)l1 << 16);
+      *reinterpret_cast<uint32_t *>(Alo + ge_swz(rbase, (lane + 64) * 4)) = (uint32_t)l2 | ((uint32_t)l3 << 16);
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase 2: [4 x (32 x 256)] x (256 x 32-channel slice) on the matrix cores
+  f32x16 acc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  const int arow = lane & 31, khalf = lane >> 5;
+  const int ch = wave * 32 + (lane & 31);  // B operand column = output channel
+  const bf16x8 *Wd_hi = reinterpret_cast<const bf16x8 *>(wd_hi + (size_t)ch * GE_DIM);
+  const bf16x8 *Wa_hi = reinterpret_cast<const bf16x8 *>(wa_hi + (size_t)ch * GE_DIM);
+  const bf16x8 *Wd_lo = SPLIT ? reinterpret_cast<const bf16x8 *>(wd_lo + (size_t)ch * GE_DIM) : nullptr;
+  const bf16x8 *Wa_lo = SPLIT ? reinterpret_cast<const bf16x8 *>(wa_lo + (size_t)ch * GE_DIM) : nullptr;
+#pragma unroll 2
+  for (int ks = 0; ks < GE_DIM / 16; ++ks) {
+    const int kidx = ks * 2 + khalf;  // which group of 8 k's this lane holds
+    const bf16x8 bd = Wd_hi[kidx], ba = Wa_hi[kidx];
+    bf16x8 bdl, bal;
+    if (SPLIT) {
+      bdl = Wd_lo[kidx];
+      bal = Wa_lo[kidx];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Ahi + ge_swz(s * GE_PAIRS + arow, kidx * 16));
+      const bf16x8 bw = s == 0 ? bd : ba;
+      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw, acc[s], 0, 0, 0);
+      if (SPLIT) {
+        const bf16x8 al = *reinterpret_cast<const bf16x8 *>(Alo + ge_swz(s * GE_PAIRS + arow, kidx * 16));
+        const bf16x8 bl = s == 0 ? bdl : bal;
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bw, acc[s], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---------------- phase 3: E = d + reduce_k(a_k) + (b_d + b_a)
+  const float bsum = bias[ch];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;  // 32x32 C/D layout
+    const int pair = pair0 + row;
+    if (pair >= nn) continue;
+    float a = reduce_mean ? (acc[1][r] + acc[2][r] + acc[3][r]) * (1.f / 3.f)
+                          : fmaxf(fmaxf(acc[1][r], acc[2][r]), acc[3][r]);
+    const float v = acc[0][r] + a + bsum;
+    const size_t o = ((size_t)b * nn + pair) * GE_DIM + ch;
+    if (OUT_BF16)
+      reinterpret_cast<u16 *>(out_)[o] = f2bf(v);
+    else
+      reinterpret_cast<float *>(out_)[o] = v;
+  }
+}
+
+}  // namespace unopose
+
+using namespace unopose;
+
+extern "C" {
+
+int unopose_geo_embedding(const float *points, int B, int n, const void *wd_hi, const void *wd_lo, const void *wa_hi,
+                          const void *wa_lo, const float *bias_sum, const float *div_term, float sigma_d,
+                          float factor_a, int reduce_mean, int split, int out_bf16, int32_t *knn_ws, void *out,
+                          unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(points && wd_hi && wa_hi && bias_sum && div_term && knn_ws && out, "geo_embedding: null pointer");
+  UNOPOSE_REQUIRE(!split || (wd_lo && wa_lo), "geo_embedding: split precision needs the lo weight parts");
+  UNOPOSE_REQUIRE(B >= 0 && n >= 4 && B <= 65535, "geo_embedding: bad sizes (n must be >= 4 for 3-NN)");
+  if (B == 0) return UNOPOSE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(geo_knn_kernel, dim3(cdiv(n, 256), B), dim3(256), 0, s, points, n, knn_ws);
+  int rc = check_launch("geo_knn");
+  if (rc) return rc;
+  dim3 grid(cdiv((long)n * n, GE_PAIRS), B);
+  const size_t lds = (size_t)4 * GE_PAIRS * 512 * (split ? 2 : 1);
+  const u16 *dh = (const u16 *)wd_hi, *dl = (const u16 *)wd_lo, *ah = (const u16 *)wa_hi, *al = (const u16 *)wa_lo;
+#define UNOPOSE_GE_LAUNCH(SP, OB)                                                                               \
+  hipLaunchKernelGGL((geo_embed_kernel<SP, OB>), grid, dim3(GE_THREADS), lds, s, points, knn_ws, dh, dl, ah, al, \
+                     bias_sum, div_term, n, sigma_d, factor_a, reduce_mean, out)
+  if (split) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void *)geo_embed_kernel<true, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void *)geo_embed_kernel<true, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    if (out_bf16) UNOPOSE_GE_LAUNCH(true, true); else UNOPOSE_GE_LAUNCH(true, false);
+  } else {
+    if (out_bf16) UNOPOSE_GE_LAUNCH(false, true); else UNOPOSE_GE_LAUNCH(false, false);
+  }
+#undef UNOPOSE_GE_LAUNCH
+  return check_launch("geo_embedding");
+}
+
+}  // extern "C"
