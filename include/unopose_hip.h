@@ -138,6 +138,16 @@ int unopose_geo_embedding(const float *points, int B, int n, const void *wd_hi,
                           int out_bf16, int32_t *knn_ws, void *out,
                           unopose_stream_t stream);
 
+/* One scale of the fine matcher's PositionalEncoding: QueryAndLRFGroup(radius, nsample,
+ * use_xyz) -> SharedMLP[6,32,64,128] (1x1 conv + eval BatchNorm + ReLU) -> max over neighbours
+ * (core/unopose/model/oneref_predator_fine_point_matching.py:167-174).  xyz (B,N,3) ->
+ * out (B,N,128) float32.  w1 (32,6), w2 (64,32), w3 (128,64) row-major [out][in] with
+ * BatchNorm already folded in, b1/b2/b3 the folded biases.  nsample % 32 == 0. */
+int unopose_pe_group_mlp_max(const float *xyz, int B, int N, float radius, int nsample,
+                             const float *w1, const float *b1, const float *w2,
+                             const float *b2, const float *w3, const float *b3,
+                             float *out, unopose_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -172,3 +172,21 @@ def test_geo_embedding_kernel_full_size_fp32_and_bf16(model):
     off, diag = _offdiag_err(outb, ref)
     assert off < 6e-2, off
     assert (outb.float() - ref).abs().mean().item() < 6e-3
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("r,ns", [(0.1, 64), (0.2, 256), (0.3, 32)])
+def test_fused_pe_kernel_vs_unfused(model, r, ns):
+    """Fused ball-query+LRF+MLP+max kernel (fp32 MFMA) vs the materialised path (same HIP grouping
+    kernel + torch GEMMs): identical neighbour lists and frames, so every point must agree to fp32
+    round-off of the 3-layer MLP."""
+    from test_geom_gpu import norm_clouds
+    from unopose_amd import ops
+
+    x = norm_clouds(2048, 3, seed=21).cuda()
+    mlp = model.fine_point_matching.PE.mlp1
+    out = ops.pe_group_mlp_max(x, r, ns, mlp)
+    ref = ops.pe_group_mlp_max_unfused(x, r, ns, mlp)
+    assert out.shape == (3, 2048, 128)
+    e = (out - ref).abs().max().item()
+    assert e < 2e-4, e

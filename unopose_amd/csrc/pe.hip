@@ -1,0 +1,233 @@
+// Fused positional-encoding branch of the fine matcher for gfx950 (C ABI part 2).
+//
+// Replaces, per scale, QueryAndLRFGroup -> SharedMLP[6,32,64,128] -> max over neighbours
+// (core/unopose/model/oneref_predator_fine_point_matching.py:167-174,
+//  core/unopose/model/pointnet2/pointnet2_utils.py:429-584, pointnet2/pytorch_utils.py:25-132).
+// The reference materialises (B,6,N,S), (B,32,N,S), (B,64,N,S) and (B,128,N,S) fp32 tensors in HBM
+// (268 MB for the last one alone at S=256, B=1).  Here ONE wavefront owns one centre: ball-query
+// compaction into an LDS neighbour list, the per-point local reference frame (register Jacobi), and the
+// three 1x1-conv layers (BatchNorm folded) chained on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32, exact fp32) with NO data movement between layers: the layers are computed
+// transposed, D[out_ch][neighbour] = W[out_ch][k] * X[k][neighbour], so a layer's accumulator registers
+// are directly the next layer's B operand (the k order inside the contraction is permuted to match the
+// C/D register layout, and the weights are staged in LDS in that permuted order).  Only the (B,N,128)
+// max-pooled result reaches HBM.
+#include "common.h"
+#include "jacobi3.h"
+
+namespace unopose {
+
+// channel held by accumulator register r of half-wave h in the 32x32 C/D layout
+__device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct PeLds {
+  // weights transposed to [k][out] so that lanes (l & 31) read consecutive floats
+  float w1[6 * 32];
+  float w2[32 * 64];
+  float w3[64 * 128];
+  float b1[32], b2[64], b3[128];
+};
+
+__global__ __launch_bounds__(256) void pe_group_mlp_max_kernel(
+    const float *__restrict__ xyz, int N, float radius, int S, int cpw, const float *__restrict__ w1,
+    const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
+    const float *__restrict__ w3, const float *__restrict__ b3, float *__restrict__ out) {
+  extern __shared__ float4 smem4[];
+  PeLds *L = reinterpret_cast<PeLds *>(smem4);
+  float *sx = reinterpret_cast<float *>(L + 1);
+  float *sy = sx + N, *sz = sy + N;
+  int *nbr_all = reinterpret_cast<int *>(sz + N);
+  float *stage_all = reinterpret_cast<float *>(nbr_all + 4 * S);  // [4 waves][128]
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  int *nbr = nbr_all + wave * S;
+  float *stage = stage_all + wave * 128;
+  const float *P = xyz + (size_t)b * N * 3;
+
+  for (int e = tid; e < N * 3; e += 256) {
+    const float v = P[e];
+    const int p = e / 3, comp = e - p * 3;
+    (comp == 0 ? sx : comp == 1 ? sy : sz)[p] = v;
+  }
+  // weights arrive row-major [out][in] (BN already folded): transpose to [in][out]
+  for (int e = tid; e < 32 * 6; e += 256) L->w1[(e % 6) * 32 + e / 6] = w1[e];
+  for (int e = tid; e < 64 * 32; e += 256) L->w2[(e % 32) * 64 + e / 32] = w2[e];
+  for (int e = tid; e < 128 * 64; e += 256) L->w3[(e % 64) * 128 + e / 64] = w3[e];
+  if (tid < 32) L->b1[tid] = b1[tid];
+  if (tid < 64) L->b2[tid] = b2[tid];
+  if (tid < 128) L->b3[tid] = b3[tid];
+  __syncthreads();
+  const float r2 = radius * radius;
+
+  for (int ci = 0; ci < cpw; ++ci) {
+    const int j = (blockIdx.x * 4 + wave) * cpw + ci;
+    if (j >= N) break;  // wave-uniform
+    const float cx = sx[j], cy = sy[j], cz = sz[j];
+    // ---- ball query (pointnet2 ball_query_gpu.cu:14-49 semantics)
+    int cnt = 0, first = 0;
+    for (int k0 = 0; k0 < N && cnt < S; k0 += 64) {
+      const int k = k0 + lane;
+      bool hit = false;
+      if (k < N) {
+        const float x = sx[k], y = sy[k], z = sz[k];
+        const float d2 = (cx - x) * (cx - x) + (cy - y) * (cy - y) + (cz - z) * (cz - z);
+        hit = d2 < r2;
+      }
+      const unsigned long long mask = __ballot(hit);
+      if (mask) {
+        const int pre =
+            (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        const int pos = cnt + pre;
+        if (hit && pos < S) nbr[pos] = k;
+        if (cnt == 0) first = k0 + __builtin_ctzll(mask);
+        cnt += __builtin_popcountll(mask);
+      }
+    }
+    for (int l = min(cnt, S) + lane; l < S; l += 64) nbr[l] = first;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- local reference frame (LRF_batch, pointnet2_utils.py:436-481)
+    float a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+    for (int l = lane; l < S; l += 64) {
+      const int k = nbr[l];
+      const float x = cx - sx[k], y = cy - sy[k], z = cz - sz[k];
+      a00 += x * x; a01 += x * y; a02 += x * z; a11 += y * y; a12 += y * z; a22 += z * z;
+    }
+    const float inv_s = 1.f / (float)S;
+    a00 = wave_sum_f32(a00) * inv_s; a01 = wave_sum_f32(a01) * inv_s; a02 = wave_sum_f32(a02) * inv_s;
+    a11 = wave_sum_f32(a11) * inv_s; a12 = wave_sum_f32(a12) * inv_s; a22 = wave_sum_f32(a22) * inv_s;
+    Vec3 e0, e1, z0;
+    float l0, l1, l2;
+    eig_sym3(a00, a01, a02, a11, a12, a22, e0, e1, z0, l0, l1, l2);
+    int vote = 0;
+    for (int l0i = 0; l0i < S; l0i += 64) {
+      const int l = l0i + lane;
+      float pr = 0.f;
+      if (l < S) {
+        const int k = nbr[l];
+        pr = z0.x * (cx - sx[k]) + z0.y * (cy - sy[k]) + z0.z * (cz - sz[k]);
+      }
+      vote += __builtin_popcountll(__ballot(pr > 1e-3f)) - __builtin_popcountll(__ballot(pr < -1e-3f));
+    }
+    const Vec3 zp = vote < 0 ? scale(z0, -1.f) : z0;
+    float vx = 0, vy = 0, vz = 0;
+    for (int l = lane; l < S; l += 64) {
+      const int k = nbr[l];
+      const Vec3 xn = v3(sx[k] - cx, sy[k] - cy, sz[k] - cz);
+      const float nrm = dot(zp, xn);
+      const Vec3 vi = sub(xn, scale(zp, nrm));
+      float alpha = radius - sqrtf(dot(xn, xn));
+      alpha *= alpha;
+      const float ab = alpha * (nrm * nrm);
+      vx += ab * vi.x; vy += ab * vi.y; vz += ab * vi.z;
+    }
+    vx = wave_sum_f32(vx); vy = wave_sum_f32(vy); vz = wave_sum_f32(vz);
+    const float nacc = sqrtf(vx * vx + vy * vy + vz * vz) + 1e-10f;
+    const Vec3 xp = v3(vx / nacc, vy / nacc, vz / nacc);
+    const Vec3 yp = cross(xp, zp);
+
+    // ---- MLP over tiles of 32 neighbours, running max over tiles
+    f32x16 rmax[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rmax[t][r] = 0.f;  // post-ReLU values are >= 0
+    for (int t0 = 0; t0 < S; t0 += 32) {
+      const int k = nbr[t0 + col];
+      const float dx = sx[k] - cx, dy = sy[k] - cy, dz = sz[k] - cz;
+      const Vec3 q = v3(dx / radius, dy / radius, dz / radius);
+      const float lx = dot(xp, q), ly = dot(yp, q), lz = dot(zp, q);
+      // layer 1: K = 6 -> 3 MFMA steps; step s contracts features (2s | 2s+1) on (lower | upper) half
+      f32x16 h1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h1[r] = 0.f;
+      h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(L->w1[(0 + half) * 32 + col], half ? dy : dx, h1, 0, 0, 0);
+      h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(L->w1[(2 + half) * 32 + col], half ? lx : dz, h1, 0, 0, 0);
+      h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(L->w1[(4 + half) * 32 + col], half ? lz : ly, h1, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h1[r] = fmaxf(h1[r] + L->b1[cd_row(r, half)], 0.f);
+      // layer 2: 32 -> 64 (2 output tiles); step r contracts channels cd_row(r,0) | cd_row(r,1)
+      f32x16 h2[2];
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h2[ot][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          h2[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(L->w2[cd_row(r, half) * 64 + ot * 32 + col], h1[r], h2[ot], 0,
+                                                       0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h2[ot][r] = fmaxf(h2[ot][r] + L->b2[ot * 32 + cd_row(r, half)], 0.f);
+      }
+      // layer 3: 64 -> 128 (4 output tiles, 2 input tiles)
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot) {
+        f32x16 h3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h3[r] = 0.f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            h3 = __builtin_amdgcn_mfma_f32_32x32x2f32(L->w3[(it * 32 + cd_row(r, half)) * 128 + ot * 32 + col],
+                                                      h2[it][r], h3, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          rmax[ot][r] = fmaxf(rmax[ot][r], fmaxf(h3[r] + L->b3[ot * 32 + cd_row(r, half)], 0.f));
+      }
+    }
+    // ---- max over the 32 neighbour lanes of each half-wave; lanes 31 / 63 hold the result
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = rmax[t][r];
+        v = fmaxf(v, dpp_f32<0x111, 0xF>(v, 0.f));
+        v = fmaxf(v, dpp_f32<0x112, 0xF>(v, 0.f));
+        v = fmaxf(v, dpp_f32<0x114, 0xF>(v, 0.f));
+        v = fmaxf(v, dpp_f32<0x118, 0xF>(v, 0.f));
+        v = fmaxf(v, dpp_f32<0x142, 0xA>(v, 0.f));  // row_bcast:15 into rows 1 and 3
+        if (col == 31) stage[t * 32 + cd_row(r, half)] = v;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float *O = out + ((size_t)b * N + j) * 128;
+    O[lane] = stage[lane];
+    O[lane + 64] = stage[lane + 64];
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace unopose
+
+using namespace unopose;
+
+extern "C" {
+
+int unopose_pe_group_mlp_max(const float *xyz, int B, int N, float radius, int nsample, const float *w1,
+                             const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                             float *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(xyz && w1 && b1 && w2 && b2 && w3 && b3 && out, "pe_group_mlp_max: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && N >= 1 && nsample >= 32 && nsample % 32 == 0 && B <= 65535,
+                  "pe_group_mlp_max: nsample must be a positive multiple of 32 (got %d)", nsample);
+  if (B == 0) return UNOPOSE_OK;
+  const size_t lds = sizeof(PeLds) + ((size_t)3 * N + 4 * (size_t)nsample + 4 * 128) * 4;
+  UNOPOSE_REQUIRE(lds <= 160 * 1024, "pe_group_mlp_max: N=%d nsample=%d exceed the LDS tile", N, nsample);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)pe_group_mlp_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  const long centres = (long)B * N;
+  const int cpw = centres >= 32768 ? 8 : centres >= 8192 ? 4 : centres >= 2048 ? 2 : 1;
+  dim3 grid(cdiv(N, 4 * cpw), B);
+  hipLaunchKernelGGL(pe_group_mlp_max_kernel, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius, nsample, cpw,
+                     w1, b1, w2, b2, w3, b3, out);
+  return check_launch("pe_group_mlp_max");
+}
+
+}  // extern "C"

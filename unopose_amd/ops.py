@@ -230,9 +230,36 @@ def focused_linear_attention(xq, xkv, att, heads, focusing):
     return x.reshape(B, i, C).to(dt)
 
 
-def pe_group_mlp_max(pts, radius, nsample, mlp, chunk=4):
-    """QueryAndLRFGroup -> SharedMLP -> max over neighbours (fine matcher PE, Fi:167-174).
-    [HIP fused ball-query+group+LRF, then torch GEMMs with BN folded, chunked over the batch]"""
+def pe_group_mlp_max(pts, radius, nsample, mlp):
+    """QueryAndLRFGroup -> SharedMLP[6,32,64,128] -> max over neighbours (fine matcher PE, Fi:167-174)
+    as ONE HIP kernel (csrc/pe.hip): neighbour lists, frames and all MLP activations stay on chip;
+    fp32 matrix cores.  (B,N,3) -> (B,N,128) fp32."""
+    pts = _c(pts.float())
+    check_f32(pts, "pts")
+    B, N, _ = pts.shape
+    cache = getattr(mlp, "_hip_cache", None)
+    key = tuple((l.conv.weight._version, l.normlayer.bn.weight._version, l.normlayer.bn.running_mean._version,
+                 l.conv.weight.data_ptr()) for l in mlp.layers())
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            flat = []
+            for l in mlp.layers():
+                w, b = l.folded()
+                flat += [w.float().contiguous(), b.float().contiguous()]
+        assert [tuple(t.shape) for t in flat[::2]] == [(32, 6), (64, 32), (128, 64)], "kernel is built for [6,32,64,128]"
+        cache = (key, flat)
+        mlp._hip_cache = cache
+    w1, b1, w2, b2, w3, b3 = cache[1]
+    out = torch.empty(B, N, 128, dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        call("unopose_pe_group_mlp_max", ptr(pts), B, N, float(radius), int(nsample), ptr(w1), ptr(b1), ptr(w2),
+             ptr(b2), ptr(w3), ptr(b3), ptr(out), stream_ptr())
+    return out
+
+
+def pe_group_mlp_max_unfused(pts, radius, nsample, mlp, chunk=4):
+    """Same function as pe_group_mlp_max through the materialised (B,6,N,S) features (HIP fused
+    ball-query+group+LRF, then torch GEMMs with BN folded): A/B reference for tests and profiling."""
     outs = []
     folded = [l.folded() for l in mlp.layers()]
     with torch.autocast("cuda", enabled=False):
