@@ -148,6 +148,44 @@ int unopose_pe_group_mlp_max(const float *xyz, int B, int N, float radius, int n
                              const float *b2, const float *w3, const float *b3,
                              float *out, unopose_stream_t stream);
 
+/* ---- pose heads (core/unopose/utils/model_utils.py:411-490 coarse, :527-566 fine) ----
+ * atten (B,R,C) float32 similarity with background row/col 0; score1 (B,R-1), score2 (B,C-1).
+ * a_ij = softmax_row * softmax_col * s1_i * s2_j (s*_0 = 1).
+ *
+ * assign_labels: streaming softmax statistics into stats_ws (2*B*(R+C) floats:
+ * [rmax B*R | rsum B*R | cmax B*C | csum B*C]) and the foreground masks
+ * w1 (B,R-1) = [argmax_j a_ij > 0], w2 (B,C-1) = [argmax_i a_ij > 0]  (:444-447, :542-545). */
+int unopose_assign_labels(const float *atten, int B, int R, int C, const float *score1,
+                          const float *score2, float *stats_ws, float *w1, float *w2,
+                          unopose_stream_t stream);
+
+/* fine stage (:547-553): weight_i = sum_j a_ij w1_i w2_j, pred_i = sum_j (..) pts2_j / (weight_i + 1e-6). */
+int unopose_fine_correspondences(const float *atten, int B, int R, int C, const float *score1,
+                                 const float *score2, const float *stats_ws, const float *w1,
+                                 const float *w2, const float *pts2, float *weight, float *pred,
+                                 unopose_stream_t stream);
+
+/* out[bc,i] = min_j |p'_i - q_j| with p' = (p_i - t_bc) R_bc when R/t are given (row-vector
+ * convention of the reference, :481, :559), bc = b*cand_per_b + c.  p (B,N,3), q (B,M,3). */
+int unopose_min_dist(const float *p, const float *q, int B, int N, int M, const float *R,
+                     const float *t, int cand_per_b, float *out, unopose_stream_t stream);
+
+/* coarse stage (:449-474): CDF of (a_ij w1_i w2_j)^1.5 into cdf_ws (B,(R-1)*(C-1)), then for
+ * each of nprop hypotheses three searchsorted look-ups with rand (B,3*nprop), a 3-point
+ * Procrustes (register Jacobi SVD) and the mean residual: Rout (B,nprop,9), tout (B,nprop,3),
+ * dis (B,nprop). */
+int unopose_coarse_hypotheses(const float *atten, int B, int R, int C, const float *score1,
+                              const float *score2, const float *stats_ws, const float *w1,
+                              const float *w2, const float *rand, int nprop, const float *pts1,
+                              const float *pts2, float *cdf_ws, float *Rout, float *tout,
+                              float *dis, unopose_stream_t stream);
+
+/* coarse pose selection (:480-485): score[b,c] = sum(w1) / (sum_i w1_i min_j |(p1_i - t) R - p2_j| + 1e-8)
+ * for the hypotheses top[b,c] (int64 indices into the nprop hypotheses). */
+int unopose_coarse_scores(const float *pts1, const float *pts2, int B, int n1, int n2,
+                          const float *Rall, const float *tall, int nprop, const int64_t *top,
+                          int ncand, const float *w1, float *score, unopose_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,3 +190,32 @@ def test_fused_pe_kernel_vs_unfused(model, r, ns):
     assert out.shape == (3, 2048, 128)
     e = (out - ref).abs().max().item()
     assert e < 2e-4, e
+
+
+@torch.no_grad()
+def test_pose_head_kernels_vs_torch_composite():
+    """HIP pose heads vs the op-by-op torch composite on the constructed-similarity fixtures, plus a
+    full-size (2049x2049) fine head."""
+    from unopose_amd import ops
+
+    z = load("coarse_rt")
+    a = ops.coarse_pose(z["atten"], z["score"], z["p1"], z["p2"], z["rand"], 6000, 300)
+    b = ops.coarse_pose_torch(z["atten"], z["score"], z["p1"], z["p2"], z["rand"], 6000, 300)
+    assert err(a[0], b[0]) < 5e-5 and err(a[1], b[1]) < 5e-5
+    z = load("fine_rt")
+    a = ops.fine_pose(z["atten"], z["score"], z["p1"], z["p2"])
+    b = ops.fine_pose_torch(z["atten"], z["score"], z["p1"], z["p2"])
+    assert err(a[0], b[0]) < 1e-5 and err(a[1], b[1]) < 1e-5 and err(a[2], b[2]) < 1e-5
+    from helpers import constructed_similarity
+    from test_geom_gpu import norm_clouds
+
+    g = torch.Generator().manual_seed(31)
+    N = 2048
+    p2 = norm_clouds(N, 2, seed=32, repl_every=99)
+    perm = torch.stack([torch.randperm(N, generator=g) for _ in range(2)])
+    p1 = torch.gather(p2, 1, perm.unsqueeze(2).expand(-1, -1, 3)) + 0.002 * torch.randn(2, N, 3, generator=g)
+    atten, score = constructed_similarity(perm, N, g, n_bg=300)
+    a = ops.fine_pose(atten.cuda(), score.cuda(), p1.cuda(), p2.cuda())
+    b = ops.fine_pose_torch(atten.cuda(), score.cuda(), p1.cuda(), p2.cuda())
+    assert err(a[0], b[0]) < 1e-5 and err(a[1], b[1]) < 1e-5 and err(a[2], b[2]) < 1e-4
+    assert err(a[0], torch.eye(3).cuda().expand(2, -1, -1)) < 1e-2

@@ -33,6 +33,11 @@ SIGNATURES = {
     "unopose_lrf_global": [_P, _I, _I, _I, _P, _P],
     "unopose_query_lrf_group": [_P, _I, _I, _F, _I, _P, _P],
     "unopose_weighted_procrustes": [_P, _P, _P, _I, _I, _F, _F, _P, _P, _P],
+    "unopose_assign_labels": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "unopose_fine_correspondences": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "unopose_min_dist": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P],
+    "unopose_coarse_hypotheses": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "unopose_coarse_scores": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P],
     "unopose_pe_group_mlp_max": [_P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "unopose_geo_embedding": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P, _P, _P],
 }

@@ -293,7 +293,7 @@ def soft_assignment(atten, score1, score2):
     return a, label1, label2
 
 
-def coarse_pose(atten, score, pts1, pts2, rand, n1p=6000, n2p=300):
+def coarse_pose_torch(atten, score, pts1, pts2, rand, n1p=6000, n2p=300):
     """compute_coarse_Rt_overlap (model_utils.py:411-490); `rand` (B,3*n1p) is the uniform draw the
     reference makes inside forward (:462).  [torch composite + HIP 3-point Procrustes]"""
     B, N1, _ = pts1.shape
@@ -326,7 +326,7 @@ def coarse_pose(atten, score, pts1, pts2, rand, n1p=6000, n2p=300):
     return R, t, pose_score
 
 
-def fine_pose(atten, score, pts1, pts2, dis_thres=0.15):
+def fine_pose_torch(atten, score, pts1, pts2, dis_thres=0.15):
     """compute_fine_Rt_overlap (model_utils.py:527-566).  [torch composite + HIP weighted Procrustes]"""
     atten, pts1, pts2 = atten.float(), pts1.float(), pts2.float()
     N1 = pts1.shape[1]
@@ -340,3 +340,68 @@ def fine_pose(atten, score, pts1, pts2, dis_thres=0.15):
     mask = (l1 > 0).float()
     ps = ((dis < dis_thres).float() * mask).sum(1) / (mask.sum(1) + 1e-8)
     return R, t, ps * mask.mean(1)
+
+
+def _assign_labels(atten, score1, score2):
+    B, R, C = atten.shape
+    dev = atten.device
+    stats = torch.empty(2 * B * (R + C), dtype=torch.float32, device=dev)
+    w1 = torch.empty(B, R - 1, dtype=torch.float32, device=dev)
+    w2 = torch.empty(B, C - 1, dtype=torch.float32, device=dev)
+    call("unopose_assign_labels", ptr(atten), B, R, C, ptr(score1), ptr(score2), ptr(stats), ptr(w1), ptr(w2),
+         stream_ptr())
+    return stats, w1, w2
+
+
+def coarse_pose(atten, score, pts1, pts2, rand, n1p=6000, n2p=300):
+    """compute_coarse_Rt_overlap (model_utils.py:411-490) on HIP kernels (csrc/posehead.hip): streaming
+    assignment statistics, CDF + searchsorted + 3-point Procrustes + residual per hypothesis, candidate
+    scoring; torch only picks the top-k / argmax of tiny (B,6000) / (B,300) arrays."""
+    B, N1, _ = pts1.shape
+    N2 = pts2.shape[1]
+    atten, pts1, pts2 = _c(atten.float()), _c(pts1.float()), _c(pts2.float())
+    check_f32(atten, "atten")
+    score1, score2 = _c(score[:, :N1].float()), _c(score[:, N2:].float())  # NB `N2:` (model_utils.py:440)
+    rand = _c(rand.float())
+    dev = atten.device
+    with torch.cuda.device(dev):
+        stats, w1, w2 = _assign_labels(atten, score1, score2)
+        cdf = torch.empty(B, N1 * N2, dtype=torch.float32, device=dev)
+        rs = torch.empty(B, n1p, 3, 3, dtype=torch.float32, device=dev)
+        ts = torch.empty(B, n1p, 3, dtype=torch.float32, device=dev)
+        dis = torch.empty(B, n1p, dtype=torch.float32, device=dev)
+        call("unopose_coarse_hypotheses", ptr(atten), B, N1 + 1, N2 + 1, ptr(score1), ptr(score2), ptr(stats),
+             ptr(w1), ptr(w2), ptr(rand), n1p, ptr(pts1), ptr(pts2), ptr(cdf), ptr(rs), ptr(ts), ptr(dis),
+             stream_ptr())
+        top = torch.topk(dis, n2p, dim=1, largest=False)[1].contiguous()
+        sc = torch.empty(B, n2p, dtype=torch.float32, device=dev)
+        call("unopose_coarse_scores", ptr(pts1), ptr(pts2), B, N1, N2, ptr(rs), ptr(ts), n1p, ptr(top), n2p, ptr(w1),
+             ptr(sc), stream_ptr())
+    pose_score, best = sc.max(1)
+    hyp = torch.gather(top, 1, best.unsqueeze(1))  # (B,1)
+    R = torch.gather(rs, 1, hyp.reshape(B, 1, 1, 1).expand(-1, -1, 3, 3)).squeeze(1)
+    t = torch.gather(ts, 1, hyp.reshape(B, 1, 1).expand(-1, -1, 3)).squeeze(1)
+    return R, t, pose_score
+
+
+def fine_pose(atten, score, pts1, pts2, dis_thres=0.15):
+    """compute_fine_Rt_overlap (model_utils.py:527-566) on HIP kernels: five streaming passes over the
+    (B,N1+1,N2+1) similarity that write only O(N) statistics, weighted Procrustes (Jacobi), min-distance
+    verification."""
+    B, N1, _ = pts1.shape
+    N2 = pts2.shape[1]
+    atten, pts1, pts2 = _c(atten.float()), _c(pts1.float()), _c(pts2.float())
+    check_f32(atten, "atten")
+    score1, score2 = _c(score[:, :N1].float()), _c(score[:, N1:].float())
+    dev = atten.device
+    with torch.cuda.device(dev):
+        stats, w1, w2 = _assign_labels(atten, score1, score2)
+        weight = torch.empty(B, N1, dtype=torch.float32, device=dev)
+        pred = torch.empty(B, N1, 3, dtype=torch.float32, device=dev)
+        call("unopose_fine_correspondences", ptr(atten), B, N1 + 1, N2 + 1, ptr(score1), ptr(score2), ptr(stats),
+             ptr(w1), ptr(w2), ptr(pts2), ptr(weight), ptr(pred), stream_ptr())
+        R, t = weighted_procrustes(pred, pts1, weight, 0.001)
+        dis = torch.empty(B, N1, dtype=torch.float32, device=dev)
+        call("unopose_min_dist", ptr(pts1), ptr(pts2), B, N1, N2, ptr(R), ptr(t), 1, ptr(dis), stream_ptr())
+    ps = ((dis < dis_thres).float() * w1).sum(1) / (w1.sum(1) + 1e-8)
+    return R, t, ps * w1.mean(1)
