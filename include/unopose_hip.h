@@ -186,6 +186,17 @@ int unopose_coarse_scores(const float *pts1, const float *pts2, int B, int n1, i
                           const float *Rall, const float *tall, int nprop, const int64_t *top,
                           int ncand, const float *w1, float *score, unopose_stream_t stream);
 
+/* Attention core of the 4-head x 64 token transformers (core/unopose/model/transformer.py:130-148
+ * cross, :386-405 RPE self): out (B,n,256) = softmax((q k^T [+ qp . E]) * scale) v, all tensors
+ * bfloat16 bit patterns.  q (B,n,256), k (B,m,256) with channel = head*64 + c; vt (B,256,KP) = v
+ * transposed to channel-major and zero-padded to KP = unopose_token_attention_key_pad() keys;
+ * RPE only: qp (B,n,4,256) = q_h W_p,h (the folded proj_p), E (B,n,m,256) the geometric embedding;
+ * pass qp = E = NULL for plain (cross) attention.  m <= KP. */
+int unopose_token_attention(const void *q, const void *k, const void *vt, const void *qp,
+                            const void *E, int B, int n, int m, float scale, void *out,
+                            unopose_stream_t stream);
+int unopose_token_attention_key_pad(void);
+
 #ifdef __cplusplus
 }
 #endif

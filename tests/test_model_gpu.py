@@ -219,3 +219,28 @@ def test_pose_head_kernels_vs_torch_composite():
     b = ops.fine_pose_torch(atten.cuda(), score.cuda(), p1.cuda(), p2.cuda())
     assert err(a[0], b[0]) < 1e-5 and err(a[1], b[1]) < 1e-5 and err(a[2], b[2]) < 1e-4
     assert err(a[0], torch.eye(3).cuda().expand(2, -1, -1)) < 1e-2
+
+
+@torch.no_grad()
+def test_token_attention_kernel_bf16(model):
+    """Fused bf16 MFMA attention (RPE self + cross) vs the fp32 composite on 197 tokens.  bf16
+    operands: tolerance 3e-2 absolute on O(1) outputs, mean error < 4e-3."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(41)
+    B, n = 3, 197
+    pts = torch.cat([torch.ones(B, 1, 3), torch.rand(B, n - 1, 3, generator=g) * 1.2 - 0.6], 1).cuda()
+    E = ops.geo_embedding(pts, model.geo_embedding)
+    x = torch.randn(B, n, 256, generator=g).cuda()
+    y = torch.randn(B, n, 256, generator=g).cuda()
+    layer0 = model.coarse_point_matching.transformers[0].layers[0].attention.attention
+    layer1 = model.coarse_point_matching.transformers[0].layers[1].attention.attention
+    ref_self = ops.token_attention_torch(x, x, layer0, 4, E)
+    ref_cross = ops.token_attention_torch(x, y, layer1, 4, None)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out_self = ops.token_attention(x, x, layer0, 4, E)
+        out_cross = ops.token_attention(x, y, layer1, 4, None)
+    assert out_self.dtype == torch.bfloat16
+    for o, r in ((out_self, ref_self), (out_cross, ref_cross)):
+        e = (o.float() - r).abs()
+        assert e.max().item() < 3e-2 and e.mean().item() < 4e-3, (e.max().item(), e.mean().item())

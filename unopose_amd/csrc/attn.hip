@@ -1,0 +1,196 @@
+// Token attention of the correspondence transformer for gfx950 (C ABI part 2).
+//
+// Replaces the attention cores of MultiHeadAttention (cross) and RPEMultiHeadAttention (self, with
+// relative-position embedding) -- core/unopose/model/transformer.py:130-148 and :386-405 -- for the
+// 197-token coarse sequences (4 heads x 64):
+//     P = softmax((q k^T + q proj_p(E)[n,m]) / 8),  out = P v
+// The reference materialises proj_p(E) as a (B,4,n,m,64) tensor (5.09 GFLOP + 40 MB per cloud and layer).
+// Here the RPE term is folded, q.(W_p e + b_p) = (q W_p).e + const (the constant cancels in the
+// softmax), and ONE kernel streams E[n] (the only HBM-sized operand) exactly once: a wavefront owns four
+// query rows x four heads = the 16 rows of a v_mfma_f32_16x16x32_bf16 tile, so q k^T, the four per-row
+// (q W_p) E[n]^T products, the softmax (row == 16-lane DPP row) and P v all run on one set of
+// accumulators without touching HBM in between.
+#include "common.h"
+
+namespace unopose {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ u16 f2bf_rn(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+
+template <int XOR>
+__device__ __forceinline__ float swz_xor(float v) {  // butterfly inside 32 lanes, no LDS memory touched
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (XOR << 10) | 0x1F));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, swz_xor<1>(v));
+  v = fmaxf(v, swz_xor<2>(v));
+  v = fmaxf(v, swz_xor<4>(v));
+  v = fmaxf(v, swz_xor<8>(v));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += swz_xor<1>(v);
+  v += swz_xor<2>(v);
+  v += swz_xor<4>(v);
+  v += swz_xor<8>(v);
+  return v;
+}
+
+__device__ __forceinline__ bf16x8 zero8() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
+  return z;
+}
+
+constexpr int TA_NT = 14;          // key tiles of 16 -> up to 224 keys
+constexpr int TA_MP = TA_NT * 16;  // padded key count (V^T and the P staging use this stride)
+
+template <bool RPE>
+__global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__ q, const u16 *__restrict__ k,
+                                                         const u16 *__restrict__ vt, const u16 *__restrict__ qp,
+                                                         const u16 *__restrict__ E, int n, int m, float scale,
+                                                         u16 *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) u16 Pl[4][16][TA_MP];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * 4;  // first of this wave's 4 query rows
+  if (n0 >= n) return;
+  const int li = lane & 15, kg = lane >> 4;     // A: row li, k-group kg | B: column li, k-group kg
+  const int a_nl = li >> 2, a_h = li & 3;       // A-operand row = (query row a_nl, head a_h)
+  const bool a_valid = n0 + a_nl < n;
+  const u16 *Q = q + ((size_t)b * n + n0 + a_nl) * 256;
+  const u16 *K = k + (size_t)b * m * 256;
+
+  f32x4 acc[TA_NT];
+#pragma unroll
+  for (int t = 0; t < TA_NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- q k^T: block-diagonal A (row (n_l,h) only sees head h's 64 channels), B = K
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const int kk = ks * 32 + kg * 8;
+    bf16x8 a = zero8();
+    if (a_valid && (kk >> 6) == a_h) a = *reinterpret_cast<const bf16x8 *>(Q + kk);
+#pragma unroll
+    for (int t = 0; t < TA_NT; ++t) {
+      const int mm = t * 16 + li;
+      bf16x8 bv = zero8();
+      if (mm < m) bv = *reinterpret_cast<const bf16x8 *>(K + (size_t)mm * 256 + kk);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bv, acc[t], 0, 0, 0);
+    }
+  }
+  // ---- RPE term: for each of the 4 query rows, (q W_p)[n] . E[n,m,:]
+  if (RPE) {
+    for (int nl = 0; nl < 4; ++nl) {
+      if (n0 + nl >= n) break;  // wave-uniform
+      const u16 *QP = qp + (((size_t)b * n + n0 + nl) * 4 + a_h) * 256;
+      const u16 *En = E + ((size_t)b * n + n0 + nl) * (size_t)m * 256;
+      bf16x8 a[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        a[ks] = zero8();
+        if (a_nl == nl) a[ks] = *reinterpret_cast<const bf16x8 *>(QP + ks * 32 + kg * 8);
+      }
+#pragma unroll
+      for (int t = 0; t < TA_NT; ++t) {
+        const int mm = t * 16 + li;
+        if (t * 16 >= m) continue;  // uniform: tile entirely beyond the keys
+        const u16 *Er = En + (size_t)min(mm, m - 1) * 256 + kg * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(Er + ks * 32);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- softmax over keys: C/D layout row = kg*4 + reg = (query row kg, head reg), column = key li
+  float mx[4] = {-3e38f, -3e38f, -3e38f, -3e38f};
+#pragma unroll
+  for (int t = 0; t < TA_NT; ++t) {
+    const bool ok = t * 16 + li < m;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      acc[t][h] = ok ? acc[t][h] * scale : -3e38f;
+      mx[h] = fmaxf(mx[h], acc[t][h]);
+    }
+  }
+  float sm[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    mx[h] = row16_max(mx[h]);
+    sm[h] = 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < TA_NT; ++t) {
+    const bool ok = t * 16 + li < m;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float p = ok ? __expf(acc[t][h] - mx[h]) : 0.f;
+      acc[t][h] = p;
+      sm[h] += p;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 4; ++h) sm[h] = 1.f / row16_sum(sm[h]);
+  // ---- P (bf16) -> LDS in A-operand order: row (query row, head), column key
+#pragma unroll
+  for (int t = 0; t < TA_NT; ++t)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) Pl[wave][kg * 4 + h][t * 16 + li] = f2bf_rn(acc[t][h] * sm[h]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // ---- P v: B = V^T (channel-major, zero-padded keys); only the head-matching quarter is kept
+  bf16x8 pa[TA_MP / 32];
+#pragma unroll
+  for (int ks = 0; ks < TA_MP / 32; ++ks)
+    pa[ks] = *reinterpret_cast<const bf16x8 *>(&Pl[wave][li][ks * 32 + kg * 8]);
+  const u16 *VT = vt + (size_t)b * 256 * TA_MP;
+#pragma unroll
+  for (int nt = 0; nt < 16; ++nt) {
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u16 *Vr = VT + (size_t)(nt * 16 + li) * TA_MP + kg * 8;
+#pragma unroll
+    for (int ks = 0; ks < TA_MP / 32; ++ks) {
+      const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(Vr + ks * 32);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[ks], bv, o, 0, 0, 0);
+    }
+    // D row = (query row kg, head reg); channel tile nt belongs to head nt >> 2
+    if (n0 + kg < n) out[((size_t)b * n + n0 + kg) * 256 + nt * 16 + li] = f2bf_rn(o[nt >> 2]);
+  }
+}
+
+}  // namespace unopose
+
+using namespace unopose;
+
+extern "C" {
+
+int unopose_token_attention(const void *q, const void *k, const void *vt, const void *qp, const void *E, int B, int n,
+                            int m, float scale, void *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(q && k && vt && out, "token_attention: null pointer");
+  UNOPOSE_REQUIRE((qp == nullptr) == (E == nullptr), "token_attention: qp and E go together");
+  UNOPOSE_REQUIRE(B >= 0 && n >= 1 && m >= 1 && m <= TA_MP && B <= 65535,
+                  "token_attention: m=%d exceeds the %d-key tile", m, TA_MP);
+  if (B == 0) return UNOPOSE_OK;
+  dim3 grid(cdiv(n, 16), B);
+  hipStream_t s = (hipStream_t)stream;
+  if (E)
+    hipLaunchKernelGGL(token_attn_kernel<true>, grid, dim3(256), 0, s, (const u16 *)q, (const u16 *)k,
+                       (const u16 *)vt, (const u16 *)qp, (const u16 *)E, n, m, scale, (u16 *)out);
+  else
+    hipLaunchKernelGGL(token_attn_kernel<false>, grid, dim3(256), 0, s, (const u16 *)q, (const u16 *)k,
+                       (const u16 *)vt, (const u16 *)nullptr, (const u16 *)nullptr, n, m, scale, (u16 *)out);
+  return check_launch("token_attention");
+}
+
+int unopose_token_attention_key_pad(void) { return TA_MP; }
+
+}  // extern "C"

@@ -182,11 +182,48 @@ def geo_embedding_torch(points, m):
     return d_emb + a_emb
 
 
+_KEY_PAD = None
+
+
 def token_attention(x, mem, att, heads, embed=None):
     """MultiHeadAttention / RPEMultiHeadAttention core (transformer.py:130-148, 386-405): returns the
     concatenated heads (B,n,C) before the output Linear.  The RPE term q.proj_p(E) is folded:
     q.(W_p e + b_p) = (q W_p).e + q.b_p  (SURVEY.md App-F), so no (B,4,n,m,64) tensor exists.
-    [torch einsum for now]"""
+    Under autocast(bf16) the whole core (q k^T, folded RPE term, softmax, P v) is ONE HIP kernel on the
+    bf16 matrix cores (csrc/attn.hip) that streams E once; in fp32 the op-by-op composite below runs."""
+    global _KEY_PAD
+    if torch.is_autocast_enabled() and heads == 4 and x.shape[-1] == 256:
+        if _KEY_PAD is None:
+            from ._lib import lib
+            _KEY_PAD = lib().unopose_token_attention_key_pad()
+        if mem.shape[1] <= _KEY_PAD:
+            return _token_attention_hip(x, mem, att, embed)
+    return token_attention_torch(x, mem, att, heads, embed)
+
+
+def _token_attention_hip(x, mem, att, embed):
+    B, n, C = x.shape
+    m = mem.shape[1]
+    bf = torch.bfloat16
+    q = _c(att.proj_q(x).to(bf))
+    k = _c(att.proj_k(mem).to(bf))
+    v = att.proj_v(mem).to(bf)
+    vt = torch.zeros(B, C, _KEY_PAD, dtype=bf, device=x.device)
+    vt[:, :, :m] = v.transpose(1, 2)
+    qp = E = None
+    if embed is not None:
+        wp = att.proj_p.weight.reshape(4, 64, C).to(bf)
+        qp = _c(torch.einsum("bnhc,hcd->bnhd", q.reshape(B, n, 4, 64), wp))
+        E = _c(embed.to(bf))
+    out = torch.empty(B, n, C, dtype=bf, device=x.device)
+    with torch.cuda.device(x.device):
+        call("unopose_token_attention", ptr(q), ptr(k), ptr(vt), ptr(qp) if qp is not None else None,
+             ptr(E) if E is not None else None, B, n, m, 0.125, ptr(out), stream_ptr())
+    return out
+
+
+def token_attention_torch(x, mem, att, heads, embed=None):
+    """Op-by-op composite of the same function (fp32 path; A/B reference for the HIP kernel)."""
     B, n, C = x.shape
     hd = C // heads
     q = att.proj_q(x).reshape(B, n, heads, hd)
