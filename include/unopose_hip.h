@@ -142,11 +142,13 @@ int unopose_geo_embedding(const float *points, int B, int n, const void *wd_hi,
  * use_xyz) -> SharedMLP[6,32,64,128] (1x1 conv + eval BatchNorm + ReLU) -> max over neighbours
  * (core/unopose/model/oneref_predator_fine_point_matching.py:167-174).  xyz (B,N,3) ->
  * out (B,N,128) float32.  w1 (32,6), w2 (64,32), w3 (128,64) row-major [out][in] with
- * BatchNorm already folded in, b1/b2/b3 the folded biases.  nsample % 32 == 0. */
+ * BatchNorm already folded in, b1/b2/b3 the folded biases.  nsample % 32 == 0.
+ * bf16x3 = 0: exact fp32 matrix cores (v_mfma_f32_32x32x2_f32); bf16x3 != 0: bf16 matrix
+ * cores with hi/lo-split operands (3 MFMAs per product, ~2^-16 relative error). */
 int unopose_pe_group_mlp_max(const float *xyz, int B, int N, float radius, int nsample,
                              const float *w1, const float *b1, const float *w2,
                              const float *b2, const float *w3, const float *b3,
-                             float *out, unopose_stream_t stream);
+                             int bf16x3, float *out, unopose_stream_t stream);
 
 /* ---- pose heads (core/unopose/utils/model_utils.py:411-490 coarse, :527-566 fine) ----
  * atten (B,R,C) float32 similarity with background row/col 0; score1 (B,R-1), score2 (B,C-1).

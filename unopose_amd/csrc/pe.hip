@@ -20,6 +20,77 @@ namespace unopose {
 // channel held by accumulator register r of half-wave h in the 32x32 C/D layout
 __device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// Ball query (pointnet2 ball_query_gpu.cu:14-49 semantics) into the wave's LDS neighbour list and the
+// local reference frame of LRF_batch (pointnet2_utils.py:436-481) for one centre; wave-collective.
+__device__ __forceinline__ void pe_centre_frame(const float *sx, const float *sy, const float *sz, int N, int S,
+                                                float radius, float r2, int lane, float cx, float cy, float cz,
+                                                int *nbr, Vec3 &xp, Vec3 &yp, Vec3 &zp) {
+  // ---- ball query (pointnet2 ball_query_gpu.cu:14-49 semantics)
+  int cnt = 0, first = 0;
+  for (int k0 = 0; k0 < N && cnt < S; k0 += 64) {
+    const int k = k0 + lane;
+    bool hit = false;
+    if (k < N) {
+      const float x = sx[k], y = sy[k], z = sz[k];
+      const float d2 = (cx - x) * (cx - x) + (cy - y) * (cy - y) + (cz - z) * (cz - z);
+      hit = d2 < r2;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+      const int pre =
+          (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      const int pos = cnt + pre;
+      if (hit && pos < S) nbr[pos] = k;
+      if (cnt == 0) first = k0 + __builtin_ctzll(mask);
+      cnt += __builtin_popcountll(mask);
+    }
+  }
+  for (int l = min(cnt, S) + lane; l < S; l += 64) nbr[l] = first;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- local reference frame (LRF_batch, pointnet2_utils.py:436-481)
+  float a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+  for (int l = lane; l < S; l += 64) {
+    const int k = nbr[l];
+    const float x = cx - sx[k], y = cy - sy[k], z = cz - sz[k];
+    a00 += x * x; a01 += x * y; a02 += x * z; a11 += y * y; a12 += y * z; a22 += z * z;
+  }
+  const float inv_s = 1.f / (float)S;
+  a00 = wave_sum_f32(a00) * inv_s; a01 = wave_sum_f32(a01) * inv_s; a02 = wave_sum_f32(a02) * inv_s;
+  a11 = wave_sum_f32(a11) * inv_s; a12 = wave_sum_f32(a12) * inv_s; a22 = wave_sum_f32(a22) * inv_s;
+  Vec3 e0, e1, z0;
+  float l0, l1, l2;
+  eig_sym3(a00, a01, a02, a11, a12, a22, e0, e1, z0, l0, l1, l2);
+  int vote = 0;
+  for (int l0i = 0; l0i < S; l0i += 64) {
+    const int l = l0i + lane;
+    float pr = 0.f;
+    if (l < S) {
+      const int k = nbr[l];
+      pr = z0.x * (cx - sx[k]) + z0.y * (cy - sy[k]) + z0.z * (cz - sz[k]);
+    }
+    vote += __builtin_popcountll(__ballot(pr > 1e-3f)) - __builtin_popcountll(__ballot(pr < -1e-3f));
+  }
+  zp = vote < 0 ? scale(z0, -1.f) : z0;
+  float vx = 0, vy = 0, vz = 0;
+  for (int l = lane; l < S; l += 64) {
+    const int k = nbr[l];
+    const Vec3 xn = v3(sx[k] - cx, sy[k] - cy, sz[k] - cz);
+    const float nrm = dot(zp, xn);
+    const Vec3 vi = sub(xn, scale(zp, nrm));
+    float alpha = radius - sqrtf(dot(xn, xn));
+    alpha *= alpha;
+    const float ab = alpha * (nrm * nrm);
+    vx += ab * vi.x; vy += ab * vi.y; vz += ab * vi.z;
+  }
+  vx = wave_sum_f32(vx); vy = wave_sum_f32(vy); vz = wave_sum_f32(vz);
+  const float nacc = sqrtf(vx * vx + vy * vy + vz * vz) + 1e-10f;
+  xp = v3(vx / nacc, vy / nacc, vz / nacc);
+  yp = cross(xp, zp);
+}
+
 struct PeLds {
   // weights transposed to [k][out] so that lanes (l & 31) read consecutive floats
   float w1[6 * 32];
@@ -63,70 +134,8 @@ __global__ __launch_bounds__(256) void pe_group_mlp_max_kernel(
     const int j = (blockIdx.x * 4 + wave) * cpw + ci;
     if (j >= N) break;  // wave-uniform
     const float cx = sx[j], cy = sy[j], cz = sz[j];
-    // ---- ball query (pointnet2 ball_query_gpu.cu:14-49 semantics)
-    int cnt = 0, first = 0;
-    for (int k0 = 0; k0 < N && cnt < S; k0 += 64) {
-      const int k = k0 + lane;
-      bool hit = false;
-      if (k < N) {
-        const float x = sx[k], y = sy[k], z = sz[k];
-        const float d2 = (cx - x) * (cx - x) + (cy - y) * (cy - y) + (cz - z) * (cz - z);
-        hit = d2 < r2;
-      }
-      const unsigned long long mask = __ballot(hit);
-      if (mask) {
-        const int pre =
-            (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        const int pos = cnt + pre;
-        if (hit && pos < S) nbr[pos] = k;
-        if (cnt == 0) first = k0 + __builtin_ctzll(mask);
-        cnt += __builtin_popcountll(mask);
-      }
-    }
-    for (int l = min(cnt, S) + lane; l < S; l += 64) nbr[l] = first;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // ---- local reference frame (LRF_batch, pointnet2_utils.py:436-481)
-    float a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
-    for (int l = lane; l < S; l += 64) {
-      const int k = nbr[l];
-      const float x = cx - sx[k], y = cy - sy[k], z = cz - sz[k];
-      a00 += x * x; a01 += x * y; a02 += x * z; a11 += y * y; a12 += y * z; a22 += z * z;
-    }
-    const float inv_s = 1.f / (float)S;
-    a00 = wave_sum_f32(a00) * inv_s; a01 = wave_sum_f32(a01) * inv_s; a02 = wave_sum_f32(a02) * inv_s;
-    a11 = wave_sum_f32(a11) * inv_s; a12 = wave_sum_f32(a12) * inv_s; a22 = wave_sum_f32(a22) * inv_s;
-    Vec3 e0, e1, z0;
-    float l0, l1, l2;
-    eig_sym3(a00, a01, a02, a11, a12, a22, e0, e1, z0, l0, l1, l2);
-    int vote = 0;
-    for (int l0i = 0; l0i < S; l0i += 64) {
-      const int l = l0i + lane;
-      float pr = 0.f;
-      if (l < S) {
-        const int k = nbr[l];
-        pr = z0.x * (cx - sx[k]) + z0.y * (cy - sy[k]) + z0.z * (cz - sz[k]);
-      }
-      vote += __builtin_popcountll(__ballot(pr > 1e-3f)) - __builtin_popcountll(__ballot(pr < -1e-3f));
-    }
-    const Vec3 zp = vote < 0 ? scale(z0, -1.f) : z0;
-    float vx = 0, vy = 0, vz = 0;
-    for (int l = lane; l < S; l += 64) {
-      const int k = nbr[l];
-      const Vec3 xn = v3(sx[k] - cx, sy[k] - cy, sz[k] - cz);
-      const float nrm = dot(zp, xn);
-      const Vec3 vi = sub(xn, scale(zp, nrm));
-      float alpha = radius - sqrtf(dot(xn, xn));
-      alpha *= alpha;
-      const float ab = alpha * (nrm * nrm);
-      vx += ab * vi.x; vy += ab * vi.y; vz += ab * vi.z;
-    }
-    vx = wave_sum_f32(vx); vy = wave_sum_f32(vy); vz = wave_sum_f32(vz);
-    const float nacc = sqrtf(vx * vx + vy * vy + vz * vz) + 1e-10f;
-    const Vec3 xp = v3(vx / nacc, vy / nacc, vz / nacc);
-    const Vec3 yp = cross(xp, zp);
+    Vec3 xp, yp, zp;
+    pe_centre_frame(sx, sy, sz, N, S, radius, r2, lane, cx, cy, cz, nbr, xp, yp, zp);
 
     // ---- MLP over tiles of 32 neighbours, running max over tiles
     f32x16 rmax[4];
@@ -201,6 +210,210 @@ __global__ __launch_bounds__(256) void pe_group_mlp_max_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 hi/lo-split variant: the same three layers on v_mfma_f32_32x32x16_bf16 with both operands split
+// into hi + lo bf16 parts (a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, ~2^-16 relative error, fp32
+// accumulation): 3 bf16 MFMAs replace 8 fp32 MFMAs.  Layer chaining without data movement as above:
+// accumulator registers 8s..8s+7 of a 32x32 C/D tile hold, per half-wave hb, the channels
+// 16s + (e&3) + 8(e>>2) + 4hb (e = 0..7) -- exactly one 16-wide k-step of the next layer -- so the
+// weights are stored with their input channels permuted to k' = 16s + 8hb + e.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ u16 pe_f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+__device__ __forceinline__ float pe_bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+__device__ __forceinline__ int pe_kperm(int c) {  // input channel -> position in the permuted k order
+  const int cc = c & 15;
+  return (c & ~15) + ((cc >> 2) & 1) * 8 + (cc & 3) + 4 * (cc >> 3);
+}
+
+struct PeLdsB {
+  u16 w1h[32][24], w1l[32][24];   // K padded 6 -> 16 (+8 pad)
+  u16 w2h[64][40], w2l[64][40];   // K = 32 (+8 pad)
+  u16 w3h[128][64], w3l[128][64]; // K = 64, 16-byte slots XOR-swizzled by (row & 7)
+  float b1[32], b2[64], b3[128];
+};
+
+// split 8 fp32 accumulator values into packed bf16 hi / lo fragments (optionally bias + ReLU first)
+__device__ __forceinline__ void pe_split8(const float *v, bf16x8 &hi, bf16x8 &lo) {
+  union { bf16x8 v; u16 s[8]; } H, Lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const u16 h = pe_f2bf(v[e]);
+    H.s[e] = h;
+    Lo.s[e] = pe_f2bf(v[e] - pe_bf2f(h));
+  }
+  hi = H.v;
+  lo = Lo.v;
+}
+
+#define PE_MFMA3(acc, ah, al, bh, bl)                                       \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);      \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);      \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0)
+
+__global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
+    const float *__restrict__ xyz, int N, float radius, int S, int cpw, const float *__restrict__ w1,
+    const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
+    const float *__restrict__ w3, const float *__restrict__ b3, float *__restrict__ out) {
+  extern __shared__ float4 smem4[];
+  PeLdsB *L = reinterpret_cast<PeLdsB *>(smem4);
+  float *sx = reinterpret_cast<float *>(L + 1);
+  float *sy = sx + N, *sz = sy + N;
+  int *nbr_all = reinterpret_cast<int *>(sz + N);
+  float *stage_all = reinterpret_cast<float *>(nbr_all + 4 * S);
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  int *nbr = nbr_all + wave * S;
+  float *stage = stage_all + wave * 128;
+  const float *P = xyz + (size_t)b * N * 3;
+
+  for (int e = tid; e < N * 3; e += 256) {
+    const float v = P[e];
+    const int p = e / 3, comp = e - p * 3;
+    (comp == 0 ? sx : comp == 1 ? sy : sz)[p] = v;
+  }
+  for (int e = tid; e < 32 * 16; e += 256) {
+    const int o = e >> 4, kk = e & 15;
+    const float v = kk < 6 ? w1[o * 6 + kk] : 0.f;
+    const u16 h = pe_f2bf(v);
+    L->w1h[o][kk] = h;
+    L->w1l[o][kk] = pe_f2bf(v - pe_bf2f(h));
+  }
+  for (int e = tid; e < 64 * 32; e += 256) {
+    const int o = e >> 5, c = e & 31;
+    const float v = w2[e];
+    const u16 h = pe_f2bf(v);
+    L->w2h[o][pe_kperm(c)] = h;
+    L->w2l[o][pe_kperm(c)] = pe_f2bf(v - pe_bf2f(h));
+  }
+  for (int e = tid; e < 128 * 64; e += 256) {
+    const int o = e >> 6, c = e & 63;
+    const float v = w3[e];
+    const u16 h = pe_f2bf(v);
+    const int kp = pe_kperm(c) ^ ((o & 7) << 3);  // swizzle the 8-element (16-byte) slot
+    L->w3h[o][kp] = h;
+    L->w3l[o][kp] = pe_f2bf(v - pe_bf2f(h));
+  }
+  if (tid < 32) L->b1[tid] = b1[tid];
+  if (tid < 64) L->b2[tid] = b2[tid];
+  if (tid < 128) L->b3[tid] = b3[tid];
+  __syncthreads();
+  const float r2 = radius * radius;
+
+  for (int ci = 0; ci < cpw; ++ci) {
+    const int j = (blockIdx.x * 4 + wave) * cpw + ci;
+    if (j >= N) break;  // wave-uniform
+    const float cx = sx[j], cy = sy[j], cz = sz[j];
+    Vec3 xp, yp, zp;
+    pe_centre_frame(sx, sy, sz, N, S, radius, r2, lane, cx, cy, cz, nbr, xp, yp, zp);
+
+    f32x16 rmax[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rmax[t][r] = 0.f;
+    for (int t0 = 0; t0 < S; t0 += 32) {
+      // keep the weight fragments in LDS (re-read per tile) instead of letting the compiler hoist ~170
+      // registers of loop-invariant operands: leaves room for 2 waves / SIMD so one wave's VALU phases
+      // (ball query, frame, hi/lo splits) overlap the other's MFMAs
+      asm volatile("" ::: "memory");
+      const int k = nbr[t0 + col];
+      const float dx = sx[k] - cx, dy = sy[k] - cy, dz = sz[k] - cz;
+      const Vec3 q = v3(dx / radius, dy / radius, dz / radius);
+      float f[8] = {dx, dy, dz, dot(xp, q), dot(yp, q), dot(zp, q), 0.f, 0.f};
+      if (half) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;  // k' 8..15 of the padded first layer
+      }
+      bf16x8 xh, xl;
+      pe_split8(f, xh, xl);
+      // layer 1 (one k-step)
+      f32x16 h1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h1[r] = 0.f;
+      {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&L->w1h[col][half * 8]);
+        const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&L->w1l[col][half * 8]);
+        PE_MFMA3(h1, ah, al, xh, xl);
+      }
+      bf16x8 a1h[2], a1l[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(h1[s2 * 8 + e] + L->b1[cd_row(s2 * 8 + e, half)], 0.f);
+        pe_split8(v, a1h[s2], a1l[s2]);
+      }
+      // layer 2: 32 -> 64
+      bf16x8 a2h[4], a2l[4];
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        f32x16 h2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h2[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&L->w2h[ot * 32 + col][ks * 16 + half * 8]);
+          const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&L->w2l[ot * 32 + col][ks * 16 + half * 8]);
+          PE_MFMA3(h2, ah, al, a1h[ks], a1l[ks]);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            v[e] = fmaxf(h2[s2 * 8 + e] + L->b2[ot * 32 + cd_row(s2 * 8 + e, half)], 0.f);
+          pe_split8(v, a2h[ot * 2 + s2], a2l[ot * 2 + s2]);
+        }
+      }
+      // layer 3: 64 -> 128, running max
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot) {
+        f32x16 h3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h3[r] = 0.f;
+        const int row = ot * 32 + col;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int kp = (ks * 16 + half * 8) ^ ((row & 7) << 3);
+          const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&L->w3h[row][kp]);
+          const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&L->w3l[row][kp]);
+          PE_MFMA3(h3, ah, al, a2h[ks], a2l[ks]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          rmax[ot][r] = fmaxf(rmax[ot][r], fmaxf(h3[r] + L->b3[ot * 32 + cd_row(r, half)], 0.f));
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = rmax[t][r];
+        v = fmaxf(v, dpp_f32<0x111, 0xF>(v, 0.f));
+        v = fmaxf(v, dpp_f32<0x112, 0xF>(v, 0.f));
+        v = fmaxf(v, dpp_f32<0x114, 0xF>(v, 0.f));
+        v = fmaxf(v, dpp_f32<0x118, 0xF>(v, 0.f));
+        v = fmaxf(v, dpp_f32<0x142, 0xA>(v, 0.f));
+        if (col == 31) stage[t * 32 + cd_row(r, half)] = v;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float *O = out + ((size_t)b * N + j) * 128;
+    O[lane] = stage[lane];
+    O[lane + 64] = stage[lane + 64];
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+#undef PE_MFMA3
+
 }  // namespace unopose
 
 using namespace unopose;
@@ -209,24 +422,30 @@ extern "C" {
 
 int unopose_pe_group_mlp_max(const float *xyz, int B, int N, float radius, int nsample, const float *w1,
                              const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
-                             float *out, unopose_stream_t stream) {
+                             int bf16x3, float *out, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(xyz && w1 && b1 && w2 && b2 && w3 && b3 && out, "pe_group_mlp_max: null pointer");
   UNOPOSE_REQUIRE(B >= 0 && N >= 1 && nsample >= 32 && nsample % 32 == 0 && B <= 65535,
                   "pe_group_mlp_max: nsample must be a positive multiple of 32 (got %d)", nsample);
   if (B == 0) return UNOPOSE_OK;
-  const size_t lds = sizeof(PeLds) + ((size_t)3 * N + 4 * (size_t)nsample + 4 * 128) * 4;
+  const size_t lds = (bf16x3 ? sizeof(PeLdsB) : sizeof(PeLds)) + ((size_t)3 * N + 4 * (size_t)nsample + 4 * 128) * 4;
   UNOPOSE_REQUIRE(lds <= 160 * 1024, "pe_group_mlp_max: N=%d nsample=%d exceed the LDS tile", N, nsample);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)pe_group_mlp_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
+    (void)hipFuncSetAttribute((const void *)pe_group_mlp_max_bf16x3_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const long centres = (long)B * N;
   const int cpw = centres >= 32768 ? 8 : centres >= 8192 ? 4 : centres >= 2048 ? 2 : 1;
   dim3 grid(cdiv(N, 4 * cpw), B);
-  hipLaunchKernelGGL(pe_group_mlp_max_kernel, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius, nsample, cpw,
-                     w1, b1, w2, b2, w3, b3, out);
+  if (bf16x3)
+    hipLaunchKernelGGL(pe_group_mlp_max_bf16x3_kernel, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius,
+                       nsample, cpw, w1, b1, w2, b2, w3, b3, out);
+  else
+    hipLaunchKernelGGL(pe_group_mlp_max_kernel, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius, nsample,
+                       cpw, w1, b1, w2, b2, w3, b3, out);
   return check_launch("pe_group_mlp_max");
 }
 

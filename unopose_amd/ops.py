@@ -267,10 +267,13 @@ def focused_linear_attention(xq, xkv, att, heads, focusing):
     return x.reshape(B, i, C).to(dt)
 
 
-def pe_group_mlp_max(pts, radius, nsample, mlp):
+def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None):
     """QueryAndLRFGroup -> SharedMLP[6,32,64,128] -> max over neighbours (fine matcher PE, Fi:167-174)
     as ONE HIP kernel (csrc/pe.hip): neighbour lists, frames and all MLP activations stay on chip;
-    fp32 matrix cores.  (B,N,3) -> (B,N,128) fp32."""
+    (B,N,3) -> (B,N,128) fp32.  Matrix-core precision: exact fp32 MFMA by default; under autocast(bf16)
+    (or bf16x3=True) bf16 MFMA with hi/lo-split operands (~2^-16 relative error, ~5x the fp32 MFMA rate)."""
+    if bf16x3 is None:
+        bf16x3 = torch.is_autocast_enabled()
     pts = _c(pts.float())
     check_f32(pts, "pts")
     B, N, _ = pts.shape
@@ -290,7 +293,7 @@ def pe_group_mlp_max(pts, radius, nsample, mlp):
     out = torch.empty(B, N, 128, dtype=torch.float32, device=pts.device)
     with torch.cuda.device(pts.device):
         call("unopose_pe_group_mlp_max", ptr(pts), B, N, float(radius), int(nsample), ptr(w1), ptr(b1), ptr(w2),
-             ptr(b2), ptr(w3), ptr(b3), ptr(out), stream_ptr())
+             ptr(b2), ptr(w3), ptr(b3), int(bool(bf16x3)), ptr(out), stream_ptr())
     return out
 
 
