@@ -127,7 +127,8 @@ int unopose_weighted_procrustes(const float *src, const float *ref,
 
 /* GeometricStructureEmbedding.forward (core/unopose/model/transformer.py:303-350):
  * points (B,n,3) -> out (B,n,n,256), float32 or bfloat16 (out_bf16).  hidden_dim = 256,
- * angle_k = 3.  Weights are passed as bfloat16 bit patterns, row-major [out][in]:
+ * angle_k = 3.  Weights are passed as bfloat16 bit patterns in MFMA-fragment order
+ * [k/16][out/32][(k%16)/8][out%32][k%8] (so one wave-wide operand load is 1 KiB contiguous):
  * w*_hi = bf16(W), w*_lo = bf16(W - float(w*_hi)) (only read when split != 0: hi/lo split
  * keeps fp32-class accuracy on the bf16 matrix cores).  bias_sum = proj_d.bias + proj_a.bias,
  * div_term = the 128 sinusoid frequencies, knn_ws = B*n*3 int32 of scratch. */

@@ -46,6 +46,13 @@ __device__ __forceinline__ void sincos_cw(float x, float &s, float &c) {
   c = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// |x| <= ~0.35: Taylor polynomials, absolute error < 1e-8
+__device__ __forceinline__ void sincos_small(float x, float &s, float &c) {
+  const float z = x * x;
+  s = fmaf(fmaf(fmaf(-1.9841270e-4f, z, 8.3333333e-3f), z, -1.6666667e-1f) * z, x, x);
+  c = fmaf(fmaf(fmaf(-1.3888889e-3f, z, 4.1666667e-2f), z, -0.5f), z, 1.0f);
+}
+
 // k nearest neighbours (self excluded) of every point of a small cloud: knn (B,n,3).
 __global__ __launch_bounds__(256) void geo_knn_kernel(const float *__restrict__ pts, int n,
                                                       int32_t *__restrict__ knn) {
@@ -95,9 +102,10 @@ __global__ __launch_bounds__(GE_THREADS) void geo_embed_kernel(
   const int32_t *KNN = knn + (size_t)b * n * 3;
 
   // ---------------- phase 1: sinusoids of 4 x 32 index values -> LDS (bf16, A-operand layout)
-  const float div0 = div_term[lane], div1 = div_term[lane + 64];
-  for (int c = wave; c < 4 * GE_PAIRS; c += GE_THREADS / 64) {
-    const int set = c >> 5, row = c & 31;
+  // (a) the 128 index values of the tile, ONE lane each (waves 0-1), parked in LDS
+  float *sidx = reinterpret_cast<float *>(Ahi + (SPLIT ? 2 : 1) * 4 * GE_PAIRS * 512);  // [128]
+  if (tid < 4 * GE_PAIRS) {
+    const int set = tid >> 5, row = tid & 31;
     const int pair = min(pair0 + row, nn - 1);
     const int i = pair / n, j = pair - i * n;
     const float xi = P[i * 3], yi = P[i * 3 + 1], zi = P[i * 3 + 2];
@@ -115,11 +123,24 @@ __global__ __launch_bounds__(GE_THREADS) void geo_embed_kernel(
       const float cosv = 0.0f + (rx * ax + ry * ay + rz * az);
       idx = atan2f(sinv, cosv) * factor_a;
     }
+    sidx[tid] = idx;
+  }
+  __syncthreads();
+  // (b) lane t of every wave owns frequencies t and t+64; the upper one has div_term <= 1e-2, so its
+  // argument stays below ~0.3 for any index < 32 and needs no range reduction
+  const float div0 = div_term[lane], div1 = div_term[lane + 64];
+  for (int c = wave; c < 4 * GE_PAIRS; c += GE_THREADS / 64) {
+    const float idx = sidx[c];
     float s0, c0, s1, c1;
     sincos_cw(idx * div0, s0, c0);
-    sincos_cw(idx * div1, s1, c1);
+    const float w1 = idx * div1;
+    if (fabsf(idx) < 32.f) {  // wave-uniform
+      sincos_small(w1, s1, c1);
+    } else {
+      sincos_cw(w1, s1, c1);
+    }
     // channel 2t = sin(w_t), 2t+1 = cos(w_t)  (transformer.py:278-282)
-    const int rbase = (set * GE_PAIRS + row);
+    const int rbase = c;  // = set * GE_PAIRS + row
     const u16 h0 = f2bf(s0), h1 = f2bf(c0), h2 = f2bf(s1), h3 = f2bf(c1);
     *reinterpret_cast<uint32_t *>(Ahi + ge_swz(rbase, lane * 4)) = (uint32_t)h0 | ((uint32_t)h1 << 16);
     *reinterpret_cast<uint32_t *>(Ahi + ge_swz(rbase, (lane + 64) * 4)) = (uint32_t)h2 | ((uint32_t)h3 << 16);
@@ -140,18 +161,20 @@ __global__ __launch_bounds__(GE_THREADS) void geo_embed_kernel(
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
   const int arow = lane & 31, khalf = lane >> 5;
   const int ch = wave * 32 + (lane & 31);  // B operand column = output channel
-  const bf16x8 *Wd_hi = reinterpret_cast<const bf16x8 *>(wd_hi + (size_t)ch * GE_DIM);
-  const bf16x8 *Wa_hi = reinterpret_cast<const bf16x8 *>(wa_hi + (size_t)ch * GE_DIM);
-  const bf16x8 *Wd_lo = SPLIT ? reinterpret_cast<const bf16x8 *>(wd_lo + (size_t)ch * GE_DIM) : nullptr;
-  const bf16x8 *Wa_lo = SPLIT ? reinterpret_cast<const bf16x8 *>(wa_lo + (size_t)ch * GE_DIM) : nullptr;
+  // weights arrive in MFMA-fragment order [k-step 16][channel group 8][lane 64][8 bf16]: one B-operand
+  // load of a wave is 1 KiB contiguous (8 cache lines instead of 32 strided ones)
+  const bf16x8 *Wd_hi = reinterpret_cast<const bf16x8 *>(wd_hi) + wave * 64 + lane;
+  const bf16x8 *Wa_hi = reinterpret_cast<const bf16x8 *>(wa_hi) + wave * 64 + lane;
+  const bf16x8 *Wd_lo = SPLIT ? reinterpret_cast<const bf16x8 *>(wd_lo) + wave * 64 + lane : nullptr;
+  const bf16x8 *Wa_lo = SPLIT ? reinterpret_cast<const bf16x8 *>(wa_lo) + wave * 64 + lane : nullptr;
 #pragma unroll 2
   for (int ks = 0; ks < GE_DIM / 16; ++ks) {
     const int kidx = ks * 2 + khalf;  // which group of 8 k's this lane holds
-    const bf16x8 bd = Wd_hi[kidx], ba = Wa_hi[kidx];
+    const bf16x8 bd = Wd_hi[ks * 512], ba = Wa_hi[ks * 512];
     bf16x8 bdl, bal;
     if (SPLIT) {
-      bdl = Wd_lo[kidx];
-      bal = Wa_lo[kidx];
+      bdl = Wd_lo[ks * 512];
+      bal = Wa_lo[ks * 512];
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -204,7 +227,7 @@ int unopose_geo_embedding(const float *points, int B, int n, const void *wd_hi, 
   int rc = check_launch("geo_knn");
   if (rc) return rc;
   dim3 grid(cdiv((long)n * n, GE_PAIRS), B);
-  const size_t lds = (size_t)4 * GE_PAIRS * 512 * (split ? 2 : 1);
+  const size_t lds = (size_t)4 * GE_PAIRS * 512 * (split ? 2 : 1) + 4 * GE_PAIRS * sizeof(float);
   const u16 *dh = (const u16 *)wd_hi, *dl = (const u16 *)wd_lo, *ah = (const u16 *)wa_hi, *al = (const u16 *)wa_lo;
 #define UNOPOSE_GE_LAUNCH(SP, OB)                                                                               \
   hipLaunchKernelGGL((geo_embed_kernel<SP, OB>), grid, dim3(GE_THREADS), lds, s, points, knn_ws, dh, dl, ah, al, \

@@ -124,6 +124,12 @@ def _bf16_split(w):
     return hi.contiguous(), lo.contiguous()
 
 
+def _mfma_fragment_order(w):
+    """(256 out, 256 in) -> [k/16][out/32][(k%16)/8][out%32][k%8], the B-operand order of
+    v_mfma_f32_32x32x16_bf16 when wave w owns output channels [32w, 32w+32)."""
+    return w.reshape(8, 32, 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
+
+
 def geo_embedding(points, m, out_dtype=None):
     """GeometricStructureEmbedding.forward (transformer.py:303-350) as ONE fused HIP kernel
     (sinusoid generation -> MFMA -> max-over-k epilogue; csrc/embed.hip).  Under autocast(bf16) the
@@ -139,8 +145,8 @@ def geo_embedding(points, m, out_dtype=None):
     key = (m.proj_d.weight._version, m.proj_a.weight._version, m.proj_d.weight.data_ptr(), m.proj_d.weight.device)
     if cache is None or cache[0] != key:
         assert m.proj_d.weight.shape == (256, 256) and m.angle_k == 3, "kernel is built for hidden_dim=256, k=3"
-        wdh, wdl = _bf16_split(m.proj_d.weight.detach())
-        wah, wal = _bf16_split(m.proj_a.weight.detach())
+        wdh, wdl = (_mfma_fragment_order(t) for t in _bf16_split(m.proj_d.weight.detach()))
+        wah, wal = (_mfma_fragment_order(t) for t in _bf16_split(m.proj_a.weight.detach()))
         bias = (m.proj_d.bias.detach().float() + m.proj_a.bias.detach().float()).contiguous()
         cache = (key, wdh, wdl, wah, wal, bias, m.embedding.div_term.detach().float().contiguous())
         m._hip_cache = cache
