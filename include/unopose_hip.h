@@ -200,6 +200,13 @@ int unopose_token_attention(const void *q, const void *k, const void *vt, const 
                             unopose_stream_t stream);
 int unopose_token_attention_key_pad(void);
 
+/* ViT attention core (timm Attention as driven by core/unopose/model/oneref_feature_extraction.py:38-41):
+ * out (B,T,H*64) = softmax(q k^T / 8) v per head, flash-style.  qkv (B,T,3,H,64) = the fused qkv Linear
+ * output, vt (B,H,64,TP) = v transposed to channel-major and zero-padded to TP (multiple of 32) keys;
+ * all bfloat16 bit patterns. */
+int unopose_vit_attention(const void *qkv, const void *vt, int B, int T, int TP, int H, void *out,
+                          unopose_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

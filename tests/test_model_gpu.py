@@ -248,3 +248,21 @@ def test_token_attention_kernel_bf16(model):
     for o, r in ((out_self, ref_self), (out_cross, ref_cross)):
         e = (o.float() - r).abs()
         assert e.max().item() < 3e-2 and e.mean().item() < 4e-3, (e.max().item(), e.mean().item())
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("T", [261, 1374, 40])
+def test_vit_flash_attention_kernel(T):
+    """Flash-style bf16 MFMA ViT attention vs the fp32 composite (T = 261: 224x224 crops, 1374: the
+    518x518 stress shape, 40: ragged tail)."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(T)
+    qkv = torch.randn(2, T, 3 * 768, generator=g).cuda()
+    qkv[:, :, :768] *= 2.0  # sharper softmax
+    ref = ops.vit_attention_torch(qkv, 12)
+    out = ops.vit_attention(qkv.bfloat16(), 12)
+    assert out.dtype == torch.bfloat16 and out.shape == ref.shape
+    ref_b = ops.vit_attention_torch(qkv.bfloat16().float(), 12)  # same bf16-rounded inputs
+    e = (out.float() - ref_b).abs()
+    assert e.max().item() < 3e-2 and e.mean().item() < 2e-3, (e.max().item(), e.mean().item())

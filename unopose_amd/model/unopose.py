@@ -125,17 +125,32 @@ class UNOPose(nn.Module):
         radius = torch.norm(tem_pts - tem_pts.mean(1, keepdim=True), dim=2).max(1)[0]
         dense_pm = dense_pm / (radius.reshape(-1, 1, 1) + 1e-6)
         tem_n = tem_pts / (radius.reshape(-1, 1, 1) + 1e-6)
-        # FPS of the reference cloud only needs points: issue it before the ViT so it overlaps
-        idx_o = ops.furthest_point_sample(tem_n, self.fine_npoint)
+        # The serial geometry chain (FPS 5000->2048: 2047 dependent iterations on B CUs) only needs the
+        # points, so it runs on a side HIP stream underneath the ViT GEMMs of the main stream.
+        main = torch.cuda.current_stream()
+        side = self._side_stream(tem_n.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            idx_o = ops.furthest_point_sample(tem_n, self.fine_npoint)
+            dense_po = ops.gather_rows(tem_n, idx_o)
+            sel_choose = torch.gather(tem_choose, 1, idx_o.long())
+            for t in (idx_o, dense_po, sel_choose):
+                t.record_stream(main)
         # both crops through the ViT as ONE batch of 2B images
         B = rgb.shape[0]
         low, (H, W) = net.lowres_map(torch.cat([rgb, tem_rgb], 0))
         dense_fm = ops.bilinear_sample_pixels(low[:B], choose, H, W)
+        main.wait_stream(side)
         # only the FPS-selected reference pixels are ever interpolated (gather commutes with sampling)
-        sel_choose = torch.gather(tem_choose, 1, idx_o.long())
         dense_fo = ops.bilinear_sample_pixels(low[B:], sel_choose, H, W)
-        dense_po = ops.gather_rows(tem_n, idx_o)
         return dense_pm, dense_fm, dense_po, dense_fo, radius
+
+    def _side_stream(self, device):
+        s = getattr(self, "_side", None)
+        if s is None or s.device != device:
+            s = torch.cuda.Stream(device=device)
+            self._side = s
+        return s
 
     def _sample_wlrf(self, pts, pts_lrf, feats, npoint):
         """U:156-177 (gathers done in (B,N,C) layout)."""
