@@ -207,6 +207,18 @@ int unopose_token_attention_key_pad(void);
 int unopose_vit_attention(const void *qkv, const void *vt, int B, int T, int TP, int H, void *out,
                           unopose_stream_t stream);
 
+/* out = LayerNorm(a (+ b)) * w + bias over the last dimension C (<= 1024), rows x C row-major.
+ * a / b / out are float32 or bfloat16 (flags); b may be NULL.  One pass instead of the reference's
+ * add + layer_norm (+ autocast casts): transformer.py:151-193, timm Block norm1/norm2. */
+int unopose_add_layernorm(const void *a, int a_bf16, const void *b, int b_bf16, const float *w,
+                          const float *bias, long rows, int C, float eps, void *out, int out_bf16,
+                          unopose_stream_t stream);
+
+/* x (rows,C) float32 += gamma (C) * y (rows,C) bfloat16, in place: the LayerScale residual of a
+ * timm ViT block (x = x + ls(branch(x))). */
+int unopose_scale_residual(float *x, const void *y_bf16, const float *gamma, long rows, int C,
+                           unopose_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

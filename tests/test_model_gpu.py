@@ -266,3 +266,40 @@ def test_vit_flash_attention_kernel(T):
     ref_b = ops.vit_attention_torch(qkv.bfloat16().float(), 12)  # same bf16-rounded inputs
     e = (out.float() - ref_b).abs()
     assert e.max().item() < 3e-2 and e.mean().item() < 2e-3, (e.max().item(), e.mean().item())
+
+
+@torch.no_grad()
+def test_fused_row_kernels():
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    for C in (256, 768):
+        a = torch.randn(1000, C, generator=g).cuda()
+        b = torch.randn(1000, C, generator=g).cuda()
+        ln = torch.nn.LayerNorm(C, eps=1e-6).cuda()
+        ln.weight.data.uniform_(0.5, 1.5)
+        ln.bias.data.normal_()
+        ref = ln(a + b)
+        assert err(ops.add_layernorm(a, b, ln, torch.float32), ref) < 2e-5
+        assert err(ops.add_layernorm(a, None, ln, torch.float32), ln(a)) < 2e-5
+        assert err(ops.add_layernorm(a.bfloat16(), b, ln, torch.bfloat16), ln(a.bfloat16().float() + b)) < 4e-2
+        x = a.clone()
+        y = b.bfloat16()
+        gam = torch.rand(C, generator=g).cuda()
+        assert err(ops.scale_residual_(x, y, gam), a + gam * y.float()) < 1e-6
+
+
+@torch.no_grad()
+def test_vit_autocast_fused_path_matches_unfused(tamed):
+    """The ViT under autocast (fused LayerNorm/LayerScale glue + flash attention) vs the same weights in
+    fp32: bf16-level agreement of the sampled pixel features."""
+    m = tamed[1024]
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(2, 3, 224, 224, generator=g).cuda()
+    choose = torch.randint(0, 224 * 224, (2, 500), generator=g).cuda()
+    net = m.feature_extraction.rgb_net
+    ref = net.pixel_features(img, choose)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = net.pixel_features(img, choose)
+    e = (out.float() - ref).abs()
+    assert e.mean().item() / ref.abs().mean().item() < 2e-2

@@ -57,6 +57,15 @@ class _Block(nn.Module):
         self.ls2 = _LayerScale(dim)
 
     def forward(self, x):
+        if torch.is_autocast_enabled() and x.dtype == torch.float32 and x.is_cuda:
+            # fused glue (csrc/fused.hip): LayerNorm -> bf16 in one pass, LayerScale residual in one pass;
+            # the residual stream itself stays fp32 exactly as under the reference's autocast
+            # (x is updated IN PLACE: ViT.forward owns the residual stream and rebinds it every block)
+            x = x.contiguous()
+            y = self.attn(ops.add_layernorm(x, None, self.norm1, torch.bfloat16))
+            ops.scale_residual_(x, y, self.ls1.gamma)
+            y = self.mlp(ops.add_layernorm(x, None, self.norm2, torch.bfloat16))
+            return ops.scale_residual_(x, y, self.ls2.gamma)
         x = x + self.attn(self.norm1(x)) * self.ls1.gamma
         return x + self.mlp(self.norm2(x)) * self.ls2.gamma
 
@@ -99,7 +108,8 @@ class ViT(nn.Module):
         for i, blk in enumerate(self.blocks):
             x = blk(x)
             if i in taps:
-                outs.append(self.norm(x))
+                outs.append(ops.add_layernorm(x, None, self.norm) if x.is_cuda and torch.is_autocast_enabled()
+                            else self.norm(x))
         return outs
 
 

@@ -467,3 +467,34 @@ def fine_pose(atten, score, pts1, pts2, dis_thres=0.15):
         call("unopose_min_dist", ptr(pts1), ptr(pts2), B, N1, N2, ptr(R), ptr(t), 1, ptr(dis), stream_ptr())
     ps = ((dis < dis_thres).float() * w1).sum(1) / (w1.sum(1) + 1e-8)
     return R, t, ps * w1.mean(1)
+
+
+def add_layernorm(a, b, norm, out_dtype=None):
+    """LayerNorm(a + b) in one HIP pass (b may be None); a/b fp32 or bf16, output `out_dtype`
+    (default: bf16 under autocast, else a.dtype).  norm: nn.LayerNorm."""
+    if out_dtype is None:
+        out_dtype = torch.bfloat16 if torch.is_autocast_enabled() else a.dtype
+    a = _c(a)
+    C = a.shape[-1]
+    rows = a.numel() // C
+    if b is not None:
+        b = _c(b)
+        assert b.shape == a.shape
+    out = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+    ok = (torch.float32, torch.bfloat16)
+    assert a.dtype in ok and out_dtype in ok and (b is None or b.dtype in ok) and a.is_cuda
+    with torch.cuda.device(a.device):
+        call("unopose_add_layernorm", ptr(a), int(a.dtype == torch.bfloat16), ptr(b) if b is not None else None,
+             int(b is not None and b.dtype == torch.bfloat16), ptr(norm.weight), ptr(norm.bias), rows, C,
+             float(norm.eps), ptr(out), int(out_dtype == torch.bfloat16), stream_ptr())
+    return out
+
+
+def scale_residual_(x, y, gamma):
+    """x (fp32, contiguous) += gamma * y (bf16) in place (ViT LayerScale residual)."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and y.dtype == torch.bfloat16
+    y = _c(y)
+    C = x.shape[-1]
+    with torch.cuda.device(x.device):
+        call("unopose_scale_residual", ptr(x), ptr(y), ptr(gamma), x.numel() // C, C, stream_ptr())
+    return x
