@@ -227,7 +227,10 @@ class _AttentionOutput(nn.Module):
         self.norm = nn.LayerNorm(d)
 
     def forward(self, x):
-        return self.norm(x + self.squeeze(F.relu(self.expand(x))))
+        y = self.squeeze(F.relu(self.expand(x)))
+        if x.is_cuda and torch.is_autocast_enabled():
+            return ops.add_layernorm(x, y, self.norm)  # one pass, bf16 out (csrc/fused.hip)
+        return self.norm(x + y)
 
 
 class TransformerLayer(nn.Module):
@@ -242,7 +245,10 @@ class TransformerLayer(nn.Module):
     def forward(self, x, mem, embed=None):
         a = self.attention
         h = ops.token_attention(x, mem, a.attention, self.heads, embed)
-        x = a.norm(a.linear(h) + x)
+        if x.is_cuda and torch.is_autocast_enabled():
+            x = ops.add_layernorm(a.linear(h), x, a.norm)
+        else:
+            x = a.norm(a.linear(h) + x)
         return self.output(x)
 
 
@@ -290,7 +296,10 @@ class LinearTransformerLayer(nn.Module):
     def forward(self, x, mem):
         a = self.attention
         h = ops.focused_linear_attention(x, mem, a.attention, self.heads, self.focusing_factor)
-        x = a.norm(a.linear(h) + x)
+        if x.is_cuda and torch.is_autocast_enabled():
+            x = ops.add_layernorm(a.linear(h), x, a.norm)
+        else:
+            x = a.norm(a.linear(h) + x)
         return self.output(x)
 
 

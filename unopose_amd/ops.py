@@ -223,19 +223,57 @@ def token_attention(x, mem, att, heads, embed=None):
     return token_attention_torch(x, mem, att, heads, embed)
 
 
+def _attn_weights(att, rpe):
+    """bf16 projection weights of one attention module, concatenated so that q | k | v (| the folded
+    RPE query q W_p, 4 x 256) come out of as few GEMMs as possible.  Folding in fp32:
+    (x Wq_h^T + bq_h) Wp_h = x (Wp_h^T Wq_h)^T + bq_h Wp_h."""
+    key = (att.proj_q.weight._version, att.proj_k.weight._version, att.proj_v.weight._version,
+           att.proj_q.weight.data_ptr(), att.proj_q.weight.device, rpe)
+    cache = getattr(att, "_hip_cache", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    with torch.no_grad():
+        bf = torch.bfloat16
+        wq, bq = att.proj_q.weight.float(), att.proj_q.bias.float()
+        parts_w, parts_b = [wq], [bq]
+        if rpe:
+            wp = att.proj_p.weight.float().reshape(4, 64, 256)  # [h][c][d]
+            wqh = wq.reshape(4, 64, 256)                         # [h][c][in]
+            parts_w.append(torch.einsum("hcd,hci->hdi", wp, wqh).reshape(1024, 256))
+            parts_b.append(torch.einsum("hcd,hc->hd", wp, bq.reshape(4, 64)).reshape(1024))
+        w_q = torch.cat(parts_w, 0).to(bf).contiguous()
+        b_q = torch.cat(parts_b, 0).to(bf).contiguous()
+        w_kv = torch.cat([att.proj_k.weight.float(), att.proj_v.weight.float()], 0).to(bf).contiguous()
+        b_kv = torch.cat([att.proj_k.bias.float(), att.proj_v.bias.float()], 0).to(bf).contiguous()
+        w_all = torch.cat([w_q, w_kv], 0).contiguous()
+        b_all = torch.cat([b_q, b_kv], 0).contiguous()
+    val = (w_q, b_q, w_kv, b_kv, w_all, b_all)
+    att._hip_cache = (key, val)
+    return val
+
+
 def _token_attention_hip(x, mem, att, embed):
     B, n, C = x.shape
     m = mem.shape[1]
     bf = torch.bfloat16
-    q = _c(att.proj_q(x).to(bf))
-    k = _c(att.proj_k(mem).to(bf))
-    v = att.proj_v(mem).to(bf)
+    rpe = embed is not None
+    w_q, b_q, w_kv, b_kv, w_all, b_all = _attn_weights(att, rpe)
+    nq = w_q.shape[0]
+    xb = x.to(bf)
+    with torch.autocast("cuda", enabled=False):
+        if mem is x:  # self-attention: one GEMM for q | qp | k | v
+            y = F.linear(xb, w_all, b_all)
+            yq, ykv = y[..., :nq], y[..., nq:]
+        else:
+            yq = F.linear(xb, w_q, b_q)
+            ykv = F.linear(mem.to(bf), w_kv, b_kv)
+    q = _c(yq[..., :C])
+    k = _c(ykv[..., :C])
     vt = torch.zeros(B, C, _KEY_PAD, dtype=bf, device=x.device)
-    vt[:, :, :m] = v.transpose(1, 2)
+    vt[:, :, :m] = ykv[..., C:].transpose(1, 2)
     qp = E = None
-    if embed is not None:
-        wp = att.proj_p.weight.reshape(4, 64, C).to(bf)
-        qp = _c(torch.einsum("bnhc,hcd->bnhd", q.reshape(B, n, 4, 64), wp))
+    if rpe:
+        qp = _c(yq[..., C:])  # (B,n,4*256)
         E = _c(embed.to(bf))
     out = torch.empty(B, n, C, dtype=bf, device=x.device)
     with torch.cuda.device(x.device):
