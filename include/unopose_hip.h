@@ -219,6 +219,15 @@ int unopose_add_layernorm(const void *a, int a_bf16, const void *b, int b_bf16, 
 int unopose_scale_residual(float *x, const void *y_bf16, const float *gamma, long rows, int C,
                            unopose_stream_t stream);
 
+/* Focused linear attention core (core/unopose/model/transformer.py:533-568), 4 heads x 64.
+ * x (B,N,256) bf16 = proj_q(dense) [mode 0] or proj_k(sparse) [mode 1]; inv_softplus_scale (256) fp32.
+ * mode 1: out (B,N,256) bf16 = the focused features relu/scale/cube/renorm only.
+ * mode 0: out = (q_h kv_h) / (q_h . ksum_h + 1e-6) per head with kvt (B,4,64 d,64 c) bf16 = kv_h^T and
+ *         ksum (B,256) fp32 = sum_j focused k_j. */
+int unopose_linear_attention(const void *x, const float *inv_softplus_scale, const void *kvt,
+                             const float *ksum, int B, int N, int focus, int mode, void *out,
+                             unopose_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

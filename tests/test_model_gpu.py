@@ -303,3 +303,21 @@ def test_vit_autocast_fused_path_matches_unfused(tamed):
         out = net.pixel_features(img, choose)
     e = (out.float() - ref).abs()
     assert e.mean().item() / ref.abs().mean().item() < 2e-2
+
+
+@torch.no_grad()
+def test_fused_linear_attention_kernel(model):
+    """Fused focused-linear-attention core (bf16 MFMA) vs the fp32 composite: 2048 dense x 196 sparse."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(8)
+    xq = torch.randn(2, 2048, 256, generator=g).cuda()
+    xkv = torch.randn(2, 196, 256, generator=g).cuda()
+    att = model.fine_point_matching.transformers[0].dense_layer.attention.attention
+    ref = ops.focused_linear_attention_torch(xq, xkv, att, 4, 3)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = ops.focused_linear_attention(xq, xkv, att, 4, 3)
+    assert out.dtype == torch.bfloat16
+    e = (out.float() - ref).abs()
+    scale = ref.abs().mean().item()
+    assert e.mean().item() / scale < 2e-2 and e.max().item() / scale < 0.5, (e.mean().item(), e.max().item(), scale)

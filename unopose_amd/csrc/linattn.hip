@@ -1,0 +1,143 @@
+// Focused linear attention core of the dense (2048-token) layers for gfx950 (C ABI part 2).
+//
+// Replaces the element-wise chain + two einsums of LinearAttention.forward
+// (core/unopose/model/transformer.py:533-568) on the dense side:
+//   q = relu(q) + 1e-6; q /= softplus(scale); q <- q^3 * |q| / |q^3|      ("focusing", per token)
+//   z = 1 / (q_h . sum_j k_j,h + 1e-6);  x_h = (q_h kv_h) * z            (per head, kv_h = k_h^T v_h, 64x64)
+// The reference makes ~12 passes over the (B,2048,256) tensor; here one wavefront owns 32 tokens, does
+// the focusing in registers in MFMA A-operand layout (so the result feeds v_mfma_f32_32x32x16_bf16
+// directly), contracts with the 64x64 kv of each head and scales by z in the epilogue.
+// mode 1 writes only the focused features (used for the 196 sparse keys, whose kv / k-sum are tiny
+// torch contractions).
+#include "common.h"
+
+namespace unopose {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+__device__ __forceinline__ u16 la_f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+__device__ __forceinline__ float la_bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// x: (B,N,256) bf16 projected q (or k); inv_sp: (256) 1/softplus(scale); kvt: (B,4,64 d,64 c) bf16;
+// ksum: (B,256) fp32; out (B,N,256) bf16.
+template <int MODE>
+__global__ __launch_bounds__(256) void linear_attn_kernel(const u16 *__restrict__ x, const float *__restrict__ inv_sp,
+                                                          const u16 *__restrict__ kvt, const float *__restrict__ ksum,
+                                                          int N, int focus, u16 *__restrict__ out) {
+  __shared__ float zl[4][32][4];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = (blockIdx.x * 4 + wave) * 32;
+  if (t0 >= N) return;
+  const int col = lane & 31, hb = lane >> 5;
+  const int tok = min(t0 + col, N - 1);
+  const u16 *xr = x + ((size_t)b * N + tok) * 256 + hb * 8;
+  float q[16][8];
+  float n1 = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    union { bf16x8 v; u16 u[8]; } f;
+    f.v = *reinterpret_cast<const bf16x8 *>(xr + ks * 16);
+    const float4 s0 = *reinterpret_cast<const float4 *>(inv_sp + ks * 16 + hb * 8);
+    const float4 s1 = *reinterpret_cast<const float4 *>(inv_sp + ks * 16 + hb * 8 + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = (fmaxf(la_bf2f(f.u[e]), 0.f) + 1e-6f) * sc[e];
+      q[ks][e] = v;
+      n1 += v * v;
+    }
+  }
+  n1 += __shfl_xor(n1, 32);
+  float n3 = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float p = q[ks][e];
+      if (focus == 3) p = p * p * p; else p = powf(p, (float)focus);
+      q[ks][e] = p;
+      n3 += p * p;
+    }
+  n3 += __shfl_xor(n3, 32);
+  const float fac = sqrtf(n1) / sqrtf(n3);
+  bf16x8 qa[16];
+  float zp[4] = {0.f, 0.f, 0.f, 0.f};
+  const float *ks_b = ksum + (size_t)b * 256 + hb * 8;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    union { bf16x8 v; u16 u[8]; } f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = q[ks][e] * fac;
+      f.u[e] = la_f2bf(v);
+      if (MODE == 0) zp[ks >> 2] += v * ks_b[ks * 16 + e];
+    }
+    qa[ks] = f.v;
+  }
+  if (MODE == 1) {  // focused features only
+    if (t0 + col < N) {
+      u16 *o = out + ((size_t)b * N + tok) * 256 + hb * 8;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) *reinterpret_cast<bf16x8 *>(o + ks * 16) = qa[ks];
+    }
+    return;
+  }
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    zp[h] += __shfl_xor(zp[h], 32);
+    if (hb == 0) zl[wave][col][h] = 1.f / (zp[h] + 1e-6f);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // x_h = q_h kv_h : A = q (rows = tokens), B = kv (B[k=c][n=d] read from kvt[d][c])
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const u16 *kp = kvt + (((size_t)b * 4 + h) * 64 + nt * 32 + col) * 64 + hb * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(kp + ks * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[h * 4 + ks], bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hb;
+        if (t0 + row < N)
+          out[((size_t)b * N + t0 + row) * 256 + h * 64 + nt * 32 + col] = la_f2bf(acc[r] * zl[wave][row][h]);
+      }
+    }
+  }
+}
+
+}  // namespace unopose
+
+using namespace unopose;
+
+extern "C" {
+
+int unopose_linear_attention(const void *x, const float *inv_softplus_scale, const void *kvt, const float *ksum, int B,
+                             int N, int focus, int mode, void *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(x && inv_softplus_scale && out && (mode == 1 || (kvt && ksum)), "linear_attention: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && N >= 1 && B <= 65535 && focus >= 1, "linear_attention: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  dim3 grid(cdiv(N, 128), B);
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 1)
+    hipLaunchKernelGGL(linear_attn_kernel<1>, grid, dim3(256), 0, s, (const u16 *)x, inv_softplus_scale,
+                       (const u16 *)nullptr, (const float *)nullptr, N, focus, (u16 *)out);
+  else
+    hipLaunchKernelGGL(linear_attn_kernel<0>, grid, dim3(256), 0, s, (const u16 *)x, inv_softplus_scale,
+                       (const u16 *)kvt, ksum, N, focus, (u16 *)out);
+  return check_launch("linear_attention");
+}
+
+}  // extern "C"

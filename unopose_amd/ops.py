@@ -300,7 +300,49 @@ def token_attention_torch(x, mem, att, heads, embed=None):
 
 
 def focused_linear_attention(xq, xkv, att, heads, focusing):
-    """LinearAttention.forward (transformer.py:533-568), kv branch (the shape test at :560 is static)."""
+    """LinearAttention.forward (transformer.py:533-568).  Under autocast(bf16) with 4 heads x 64 the
+    focusing + per-head contraction + z scaling run in ONE HIP kernel per side (csrc/linattn.hip);
+    otherwise the op-by-op composite."""
+    if torch.is_autocast_enabled() and heads == 4 and xq.shape[-1] == 256 and xq.is_cuda \
+            and float(focusing) == int(focusing):
+        return _focused_linear_attention_hip(xq, xkv, att, int(focusing))
+    return focused_linear_attention_torch(xq, xkv, att, heads, focusing)
+
+
+def _focused_linear_attention_hip(xq, xkv, att, focusing):
+    bf = torch.bfloat16
+    B, N, C = xq.shape
+    j = xkv.shape[1]
+    key = (att.proj_k.weight._version, att.proj_v.weight._version, att.scale._version, att.proj_k.weight.data_ptr())
+    cache = getattr(att, "_hip_cache", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            w_kv = torch.cat([att.proj_k.weight.float(), att.proj_v.weight.float()], 0).to(bf).contiguous()
+            b_kv = torch.cat([att.proj_k.bias.float(), att.proj_v.bias.float()], 0).to(bf).contiguous()
+            inv_sp = (1.0 / F.softplus(att.scale.float())).reshape(-1).contiguous()
+        cache = (key, w_kv, b_kv, inv_sp)
+        att._hip_cache = cache
+    _, w_kv, b_kv, inv_sp = cache
+    q = _c(att.proj_q(xq).to(bf))
+    with torch.autocast("cuda", enabled=False):
+        ykv = F.linear(xkv.to(bf), w_kv, b_kv)
+    kproj, v = _c(ykv[..., :C]), ykv[..., C:]
+    kf = torch.empty(B, j, C, dtype=bf, device=xq.device)
+    out = torch.empty(B, N, C, dtype=bf, device=xq.device)
+    with torch.cuda.device(xq.device):
+        call("unopose_linear_attention", ptr(kproj), ptr(inv_sp), None, None, B, j, focusing, 1, ptr(kf),
+             stream_ptr())
+        kf32 = kf.float()
+        ksum = _c(kf32.sum(dim=1))  # (B,256)
+        # kv_h^T[d][c] = sum_j v[j,h,d] k[j,h,c]
+        kvt = _c(torch.einsum("bjhd,bjhc->bhdc", v.float().reshape(B, j, 4, 64), kf32.reshape(B, j, 4, 64)).to(bf))
+        call("unopose_linear_attention", ptr(q), ptr(inv_sp), ptr(kvt), ptr(ksum), B, N, focusing, 0, ptr(out),
+             stream_ptr())
+    return out
+
+
+def focused_linear_attention_torch(xq, xkv, att, heads, focusing):
+    """Op-by-op composite, kv branch (the shape test at transformer.py:560 is static)."""
     q, k, v = att.proj_q(xq), att.proj_k(xkv), att.proj_v(xkv)
     dt = v.dtype
     q, k = q.float(), k.float()
