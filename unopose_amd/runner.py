@@ -1,0 +1,132 @@
+"""Sharded inference runner: the caller side of UNOPose.forward.
+
+Reproduces the I/O contract of the reference's test loop
+(core/unopose/engine/oneref_inference_utils_v1.py:13-136): per image, instances are chunked by
+``instance_batch_size`` (:42-48), the predicted pose is composed with the reference view's pose
+(:83-91), scores are multiplied by the detection score (:99), translations go to millimetres (:98) and
+one CSV row per instance is emitted (:114-123).  Unlike the reference -- where every rank writes the same
+file (:130-135) -- images are sharded over ranks exactly as detectron2's ``InferenceSampler`` does
+(core/unopose/utils/my_distributed_sampler.py:263-271) and the rows are GATHERED to rank 0 over
+``torch.distributed`` (RCCL on GPUs, gloo in the CPU tests).  There is no other data-path collective:
+pairs are independent.
+"""
+import json
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_size, world_size, rank):
+    """InferenceSampler._get_local_indices: contiguous blocks whose sizes differ by at most one."""
+    shard = total_size // world_size
+    left = total_size % world_size
+    sizes = [shard + int(r < left) for r in range(world_size)]
+    begin = sum(sizes[:rank])
+    end = min(sum(sizes[:rank + 1]), total_size)
+    return range(begin, end)
+
+
+def compose_pose(pred_R, pred_t, tem1_pose=None):
+    """T_query<-obj = [pred_R | pred_t] @ T_ref<-obj  (oneref_inference_utils_v1.py:83-91)."""
+    if tem1_pose is None:
+        return pred_R, pred_t
+    T = torch.zeros_like(tem1_pose)
+    T[:, 3, 3] = 1.0
+    T[:, :3, :3] = pred_R
+    T[:, :3, 3] = pred_t
+    T = T @ tem1_pose
+    return T[:, :3, :3], T[:, :3, 3]
+
+
+def csv_line(scene_id, img_id, obj_id, score, R9, t3_mm, image_time):
+    """scene_id,im_id,obj_id,score,R (9, space separated),t (3, mm),time  (:114-123)."""
+    return ",".join((str(scene_id), str(img_id), str(obj_id), str(score), " ".join(str(v) for v in R9),
+                     " ".join(str(v) for v in t3_mm), f"{image_time}\n"))
+
+
+_INPUT_KEYS = ("pts", "rgb", "rgb_choose", "fps_idx_m", "tem1_rgb", "tem1_choose", "tem1_pts", "fps_idx_o")
+
+
+@torch.no_grad()
+def run_image(model, data, instance_batch_size=16, device=None):
+    """One image = data[key] with a leading image dim of 1 and n_instance instances (:36-100)."""
+    if device is not None:
+        data = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in data.items()}
+    n = data["pts"].size(1)
+    Rs, ts, scores = [], [], []
+    for s in range(0, n, instance_batch_size):
+        e = min(n, s + instance_batch_size)
+        inputs = {k: data[k][0][s:e].contiguous() for k in _INPUT_KEYS if k in data}
+        out = model(inputs)
+        R, t = compose_pose(out["pred_R"], out["pred_t"],
+                            data["tem1_pose"][0][s:e].contiguous() if "tem1_pose" in data else None)
+        Rs.append(R)
+        ts.append(t)
+        scores.append(out["pred_pose_score"])
+    Rs = torch.cat(Rs, 0).reshape(-1, 9).float().cpu().numpy()
+    ts = torch.cat(ts, 0).float().cpu().numpy() * 1000
+    scores = (torch.cat(scores, 0) * data["score"][0, :, 0]).float().cpu().numpy()
+    return Rs, ts, scores
+
+
+def inference_and_save(model, images, save_path, instance_batch_size=16, device=None, sync=None):
+    """`images`: an indexable of per-image dicts (the reference's test dataset items, batch dim 1).
+    Every rank processes its InferenceSampler shard; rows are gathered to rank 0, which writes the CSV
+    (and the detections JSON) in global image order.  Returns the rows on rank 0, None elsewhere."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    rows, dets = [], {}
+    for idx in shard_range(len(images), world, rank):
+        data = images[idx]
+        if sync is not None:
+            sync()
+        t0 = time.perf_counter()
+        Rs, ts, scores = run_image(model, data, instance_batch_size, device)
+        if sync is not None:
+            sync()
+        image_time = time.perf_counter() - t0 + float(data["seg_time"]) if "seg_time" in data else \
+            time.perf_counter() - t0
+        scene_id, img_id = int(data["scene_id"]), int(data["img_id"])
+        inst_ids = np.asarray(data["inst_ids"][0]) if "inst_ids" in data else np.arange(len(scores))
+        for k in range(len(scores)):
+            rows.append((idx, k, csv_line(scene_id, img_id, int(data["obj_id"][0][k]), scores[k], Rs[k], ts[k],
+                                          image_time)))
+            dets.setdefault(f"{scene_id:06d}_{img_id:06d}", {})[int(inst_ids[k])] = {
+                "pred_R": Rs[k].tolist(), "pred_t": ts[k].tolist()}
+    if world > 1:
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object((rows, dets), gathered, dst=0)
+        if rank != 0:
+            return None
+        rows = [r for part in gathered for r in part[0]]
+        merged = {}
+        for part in gathered:
+            for key, v in part[1].items():
+                merged.setdefault(key, {}).update(v)
+        dets = merged
+    rows.sort(key=lambda r: (r[0], r[1]))
+    lines = [r[2] for r in rows]
+    with open(save_path, "w+") as f:
+        f.writelines(lines)
+    with open(save_path.replace(".csv", ".json"), "w") as f:
+        json.dump(dets, f)
+    return lines
+
+
+def broadcast_module_(module, src=0):
+    """One flat broadcast of all parameters and buffers from `src` (weights travel once over xGMI)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return module
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    if not tensors:
+        return module
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    dist.broadcast(flat, src)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
+        off += n
+    return module
