@@ -52,9 +52,11 @@ def hip_event_time(fn, iters, stream):
 
 
 def roofline_leg(model, batch):
-    """Roofline of the dominant hand-written kernel of the step, timed live with HIP events on the
-    inputs of this very workload.  See DESIGN.md 'Measurement' for the algorithmic-bytes model."""
+    """Roofline of the dominant hand-written kernel of the step (the S=256 launch of the fused
+    positional-encoding kernel), timed live with HIP events on the stream it runs on, plus the other rows
+    BASELINE's north star prices.  Work models: DESIGN.md section 4."""
     from unopose_amd import ops
+    from unopose_amd.pointnet2 import _ext
 
     B = batch["pts"].shape[0]
     pts = batch["pts"].float()
@@ -62,25 +64,43 @@ def roofline_leg(model, batch):
     x = (pts / (radius.reshape(-1, 1, 1) + 1e-6)).contiguous()
     N = x.shape[1]
     stream = torch.cuda.current_stream()
-    out = {}
-    legs = []
-    for r, ns in ((0.1, 64), (0.2, 256)):
-        t = hip_event_time(lambda: ops.query_lrf_group(x, r, ns), 10, stream)
-        byts = 4 * B * (3 * N + 6 * N * ns)  # read the cloud once, write (B,6,N,ns)
-        legs.append(dict(kernel=f"query_lrf_group_kernel(ns={ns})", seconds=t, bytes=byts, GBps=byts / t / 1e9))
-    # group_points (the reference's `_ext` gather): HBM-write-bound, the kernel the north star prices
-    from unopose_amd.pointnet2 import _ext
+    pe = model.fine_point_matching.PE
+    rows = []
 
+    def row(kernel, bound, work, unit_scale, peak, unit, seconds, note=None):
+        ach = work / seconds / unit_scale
+        r = dict(kernel=kernel, bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak,
+                 us=seconds * 1e6)
+        if note:
+            r["note"] = note
+        rows.append(r)
+        return r
+
+    # dominant: PE, S=256, bf16 hi/lo-split matrix cores; 20864 flop per neighbour row
+    t = hip_event_time(lambda: ops.pe_group_mlp_max(x, pe.r2, pe.ns2, pe.mlp2, bf16x3=True), 10, stream)
+    dom = row("pe_group_mlp_max_bf16x3_kernel(S=%d)" % pe.ns2, "mfma", B * N * pe.ns2 * 20864.0, 1e12, 2500.0,
+              "TFLOP/s", t, "algorithmic fp32-equivalent flops; the kernel issues 3 bf16 MFMAs per product")
+    t = hip_event_time(lambda: ops.pe_group_mlp_max(x, pe.r2, pe.ns2, pe.mlp2, bf16x3=False), 5, stream)
+    row("pe_group_mlp_max_kernel(S=%d, exact fp32 MFMA)" % pe.ns2, "mfma", B * N * pe.ns2 * 20864.0, 1e12, 157.3,
+        "TFLOP/s", t)
+    # geometric embedding: 8 n^2 256^2 flop per cloud
+    n = model.coarse_npoint + 1
+    gp = torch.cat([torch.ones(B, 1, 3, device=x.device), x[:, :n - 1]], 1).contiguous()
+    t = hip_event_time(lambda: ops.geo_embedding(gp, model.geo_embedding, out_dtype=torch.bfloat16), 10, stream)
+    row("geo_embed_kernel<bf16>", "mfma", B * 8.0 * n * n * 256 * 256, 1e12, 2500.0, "TFLOP/s", t)
+    # group_points (the reference's `_ext` gather): HBM-write-bound
     idx = _ext.ball_query(x, x, 0.2, 256)
     xt = x.transpose(1, 2).contiguous()
     t = hip_event_time(lambda: _ext.group_points(xt, idx), 20, stream)
-    byts = 4 * B * (N * 256 + 3 * N * 256 + 3 * N)
-    legs.append(dict(kernel="group_points_lds_kernel(ns=256)", seconds=t, bytes=byts, GBps=byts / t / 1e9))
-    dom = max(legs[:2], key=lambda l: l["seconds"])
-    out["roofline"] = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["GBps"], peak=8000.0, unit="GB/s",
-                           frac=dom["GBps"] / 8000.0, traffic=None)
-    out["roofline_other"] = [dict(kernel=l["kernel"], bound="hbm", achieved=l["GBps"], peak=8000.0, unit="GB/s",
-                                  frac=l["GBps"] / 8000.0, us=l["seconds"] * 1e6) for l in legs]
+    row("group_points_lds_kernel(S=256)", "hbm", 4.0 * B * (N * 256 + 3 * N * 256 + 3 * N), 1e9, 8000.0, "GB/s", t)
+    t = hip_event_time(lambda: _ext.ball_query(x, x, 0.2, 256), 20, stream)
+    row("ball_query_kernel(S=256)", "hbm", 4.0 * B * (3 * N + 3 * N + N * 256), 1e9, 8000.0, "GB/s", t)
+    tem = batch["tem1_pts"].float().contiguous()
+    t = hip_event_time(lambda: _ext.furthest_point_sampling(tem, 2048), 3, stream)
+    rows.append(dict(kernel="fps_kernel(5000->2048)", bound="latency", us=t * 1e6, us_per_iteration=t * 1e6 / 2047))
+    out = dict(roofline=dict(bound=dom["bound"], kernel=dom["kernel"], achieved=dom["achieved"], peak=dom["peak"],
+                             unit=dom["unit"], frac=dom["frac"], traffic=None, note=dom["note"]),
+               roofline_other=rows[1:])
     return out
 
 
