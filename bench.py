@@ -99,9 +99,21 @@ def roofline_leg(model, batch):
     t = hip_event_time(lambda: _ext.furthest_point_sampling(tem, 2048), 3, stream)
     rows.append(dict(kernel="fps_kernel(5000->2048)", bound="latency", us=t * 1e6, us_per_iteration=t * 1e6 / 2047))
     out = dict(roofline=dict(bound=dom["bound"], kernel=dom["kernel"], achieved=dom["achieved"], peak=dom["peak"],
-                             unit=dom["unit"], frac=dom["frac"], traffic=None, note=dom["note"]),
+                             unit=dom["unit"], frac=dom["frac"], traffic=_pmc_traffic("pe_group_mlp_max_bf16x3_kernel", B),
+                             note=dom["note"]),
                roofline_other=rows[1:])
     return out
+
+
+def _pmc_traffic(kernel, B):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_summary.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 runs at B=32, FETCH_SIZE doubled per the gfx950 note);
+    null when the batch differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if B != 32 or not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"].get(kernel)
+    return None if k is None else dict(hbm_bytes_per_launch=k["hbm_bytes_per_launch"], source="profiles/r01_pmc_summary.json")
 
 
 def cpu_baseline_leg(img):

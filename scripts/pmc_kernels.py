@@ -1,0 +1,36 @@
+"""Launch the hand-written kernels that bench.py prices, a few times each, at the bench workload's
+shapes -- the target of the rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE collected in separate runs)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unopose_amd import ops  # noqa: E402
+from unopose_amd.model import UNOPose, default_model_cfg  # noqa: E402
+from unopose_amd.pointnet2 import _ext  # noqa: E402
+from unopose_amd.synthetic import make_batch, trained_like_  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+torch.set_grad_enabled(False)
+dev = torch.device("cuda")
+model = trained_like_(UNOPose(default_model_cfg())).to(dev).eval()
+batch, _, _ = make_batch(B, device=dev)
+pts = batch["pts"].float()
+radius = torch.norm(batch["tem1_pts"] - batch["tem1_pts"].mean(1, keepdim=True), dim=2).max(1)[0]
+x = (pts / (radius.reshape(-1, 1, 1) + 1e-6)).contiguous()
+pe = model.fine_point_matching.PE
+idx = _ext.ball_query(x, x, 0.2, 256)
+xt = x.transpose(1, 2).contiguous()
+n = 197
+gp = torch.cat([torch.ones(B, 1, 3, device=dev), x[:, :n - 1]], 1).contiguous()
+for _ in range(3):
+    ops.pe_group_mlp_max(x, pe.r2, pe.ns2, pe.mlp2, bf16x3=True)
+    _ext.group_points(xt, idx)
+    _ext.ball_query(x, x, 0.2, 256)
+    E = ops.geo_embedding(gp, model.geo_embedding, out_dtype=torch.bfloat16)
+    f = torch.randn(B, n, 256, device=dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ops.token_attention(f, f, model.coarse_point_matching.transformers[0].layers[0].attention.attention, 4, E)
+torch.cuda.synchronize()
+print("done")
