@@ -246,6 +246,8 @@ class TransformerLayer(nn.Module):
         a = self.attention
         h = ops.token_attention(x, mem, a.attention, self.heads, embed)
         if x.is_cuda and torch.is_autocast_enabled():
+            if ops.USE_FUSED_TAIL and x.shape[-1] == 256:
+                return ops.transformer_tail(h, x, self)
             x = ops.add_layernorm(a.linear(h), x, a.norm)
         else:
             x = a.norm(a.linear(h) + x)
@@ -297,6 +299,8 @@ class LinearTransformerLayer(nn.Module):
         a = self.attention
         h = ops.focused_linear_attention(x, mem, a.attention, self.heads, self.focusing_factor)
         if x.is_cuda and torch.is_autocast_enabled():
+            if ops.USE_FUSED_TAIL and x.shape[-1] == 256:
+                return ops.transformer_tail(h, x, self)
             x = ops.add_layernorm(a.linear(h), x, a.norm)
         else:
             x = a.norm(a.linear(h) + x)
