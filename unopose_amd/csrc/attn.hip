@@ -97,16 +97,28 @@ __global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__
         a[ks] = zero8();
         if (a_nl == nl) a[ks] = *reinterpret_cast<const bf16x8 *>(QP + ks * 32 + kg * 8);
       }
+      // software-pipelined over key tiles: the 8 fragment loads (8 KiB per wave) of tile t+1 are in
+      // flight while the 8 MFMAs of tile t issue -- E is the only HBM-sized stream of this kernel
+      const int nt_valid = (m + 15) >> 4;
+      bf16x8 cur[8], nxt[8];
+      {
+        const u16 *Er = En + (size_t)min(li, m - 1) * 256 + kg * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) cur[ks] = *reinterpret_cast<const bf16x8 *>(Er + ks * 32);
+      }
 #pragma unroll
       for (int t = 0; t < TA_NT; ++t) {
-        const int mm = t * 16 + li;
-        if (t * 16 >= m) continue;  // uniform: tile entirely beyond the keys
-        const u16 *Er = En + (size_t)min(mm, m - 1) * 256 + kg * 8;
+        if (t >= nt_valid) continue;  // uniform: tile entirely beyond the keys
+        if (t + 1 < nt_valid) {
+          const u16 *Er = En + (size_t)min((t + 1) * 16 + li, m - 1) * 256 + kg * 8;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(Er + ks * 32);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], bv, acc[t], 0, 0, 0);
+          for (int ks = 0; ks < 8; ++ks) nxt[ks] = *reinterpret_cast<const bf16x8 *>(Er + ks * 32);
         }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], cur[ks], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) cur[ks] = nxt[ks];
       }
     }
   }
