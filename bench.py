@@ -30,7 +30,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (same GPU time: "
+                    "the step is GPU-bound, not launch-bound, at every batch size measured)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -171,7 +172,7 @@ def main():
     amp = args.dtype == "bf16"
 
     graphed = None
-    if not args.no_graph:
+    if args.graph:
         from unopose_amd.graph import GraphedForward
 
         graphed = GraphedForward(model, batch, torch.bfloat16 if amp else None)
@@ -225,7 +226,7 @@ def main():
                                f"196 coarse pts, {args.img}x{args.img} crops, DINOv2 ViT-B/14 reg4, "
                                f"random-init (trained-like) weights",
                    "sharding": f"dp{world} (independent pairs, weights broadcast, poses gathered)"},
-        "launch": "eager" if args.no_graph else "hipGraph replay",
+        "launch": "hipGraph replay" if args.graph else "eager",
         "sanity": {"median_rot_err_vs_gt": rot_err.median().item(),
                    "frac_pairs_solved(<0.05)": (rot_err < 0.05).float().mean().item()},
     }

@@ -202,10 +202,8 @@ int unopose_token_attention_key_pad(void);
 
 /* ViT attention core (timm Attention as driven by core/unopose/model/oneref_feature_extraction.py:38-41):
  * out (B,T,H*64) = softmax(q k^T / 8) v per head, flash-style.  qkv (B,T,3,H,64) = the fused qkv Linear
- * output, vt (B,H,64,TP) = v transposed to channel-major and zero-padded to TP (multiple of 32) keys;
- * all bfloat16 bit patterns. */
-int unopose_vit_attention(const void *qkv, const void *vt, int B, int T, int TP, int H, void *out,
-                          unopose_stream_t stream);
+ * output; bfloat16 bit patterns. */
+int unopose_vit_attention(const void *qkv, int B, int T, int H, void *out, unopose_stream_t stream);
 
 /* out = LayerNorm(a (+ b)) * w + bias over the last dimension C (<= 1024), rows x C row-major.
  * a / b / out are float32 or bfloat16 (flags); b may be NULL.  One pass instead of the reference's

@@ -7,8 +7,9 @@
 //   * S^T = K Q^T on v_mfma_f32_32x32x16_bf16 ("swapped" product): in the C/D layout a lane then holds
 //     16 keys of ONE query, so the softmax reductions are in-register plus one cross-half exchange;
 //   * O^T += V^T P^T with P fed straight from those registers: accumulator registers 8s..8s+7 are one
-//     16-key MFMA k-step in a fixed permuted key order, and V^T (channel-major, built once per call) is
+//     16-key MFMA k-step in a fixed permuted key order, and V^T (transposed on its way into LDS) is
 //     read in the same order, so P never moves between lanes;
+//   * K / V of a 128-key chunk are staged once per workgroup in LDS and shared by its 4 waves;
 //   * O^T is transposed through 4 KiB of LDS so every token row is stored as 128 contiguous bytes.
 #include "common.h"
 
@@ -24,16 +25,23 @@ __device__ __forceinline__ u16 va_f2bf(float f) {
   return (u16)(u >> 16);
 }
 
-// qkv: (B, T, 3, H, 64) bf16 (the fused qkv Linear output); vt: (B, H, 64, TP) bf16, TP % 32 == 0,
-// zero beyond T; out: (B, T, H*64) bf16.
-__global__ __launch_bounds__(256) void vit_attn_kernel(const u16 *__restrict__ qkv, const u16 *__restrict__ vt,
-                                                       int T, int TP, int H, float scale_log2e,
+constexpr int VA_CHUNK = 128;            // keys staged per LDS chunk
+constexpr int VA_LDK = 64 + 8;           // padded row of the K chunk  [key][channel]
+constexpr int VA_LDV = VA_CHUNK + 8;     // padded row of the V^T chunk [channel][key]
+
+// qkv: (B, T, 3, H, 64) bf16 (the fused qkv Linear output); out: (B, T, H*64) bf16.
+// The 4 waves of a workgroup share one (image, head): K and V of a 128-key chunk are loaded once with
+// coalesced 16-byte reads, K kept row-major and V transposed on the way into LDS (so the caller needs no
+// V^T copy), then every wave runs its 32 queries against the chunk.
+__global__ __launch_bounds__(256) void vit_attn_kernel(const u16 *__restrict__ qkv, int T, int H, float scale_log2e,
                                                        u16 *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) u16 Ks[VA_CHUNK][VA_LDK];
+  __shared__ __attribute__((aligned(16))) u16 Vs[64][VA_LDV];
   __shared__ __attribute__((aligned(16))) u16 Ot[4][32][72];  // per wave: 32 tokens x 64 channels (+8 pad)
   const int b = blockIdx.z, h = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q0 = (blockIdx.x * 4 + wave) * 32;
-  if (q0 >= T) return;
+  const bool active = q0 < T;  // inactive waves still help staging and hit every barrier
   const int col = lane & 31, hb = lane >> 5;
   const int C3 = 3 * H * 64;
   const u16 *base = qkv + (size_t)b * T * C3;
@@ -51,63 +59,80 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const u16 *__restrict__ q
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -3e38f, l_run = 0.f;
-  const u16 *VT = vt + ((size_t)b * H + h) * 64 * TP;
 
-  for (int k0 = 0; k0 < T; k0 += 32) {
-    // ---- S^T tile: rows = 32 keys, cols = 32 queries
-    f32x16 s;
+  for (int c0 = 0; c0 < T; c0 += VA_CHUNK) {
+    __syncthreads();  // previous chunk fully consumed
+    // ---- stage the chunk: 128 keys x 128 B for K and for V (8 lanes per key row: coalesced)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    {
-      const int tk = min(k0 + col, T - 1);
-      const u16 *kp = base + (size_t)tk * C3 + (H + h) * 64 + hb * 8;
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256, key = e >> 3, c8 = e & 7;
+      const int tk = min(c0 + key, T - 1);
+      const u16 *src = base + (size_t)tk * C3 + h * 64 + c8 * 8;
+      const uint4 kv = *reinterpret_cast<const uint4 *>(src + H * 64);
+      union { uint4 v; u16 u[8]; } vv;
+      vv.v = *reinterpret_cast<const uint4 *>(src + 2 * H * 64);
+      *reinterpret_cast<uint4 *>(&Ks[key][c8 * 8]) = kv;
+      const bool valid = c0 + key < T;  // keys beyond T contribute V = 0 (their P is 0 as well)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Vs[c8 * 8 + j][key] = valid ? vv.u[j] : (u16)0;
+    }
+    __syncthreads();
+    if (!active) continue;
+    const int nk = min(VA_CHUNK, T - c0);
+    for (int kt = 0; kt < nk; kt += 32) {
+      const int k0 = c0 + kt;
+      // ---- S^T tile: rows = 32 keys, cols = 32 queries
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + ks * 16);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(&Ks[kt + col][ks * 16 + hb * 8]);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
       }
-    }
-    // ---- online softmax for this lane's query over its 16 keys (+ the other half-wave's 16)
-    float mx = -3e38f;
+      // ---- online softmax for this lane's query over its 16 keys (+ the other half-wave's 16)
+      float mx = -3e38f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hb;
-      s[r] = key < T ? s[r] * scale_log2e : -3e38f;
-      mx = fmaxf(mx, s[r]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    float ls = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+        s[r] = key < T ? s[r] * scale_log2e : -3e38f;
+        mx = fmaxf(mx, s[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      float ls = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[r] = exp2f(s[r] - m_new);
-      ls += s[r];
-    }
-    ls += __shfl_xor(ls, 32);
-    l_run = l_run * alpha + ls;
-    m_run = m_new;
+      for (int r = 0; r < 16; ++r) {
+        s[r] = exp2f(s[r] - m_new);
+        ls += s[r];
+      }
+      ls += __shfl_xor(ls, 32);
+      l_run = l_run * alpha + ls;
+      m_run = m_new;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-    // ---- O^T += V^T P^T ; k-step s2 = accumulator registers 8*s2 .. 8*s2+7 (permuted key order)
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      // ---- O^T += V^T P^T ; k-step s2 = accumulator registers 8*s2 .. 8*s2+7 (permuted key order)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      union { bf16x8 v; u16 u[8]; } pf;
+      for (int s2 = 0; s2 < 2; ++s2) {
+        union { bf16x8 v; u16 u[8]; } pf;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pf.u[e] = va_f2bf(s[s2 * 8 + e]);
+        for (int e = 0; e < 8; ++e) pf.u[e] = va_f2bf(s[s2 * 8 + e]);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        // A = V^T: row = channel t*32 + col, keys k0 + 16 s2 + 4 hb + {0..3} and + 8 + {0..3}
-        const u16 *vp = VT + (size_t)(t * 32 + col) * TP + k0 + s2 * 16 + 4 * hb;
-        union { bf16x8 v; bf16x4 h4[2]; } vf;
-        vf.h4[0] = *reinterpret_cast<const bf16x4 *>(vp);
-        vf.h4[1] = *reinterpret_cast<const bf16x4 *>(vp + 8);
-        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) {
+          // A = V^T: row = channel t*32 + col, keys kt + 16 s2 + 4 hb + {0..3} and + 8 + {0..3}
+          const u16 *vp = &Vs[t * 32 + col][kt + s2 * 16 + 4 * hb];
+          union { bf16x8 v; bf16x4 h4[2]; } vf;
+          vf.h4[0] = *reinterpret_cast<const bf16x4 *>(vp);
+          vf.h4[1] = *reinterpret_cast<const bf16x4 *>(vp + 8);
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[t], 0, 0, 0);
+        }
       }
     }
   }
+  if (!active) return;
   // ---- normalise, transpose through LDS, store token rows
   const float inv = 1.f / l_run;
 #pragma unroll
@@ -138,16 +163,14 @@ using namespace unopose;
 
 extern "C" {
 
-int unopose_vit_attention(const void *qkv, const void *vt, int B, int T, int TP, int H, void *out,
-                          unopose_stream_t stream) {
-  UNOPOSE_REQUIRE(qkv && vt && out, "vit_attention: null pointer");
-  UNOPOSE_REQUIRE(B >= 0 && T >= 1 && H >= 1 && TP >= T && TP % 32 == 0 && B <= 65535 && H <= 65535,
-                  "vit_attention: bad sizes (TP must be a multiple of 32 >= T)");
+int unopose_vit_attention(const void *qkv, int B, int T, int H, void *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(qkv && out, "vit_attention: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && T >= 1 && H >= 1 && B <= 65535 && H <= 65535, "vit_attention: bad sizes");
   if (B == 0) return UNOPOSE_OK;
   const float scale_log2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
   dim3 grid(cdiv(T, 128), H, B);
-  hipLaunchKernelGGL(vit_attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)qkv, (const u16 *)vt, T,
-                     TP, H, scale_log2e, (u16 *)out);
+  hipLaunchKernelGGL(vit_attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)qkv, T, H, scale_log2e,
+                     (u16 *)out);
   return check_launch("vit_attention");
 }
 

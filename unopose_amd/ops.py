@@ -80,12 +80,9 @@ def vit_attention(qkv, heads):
     if qkv.dtype == torch.bfloat16 and qkv.shape[-1] == 3 * heads * 64:
         B, T, C3 = qkv.shape
         qkv = _c(qkv)
-        TP = (T + 31) // 32 * 32
-        vt = torch.zeros(B, heads, 64, TP, dtype=torch.bfloat16, device=qkv.device)
-        vt[..., :T] = qkv.view(B, T, 3, heads, 64)[:, :, 2].permute(0, 2, 3, 1)
         out = torch.empty(B, T, C3 // 3, dtype=torch.bfloat16, device=qkv.device)
         with torch.cuda.device(qkv.device):
-            call("unopose_vit_attention", ptr(qkv), ptr(vt), B, T, TP, heads, ptr(out), stream_ptr())
+            call("unopose_vit_attention", ptr(qkv), B, T, heads, ptr(out), stream_ptr())
         return out
     return vit_attention_torch(qkv, heads)
 
