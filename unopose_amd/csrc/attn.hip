@@ -52,18 +52,20 @@ __device__ __forceinline__ bf16x8 zero8() {
 constexpr int TA_NT = 14;          // key tiles of 16 -> up to 224 keys
 constexpr int TA_MP = TA_NT * 16;  // padded key count (V^T and the P staging use this stride)
 
-template <bool RPE>
+// RW = query rows per wavefront (4 fills the 16-row MFMA tile; 2 doubles the number of wavefronts that
+// stream E concurrently -- the kernel is bound by HBM latency x occupancy, not by the matrix pipe)
+template <bool RPE, int RW>
 __global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__ q, const u16 *__restrict__ k,
                                                          const u16 *__restrict__ vt, const u16 *__restrict__ qp,
                                                          const u16 *__restrict__ E, int n, int m, float scale,
                                                          u16 *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) u16 Pl[4][16][TA_MP];
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = (blockIdx.x * 4 + wave) * 4;  // first of this wave's 4 query rows
+  const int n0 = (blockIdx.x * 4 + wave) * RW;  // first of this wave's RW query rows
   if (n0 >= n) return;
   const int li = lane & 15, kg = lane >> 4;     // A: row li, k-group kg | B: column li, k-group kg
   const int a_nl = li >> 2, a_h = li & 3;       // A-operand row = (query row a_nl, head a_h)
-  const bool a_valid = n0 + a_nl < n;
+  const bool a_valid = a_nl < RW && n0 + a_nl < n;
   const u16 *Q = q + ((size_t)b * n + n0 + a_nl) * 256;
   const u16 *K = k + (size_t)b * m * 256;
 
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__
   }
   // ---- RPE term: for each of the 4 query rows, (q W_p)[n] . E[n,m,:]
   if (RPE) {
-    for (int nl = 0; nl < 4; ++nl) {
+    for (int nl = 0; nl < RW; ++nl) {
       if (n0 + nl >= n) break;  // wave-uniform
       const u16 *QP = qp + (((size_t)b * n + n0 + nl) * 4 + a_h) * 256;
       const u16 *En = E + ((size_t)b * n + n0 + nl) * (size_t)m * 256;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__
       o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[ks], bv, o, 0, 0, 0);
     }
     // D row = (query row kg, head reg); channel tile nt belongs to head nt >> 2
-    if (n0 + kg < n) out[((size_t)b * n + n0 + kg) * 256 + nt * 16 + li] = f2bf_rn(o[nt >> 2]);
+    if (kg < RW && n0 + kg < n) out[((size_t)b * n + n0 + kg) * 256 + nt * 16 + li] = f2bf_rn(o[nt >> 2]);
   }
 }
 
@@ -192,14 +194,14 @@ int unopose_token_attention(const void *q, const void *k, const void *vt, const 
   UNOPOSE_REQUIRE(B >= 0 && n >= 1 && m >= 1 && m <= TA_MP && B <= 65535,
                   "token_attention: m=%d exceeds the %d-key tile", m, TA_MP);
   if (B == 0) return UNOPOSE_OK;
-  dim3 grid(cdiv(n, 16), B);
   hipStream_t s = (hipStream_t)stream;
   if (E)
-    hipLaunchKernelGGL(token_attn_kernel<true>, grid, dim3(256), 0, s, (const u16 *)q, (const u16 *)k,
-                       (const u16 *)vt, (const u16 *)qp, (const u16 *)E, n, m, scale, (u16 *)out);
+    hipLaunchKernelGGL((token_attn_kernel<true, 4>), dim3(cdiv(n, 16), B), dim3(256), 0, s, (const u16 *)q,
+                       (const u16 *)k, (const u16 *)vt, (const u16 *)qp, (const u16 *)E, n, m, scale, (u16 *)out);
   else
-    hipLaunchKernelGGL(token_attn_kernel<false>, grid, dim3(256), 0, s, (const u16 *)q, (const u16 *)k,
-                       (const u16 *)vt, (const u16 *)nullptr, (const u16 *)nullptr, n, m, scale, (u16 *)out);
+    hipLaunchKernelGGL((token_attn_kernel<false, 4>), dim3(cdiv(n, 16), B), dim3(256), 0, s, (const u16 *)q,
+                       (const u16 *)k, (const u16 *)vt, (const u16 *)nullptr, (const u16 *)nullptr, n, m, scale,
+                       (u16 *)out);
   return check_launch("token_attention");
 }
 
