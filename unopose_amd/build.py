@@ -18,6 +18,11 @@ ARCH = "gfx950"
 # FPS / ball_query indices are bit-identical to oracle/ (DESIGN.md "fp-contract").
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall",
          "-Wno-unused-function"]
+# Dense-math kernels: `nnan` lets fmaxf lower to ONE v_max_f32 instead of canonicalise + max (the PE tile
+# loop had 288 v_max for 112 logical maxima).  Not applied to the index-producing files (pointnet2, geom,
+# posehead), whose NaN behaviour follows the reference's fminf / fmaxf semantics.
+EXTRA_FLAGS = {f: ["-fno-honor-nans"] for f in
+               ("pe.hip", "embed.hip", "attn.hip", "vit_attn.hip", "tail.hip", "linattn.hip", "fused.hip")}
 
 
 def _hipcc():
@@ -46,8 +51,8 @@ def build(force=False, verbose=False):
         src = os.path.join(CSRC, f)
         obj = os.path.join(OBJ, f[:-4] + ".o")
         objs.append(obj)
-        if force or _newer(src, obj, hdrs):
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+        if force or _newer(src, obj, hdrs + [os.path.abspath(__file__)]):
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(f, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -26,6 +26,12 @@ __device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even
   return (u16)(u >> 16);
 }
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
+// gfx950 packed fp32 -> bf16 conversion (RNE): low half = cvt(a), high half = cvt(b)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 // sin and cos of |x| <~ 1e3 with ~1e-7 absolute error: 3-term Cody-Waite reduction by pi/2 + cephes
 // single-precision minimax polynomials on [-pi/4, pi/4].
@@ -141,14 +147,14 @@ __global__ __launch_bounds__(GE_THREADS) void geo_embed_kernel(
     }
     // channel 2t = sin(w_t), 2t+1 = cos(w_t)  (transformer.py:278-282)
     const int rbase = c;  // = set * GE_PAIRS + row
-    const u16 h0 = f2bf(s0), h1 = f2bf(c0), h2 = f2bf(s1), h3 = f2bf(c1);
-    *reinterpret_cast<uint32_t *>(Ahi + ge_swz(rbase, lane * 4)) = (uint32_t)h0 | ((uint32_t)h1 << 16);
-    *reinterpret_cast<uint32_t *>(Ahi + ge_swz(rbase, (lane + 64) * 4)) = (uint32_t)h2 | ((uint32_t)h3 << 16);
+    const uint32_t p0 = cvt_pk_bf16(s0, c0), p1 = cvt_pk_bf16(s1, c1);
+    *reinterpret_cast<uint32_t *>(Ahi + ge_swz(rbase, lane * 4)) = p0;
+    *reinterpret_cast<uint32_t *>(Ahi + ge_swz(rbase, (lane + 64) * 4)) = p1;
     if (SPLIT) {
-      const u16 l0 = f2bf(s0 - bf2f(h0)), l1 = f2bf(c0 - bf2f(h1)), l2 = f2bf(s1 - bf2f(h2)),
-                l3 = f2bf(c1 - bf2f(h3));
-      *reinterpret_cast<uint32_t *>(Alo + ge_swz(rbase, lane * 4)) = (uint32_t)l0 | ((uint32_t)l1 << 16);
-      *reinterpret_cast<uint32_t *>(Alo + ge_swz(rbase, (lane + 64) * 4)) = (uint32_t)l2 | ((uint32_t)l3 << 16);
+      const uint32_t q0 = cvt_pk_bf16(s0 - __uint_as_float(p0 << 16), c0 - __uint_as_float(p0 & 0xFFFF0000u));
+      const uint32_t q1 = cvt_pk_bf16(s1 - __uint_as_float(p1 << 16), c1 - __uint_as_float(p1 & 0xFFFF0000u));
+      *reinterpret_cast<uint32_t *>(Alo + ge_swz(rbase, lane * 4)) = q0;
+      *reinterpret_cast<uint32_t *>(Alo + ge_swz(rbase, (lane + 64) * 4)) = q1;
     }
   }
   __syncthreads();

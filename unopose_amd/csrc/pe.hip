@@ -239,14 +239,23 @@ struct PeLdsB {
   float b1[32], b2[64], b3[128];
 };
 
-// split 8 fp32 accumulator values into packed bf16 hi / lo fragments (optionally bias + ReLU first)
+// gfx950 packed fp32 -> bf16 conversion (RNE): low half = cvt(a), high half = cvt(b)
+__device__ __forceinline__ uint32_t pe_cvt_pk(float a, float b) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// split 8 fp32 values into packed bf16 hi / lo fragments: v ~ hi + lo
 __device__ __forceinline__ void pe_split8(const float *v, bf16x8 &hi, bf16x8 &lo) {
-  union { bf16x8 v; u16 s[8]; } H, Lo;
+  union { bf16x8 v; uint32_t w[4]; } H, Lo;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const u16 h = pe_f2bf(v[e]);
-    H.s[e] = h;
-    Lo.s[e] = pe_f2bf(v[e] - pe_bf2f(h));
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t h = pe_cvt_pk(v[2 * e], v[2 * e + 1]);
+    H.w[e] = h;
+    const float r0 = v[2 * e] - __uint_as_float(h << 16);
+    const float r1 = v[2 * e + 1] - __uint_as_float(h & 0xFFFF0000u);
+    Lo.w[e] = pe_cvt_pk(r0, r1);
   }
   hi = H.v;
   lo = Lo.v;
@@ -334,9 +343,10 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
       bf16x8 xh, xl;
       pe_split8(f, xh, xl);
       // layer 1 (one k-step)
+      // (biases are folded into the accumulator initialisation: one move instead of move + add)
       f32x16 h1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) h1[r] = 0.f;
+      for (int r = 0; r < 16; ++r) h1[r] = L->b1[cd_row(r, half)];
       {
         const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&L->w1h[col][half * 8]);
         const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&L->w1l[col][half * 8]);
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
       for (int s2 = 0; s2 < 2; ++s2) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(h1[s2 * 8 + e] + L->b1[cd_row(s2 * 8 + e, half)], 0.f);
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(h1[s2 * 8 + e], 0.f);
         pe_split8(v, a1h[s2], a1l[s2]);
       }
       // layer 2: 32 -> 64
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
       for (int ot = 0; ot < 2; ++ot) {
         f32x16 h2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h2[r] = 0.f;
+        for (int r = 0; r < 16; ++r) h2[r] = L->b2[ot * 32 + cd_row(r, half)];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&L->w2h[ot * 32 + col][ks * 16 + half * 8]);
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e)
-            v[e] = fmaxf(h2[s2 * 8 + e] + L->b2[ot * 32 + cd_row(s2 * 8 + e, half)], 0.f);
+            v[e] = fmaxf(h2[s2 * 8 + e], 0.f);
           pe_split8(v, a2h[ot * 2 + s2], a2l[ot * 2 + s2]);
         }
       }
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
       for (int ot = 0; ot < 4; ++ot) {
         f32x16 h3;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h3[r] = 0.f;
+        for (int r = 0; r < 16; ++r) h3[r] = L->b3[ot * 32 + cd_row(r, half)];
         const int row = ot * 32 + col;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -386,9 +396,9 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
           const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&L->w3l[row][kp]);
           PE_MFMA3(h3, ah, al, a2h[ks], a2l[ks]);
         }
+        // running max starts at 0, so max(rmax, h3) already includes the ReLU
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          rmax[ot][r] = fmaxf(rmax[ot][r], fmaxf(h3[r] + L->b3[ot * 32 + cd_row(r, half)], 0.f));
+        for (int r = 0; r < 16; ++r) rmax[ot][r] = fmaxf(rmax[ot][r], h3[r]);
       }
     }
 #pragma unroll
