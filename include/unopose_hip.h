@@ -125,6 +125,16 @@ int unopose_weighted_procrustes(const float *src, const float *ref,
                                 float eps, float *R, float *t,
                                 unopose_stream_t stream);
 
+/* Same operator on the bf16 matrix cores with hi/lo-split operands (3 MFMAs per product, ~2^-16
+ * relative error).  The folded weights are packed ONCE into an LDS image of unopose_pe_image_bytes()
+ * bytes (bf16 hi/lo, k permuted to the MFMA C/D register map, bank-swizzled) that every workgroup
+ * copies verbatim. */
+int unopose_pe_image_bytes(void);
+int unopose_pe_pack_weights(const float *w1, const float *b1, const float *w2, const float *b2,
+                            const float *w3, const float *b3, void *image, unopose_stream_t stream);
+int unopose_pe_group_mlp_max_packed(const float *xyz, int B, int N, float radius, int nsample,
+                                    const void *image, float *out, unopose_stream_t stream);
+
 /* GeometricStructureEmbedding.forward (core/unopose/model/transformer.py:303-350):
  * points (B,n,3) -> out (B,n,n,256), float32 or bfloat16 (out_bf16).  hidden_dim = 256,
  * angle_k = 3.  Weights are passed as bfloat16 bit patterns in MFMA-fragment order
@@ -144,8 +154,8 @@ int unopose_geo_embedding(const float *points, int B, int n, const void *wd_hi,
  * (core/unopose/model/oneref_predator_fine_point_matching.py:167-174).  xyz (B,N,3) ->
  * out (B,N,128) float32.  w1 (32,6), w2 (64,32), w3 (128,64) row-major [out][in] with
  * BatchNorm already folded in, b1/b2/b3 the folded biases.  nsample % 32 == 0.
- * bf16x3 = 0: exact fp32 matrix cores (v_mfma_f32_32x32x2_f32); bf16x3 != 0: bf16 matrix
- * cores with hi/lo-split operands (3 MFMAs per product, ~2^-16 relative error). */
+ * Exact fp32 matrix cores (v_mfma_f32_32x32x2_f32); bf16x3 must be 0 (the split-precision form is
+ * unopose_pe_group_mlp_max_packed below). */
 int unopose_pe_group_mlp_max(const float *xyz, int B, int N, float radius, int nsample,
                              const float *w1, const float *b1, const float *w2,
                              const float *b2, const float *w3, const float *b3,

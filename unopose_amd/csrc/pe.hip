@@ -266,27 +266,12 @@ __device__ __forceinline__ void pe_split8(const float *v, bf16x8 &hi, bf16x8 &lo
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);      \
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0)
 
-__global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
-    const float *__restrict__ xyz, int N, float radius, int S, int cpw, const float *__restrict__ w1,
-    const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
-    const float *__restrict__ w3, const float *__restrict__ b3, float *__restrict__ out) {
-  extern __shared__ float4 smem4[];
-  PeLdsB *L = reinterpret_cast<PeLdsB *>(smem4);
-  float *sx = reinterpret_cast<float *>(L + 1);
-  float *sy = sx + N, *sz = sy + N;
-  int *nbr_all = reinterpret_cast<int *>(sz + N);
-  float *stage_all = reinterpret_cast<float *>(nbr_all + 4 * S);
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, col = lane & 31;
-  int *nbr = nbr_all + wave * S;
-  float *stage = stage_all + wave * 128;
-  const float *P = xyz + (size_t)b * N * 3;
-
-  for (int e = tid; e < N * 3; e += 256) {
-    const float v = P[e];
-    const int p = e / 3, comp = e - p * 3;
-    (comp == 0 ? sx : comp == 1 ? sy : sz)[p] = v;
-  }
+// One-time packing of the folded fp32 weights into the LDS image of the bf16x3 kernel.
+__global__ __launch_bounds__(256) void pe_pack_weights_kernel(const float *__restrict__ w1, const float *__restrict__ b1,
+                                                              const float *__restrict__ w2, const float *__restrict__ b2,
+                                                              const float *__restrict__ w3, const float *__restrict__ b3,
+                                                              PeLdsB *__restrict__ L) {
+  const int tid = threadIdx.x;
   for (int e = tid; e < 32 * 16; e += 256) {
     const int o = e >> 4, kk = e & 15;
     const float v = kk < 6 ? w1[o * 6 + kk] : 0.f;
@@ -312,6 +297,31 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
   if (tid < 32) L->b1[tid] = b1[tid];
   if (tid < 64) L->b2[tid] = b2[tid];
   if (tid < 128) L->b3[tid] = b3[tid];
+}
+
+__global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
+    const float *__restrict__ xyz, int N, float radius, int S, int cpw, const uint4 *__restrict__ image,
+    float *__restrict__ out) {
+  extern __shared__ float4 smem4[];
+  PeLdsB *L = reinterpret_cast<PeLdsB *>(smem4);
+  float *sx = reinterpret_cast<float *>(L + 1);
+  float *sy = sx + N, *sz = sy + N;
+  int *nbr_all = reinterpret_cast<int *>(sz + N);
+  float *stage_all = reinterpret_cast<float *>(nbr_all + 4 * S);
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  int *nbr = nbr_all + wave * S;
+  float *stage = stage_all + wave * 128;
+  const float *P = xyz + (size_t)b * N * 3;
+
+  for (int e = tid; e < N * 3; e += 256) {
+    const float v = P[e];
+    const int p = e / 3, comp = e - p * 3;
+    (comp == 0 ? sx : comp == 1 ? sy : sz)[p] = v;
+  }
+  // the LDS weight image (hi/lo bf16, permuted, swizzled; built once by pe_pack_weights_kernel) is copied
+  // verbatim with coalesced 16-byte loads
+  for (int e = tid; e < (int)(sizeof(PeLdsB) / 16); e += 256) smem4[e] = *reinterpret_cast<const float4 *>(image + e);
   __syncthreads();
   const float r2 = radius * radius;
 
@@ -430,6 +440,38 @@ using namespace unopose;
 
 extern "C" {
 
+int unopose_pe_image_bytes(void) { return (int)sizeof(PeLdsB); }
+
+int unopose_pe_pack_weights(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                            const float *b3, void *image, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && image, "pe_pack_weights: null pointer");
+  hipLaunchKernelGGL(pe_pack_weights_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3,
+                     (PeLdsB *)image);
+  return check_launch("pe_pack_weights");
+}
+
+int unopose_pe_group_mlp_max_packed(const float *xyz, int B, int N, float radius, int nsample, const void *image,
+                                    float *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(xyz && image && out, "pe_group_mlp_max_packed: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && N >= 1 && nsample >= 32 && nsample % 32 == 0 && B <= 65535,
+                  "pe_group_mlp_max_packed: nsample must be a positive multiple of 32 (got %d)", nsample);
+  if (B == 0) return UNOPOSE_OK;
+  const size_t lds = sizeof(PeLdsB) + ((size_t)3 * N + 4 * (size_t)nsample + 4 * 128) * 4;
+  UNOPOSE_REQUIRE(lds <= 160 * 1024, "pe_group_mlp_max_packed: N=%d nsample=%d exceed the LDS tile", N, nsample);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)pe_group_mlp_max_bf16x3_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const long centres = (long)B * N;
+  const int cpw = centres >= 65536 ? 16 : centres >= 32768 ? 8 : centres >= 8192 ? 4 : centres >= 2048 ? 2 : 1;
+  dim3 grid(cdiv(N, 4 * cpw), B);
+  hipLaunchKernelGGL(pe_group_mlp_max_bf16x3_kernel, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius, nsample,
+                     cpw, (const uint4 *)image, out);
+  return check_launch("pe_group_mlp_max_packed");
+}
+
 int unopose_pe_group_mlp_max(const float *xyz, int B, int N, float radius, int nsample, const float *w1,
                              const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
                              int bf16x3, float *out, unopose_stream_t stream) {
@@ -437,25 +479,21 @@ int unopose_pe_group_mlp_max(const float *xyz, int B, int N, float radius, int n
   UNOPOSE_REQUIRE(B >= 0 && N >= 1 && nsample >= 32 && nsample % 32 == 0 && B <= 65535,
                   "pe_group_mlp_max: nsample must be a positive multiple of 32 (got %d)", nsample);
   if (B == 0) return UNOPOSE_OK;
-  const size_t lds = (bf16x3 ? sizeof(PeLdsB) : sizeof(PeLds)) + ((size_t)3 * N + 4 * (size_t)nsample + 4 * 128) * 4;
+  const size_t lds = sizeof(PeLds) + ((size_t)3 * N + 4 * (size_t)nsample + 4 * 128) * 4;
   UNOPOSE_REQUIRE(lds <= 160 * 1024, "pe_group_mlp_max: N=%d nsample=%d exceed the LDS tile", N, nsample);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)pe_group_mlp_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    (void)hipFuncSetAttribute((const void *)pe_group_mlp_max_bf16x3_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const long centres = (long)B * N;
   const int cpw = centres >= 32768 ? 8 : centres >= 8192 ? 4 : centres >= 2048 ? 2 : 1;
   dim3 grid(cdiv(N, 4 * cpw), B);
-  if (bf16x3)
-    hipLaunchKernelGGL(pe_group_mlp_max_bf16x3_kernel, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius,
-                       nsample, cpw, w1, b1, w2, b2, w3, b3, out);
-  else
-    hipLaunchKernelGGL(pe_group_mlp_max_kernel, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius, nsample,
-                       cpw, w1, b1, w2, b2, w3, b3, out);
+  UNOPOSE_REQUIRE(!bf16x3, "pe_group_mlp_max: the bf16x3 form takes a packed weight image "
+                           "(unopose_pe_pack_weights + unopose_pe_group_mlp_max_packed)");
+  hipLaunchKernelGGL(pe_group_mlp_max_kernel, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius, nsample, cpw,
+                     w1, b1, w2, b2, w3, b3, out);
   return check_launch("pe_group_mlp_max");
 }
 

@@ -388,13 +388,21 @@ def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None):
                 w, b = l.folded()
                 flat += [w.float().contiguous(), b.float().contiguous()]
         assert [tuple(t.shape) for t in flat[::2]] == [(32, 6), (64, 32), (128, 64)], "kernel is built for [6,32,64,128]"
-        cache = (key, flat)
+        from ._lib import lib
+        image = torch.empty(lib().unopose_pe_image_bytes(), dtype=torch.uint8, device=pts.device)
+        with torch.cuda.device(pts.device):
+            call("unopose_pe_pack_weights", *(ptr(t) for t in flat), ptr(image), stream_ptr())
+        cache = (key, flat, image)
         mlp._hip_cache = cache
     w1, b1, w2, b2, w3, b3 = cache[1]
     out = torch.empty(B, N, 128, dtype=torch.float32, device=pts.device)
     with torch.cuda.device(pts.device):
-        call("unopose_pe_group_mlp_max", ptr(pts), B, N, float(radius), int(nsample), ptr(w1), ptr(b1), ptr(w2),
-             ptr(b2), ptr(w3), ptr(b3), int(bool(bf16x3)), ptr(out), stream_ptr())
+        if bf16x3:
+            call("unopose_pe_group_mlp_max_packed", ptr(pts), B, N, float(radius), int(nsample), ptr(cache[2]),
+                 ptr(out), stream_ptr())
+        else:
+            call("unopose_pe_group_mlp_max", ptr(pts), B, N, float(radius), int(nsample), ptr(w1), ptr(b1), ptr(w2),
+                 ptr(b2), ptr(w3), ptr(b3), 0, ptr(out), stream_ptr())
     return out
 
 
