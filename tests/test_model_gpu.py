@@ -341,3 +341,21 @@ def test_fused_transformer_tail_kernel(model, rows):
     assert out.dtype == torch.bfloat16 and out.shape == ref.shape
     e = (out.float() - ref).abs()
     assert e.max().item() < 6e-2 and e.mean().item() < 6e-3, (e.max().item(), e.mean().item())
+
+
+@torch.no_grad()
+def test_forward_autocast_bf16_vs_reference_golden(tamed):
+    """The autocast(bf16) forward -- the configuration bench.py times, with every bf16 HIP kernel on the
+    path (ViT flash attention, fused LN glue, bf16 embedding, RPE / cross token attention, linear
+    attention, bf16x3 PE) -- against the REFERENCE's fp32 outputs on the full-size fixture.
+    bf16 operands: rotation / translation within 2e-2 of the reference and of the ground truth."""
+    z = load("forward_full")
+    model = tamed[2048]
+    ep = {k: z[k] for k in ("pts", "tem1_pts", "rgb", "tem1_rgb", "rgb_choose", "tem1_choose")}
+    ep["coarse_rand"] = z["rand"]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(ep)
+    assert err(out["pred_R"], z["pred_R"]) < 2e-2, err(out["pred_R"], z["pred_R"])
+    assert err(out["pred_t"], z["pred_t"]) < 2e-2, err(out["pred_t"], z["pred_t"])
+    assert err(out["pred_R"][0], z["R_gt"]) < 2e-2
+    assert out["pred_pose_score"].item() > 0.9

@@ -122,3 +122,34 @@ def test_reference_error_behaviour(hip_ext):
         hip_ext.furthest_point_sampling(x.double().cuda(), 4)
     with pytest.raises(RuntimeError, match="int"):
         hip_ext.gather_points(torch.randn(1, 3, 10).cuda(), torch.zeros(1, 4, dtype=torch.int64).cuda())
+
+
+def test_pointnet2_utils_api_and_autograd(oracle_ext):
+    """The reference's python-level operator API on the HIP ops: names, argument order, non-differentiable
+    indices, and gradients of gather / group through the atomic scatter kernels (vs torch autograd)."""
+    from unopose_amd.pointnet2 import pointnet2_utils as pu
+
+    g = torch.Generator().manual_seed(2)
+    xyz = torch.rand(2, 300, 3, generator=g).cuda()
+    idx = pu.furthest_point_sample(xyz, 64)
+    assert idx.dtype == torch.int32 and not idx.requires_grad
+    feats = torch.randn(2, 16, 300, generator=g).cuda().requires_grad_(True)
+    out = pu.gather_operation(feats, idx)
+    ref = torch.gather(feats, 2, idx.long()[:, None, :].expand(-1, 16, -1))
+    w = torch.randn_like(out)
+    (g1,) = torch.autograd.grad((out * w).sum(), feats, retain_graph=True)
+    (g2,) = torch.autograd.grad((ref * w).sum(), feats)
+    torch.testing.assert_close(g1, g2, rtol=1e-5, atol=1e-5)
+    bq = pu.ball_query(0.2, 16, xyz, xyz[:, :50].contiguous())  # (radius, nsample, xyz, new_xyz)
+    assert torch.equal(bq.cpu(), oracle_ext.ball_query(xyz[:, :50].cpu().contiguous(), xyz.cpu(), 0.2, 16))
+    grouped = pu.grouping_operation(feats, bq)
+    ref = torch.gather(feats, 2, bq.long().reshape(2, 1, -1).expand(-1, 16, -1)).reshape(2, 16, 50, 16)
+    w = torch.randn_like(grouped)
+    (g1,) = torch.autograd.grad((grouped * w).sum(), feats, retain_graph=True)
+    (g2,) = torch.autograd.grad((ref * w).sum(), feats)
+    torch.testing.assert_close(g1, g2, rtol=1e-4, atol=1e-4)
+    grp = pu.QueryAndLRFGroup(0.2, 32, use_xyz=True)
+    f = grp(xyz, xyz, xyz.transpose(1, 2).contiguous())
+    assert f.shape == (2, 6, 300, 32)
+    qg = pu.QueryAndGroup(0.2, 16, use_xyz=True)
+    assert qg(xyz, xyz[:, :50].contiguous(), feats.detach()).shape == (2, 19, 50, 16)
