@@ -201,13 +201,14 @@ int unopose_coarse_scores(const float *pts1, const float *pts2, int B, int n1, i
 
 /* Attention core of the 4-head x 64 token transformers (core/unopose/model/transformer.py:130-148
  * cross, :386-405 RPE self): out (B,n,256) = softmax((q k^T [+ qp . E]) * scale) v, all tensors
- * bfloat16 bit patterns.  q (B,n,256), k (B,m,256) with channel = head*64 + c; vt (B,256,KP) = v
- * transposed to channel-major and zero-padded to KP = unopose_token_attention_key_pad() keys;
- * RPE only: qp (B,n,4,256) = q_h W_p,h (the folded proj_p), E (B,n,m,256) the geometric embedding;
- * pass qp = E = NULL for plain (cross) attention.  m <= KP. */
-int unopose_token_attention(const void *q, const void *k, const void *vt, const void *qp,
-                            const void *E, int B, int n, int m, float scale, void *out,
-                            unopose_stream_t stream);
+ * bfloat16 bit patterns.  q (B,n,256) with row stride ldq elements, k (B,m,256) with row stride ldk
+ * (so both can be read in place from a fused projection output), channel = head*64 + c; vt (B,256,KP)
+ * = v transposed to channel-major and zero-padded to KP = unopose_token_attention_key_pad() keys;
+ * RPE only: qp (B,n,4,256) with row stride ldqp = q_h W_p,h (the folded proj_p), E (B,n,m,256)
+ * contiguous, the geometric embedding; pass qp = E = NULL for plain (cross) attention.  m <= KP. */
+int unopose_token_attention(const void *q, int ldq, const void *k, int ldk, const void *vt,
+                            const void *qp, int ldqp, const void *E, int B, int n, int m,
+                            float scale, void *out, unopose_stream_t stream);
 int unopose_token_attention_key_pad(void);
 
 /* ViT attention core (timm Attention as driven by core/unopose/model/oneref_feature_extraction.py:38-41):

@@ -55,10 +55,11 @@ constexpr int TA_MP = TA_NT * 16;  // padded key count (V^T and the P staging us
 // RW = query rows per wavefront (4 fills the 16-row MFMA tile; 2 doubles the number of wavefronts that
 // stream E concurrently -- the kernel is bound by HBM latency x occupancy, not by the matrix pipe)
 template <bool RPE, int RW>
-__global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__ q, const u16 *__restrict__ k,
+__global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__ q, int ldq,
+                                                         const u16 *__restrict__ k, int ldk,
                                                          const u16 *__restrict__ vt, const u16 *__restrict__ qp,
-                                                         const u16 *__restrict__ E, int n, int m, float scale,
-                                                         u16 *__restrict__ out) {
+                                                         int ldqp, const u16 *__restrict__ E, int n, int m,
+                                                         float scale, u16 *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) u16 Pl[4][16][TA_MP];
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = (blockIdx.x * 4 + wave) * RW;  // first of this wave's RW query rows
@@ -66,8 +67,8 @@ __global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__
   const int li = lane & 15, kg = lane >> 4;     // A: row li, k-group kg | B: column li, k-group kg
   const int a_nl = li >> 2, a_h = li & 3;       // A-operand row = (query row a_nl, head a_h)
   const bool a_valid = a_nl < RW && n0 + a_nl < n;
-  const u16 *Q = q + ((size_t)b * n + n0 + a_nl) * 256;
-  const u16 *K = k + (size_t)b * m * 256;
+  const u16 *Q = q + ((size_t)b * n + n0 + a_nl) * ldq;
+  const u16 *K = k + (size_t)b * m * ldk;
 
   f32x4 acc[TA_NT];
 #pragma unroll
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__
     for (int t = 0; t < TA_NT; ++t) {
       const int mm = t * 16 + li;
       bf16x8 bv = zero8();
-      if (mm < m) bv = *reinterpret_cast<const bf16x8 *>(K + (size_t)mm * 256 + kk);
+      if (mm < m) bv = *reinterpret_cast<const bf16x8 *>(K + (size_t)mm * ldk + kk);
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bv, acc[t], 0, 0, 0);
     }
   }
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__
   if (RPE) {
     for (int nl = 0; nl < RW; ++nl) {
       if (n0 + nl >= n) break;  // wave-uniform
-      const u16 *QP = qp + (((size_t)b * n + n0 + nl) * 4 + a_h) * 256;
+      const u16 *QP = qp + ((size_t)b * n + n0 + nl) * ldqp + a_h * 256;
       const u16 *En = E + ((size_t)b * n + n0 + nl) * (size_t)m * 256;
       bf16x8 a[8];
 #pragma unroll
@@ -187,21 +188,24 @@ using namespace unopose;
 
 extern "C" {
 
-int unopose_token_attention(const void *q, const void *k, const void *vt, const void *qp, const void *E, int B, int n,
-                            int m, float scale, void *out, unopose_stream_t stream) {
+int unopose_token_attention(const void *q, int ldq, const void *k, int ldk, const void *vt, const void *qp, int ldqp,
+                            const void *E, int B, int n, int m, float scale, void *out, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(q && k && vt && out, "token_attention: null pointer");
   UNOPOSE_REQUIRE((qp == nullptr) == (E == nullptr), "token_attention: qp and E go together");
   UNOPOSE_REQUIRE(B >= 0 && n >= 1 && m >= 1 && m <= TA_MP && B <= 65535,
                   "token_attention: m=%d exceeds the %d-key tile", m, TA_MP);
+  UNOPOSE_REQUIRE(ldq >= 256 && ldk >= 256 && ldq % 8 == 0 && ldk % 8 == 0 && (!E || (ldqp >= 1024 && ldqp % 8 == 0)),
+                  "token_attention: row strides must be multiples of 8 elements (16-byte loads)");
   if (B == 0) return UNOPOSE_OK;
   hipStream_t s = (hipStream_t)stream;
   if (E)
     hipLaunchKernelGGL((token_attn_kernel<true, 4>), dim3(cdiv(n, 16), B), dim3(256), 0, s, (const u16 *)q,
-                       (const u16 *)k, (const u16 *)vt, (const u16 *)qp, (const u16 *)E, n, m, scale, (u16 *)out);
+                       ldq, (const u16 *)k, ldk, (const u16 *)vt, (const u16 *)qp, ldqp, (const u16 *)E, n, m, scale,
+                       (u16 *)out);
   else
     hipLaunchKernelGGL((token_attn_kernel<false, 4>), dim3(cdiv(n, 16), B), dim3(256), 0, s, (const u16 *)q,
-                       (const u16 *)k, (const u16 *)vt, (const u16 *)nullptr, (const u16 *)nullptr, n, m, scale,
-                       (u16 *)out);
+                       ldq, (const u16 *)k, ldk, (const u16 *)vt, (const u16 *)nullptr, 0, (const u16 *)nullptr, n, m,
+                       scale, (u16 *)out);
   return check_launch("token_attention");
 }
 

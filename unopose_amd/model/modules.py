@@ -25,9 +25,9 @@ class _Attention(nn.Module):
 
     def forward(self, x):
         B, T, C = x.shape
-        qkv = self.qkv(x)
+        qkv = ops.linear(x, self.qkv)
         o = ops.vit_attention(qkv, self.heads)  # (B,T,C): softmax(q k^T / sqrt(hd)) v per head
-        return self.proj(o)
+        return ops.linear(o, self.proj)
 
 
 class _LayerScale(nn.Module):
@@ -43,7 +43,7 @@ class _Mlp(nn.Module):
         self.fc2 = nn.Linear(ratio * dim, dim)
 
     def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x)))
+        return ops.linear(F.gelu(ops.linear(x, self.fc1)), self.fc2)
 
 
 class _Block(nn.Module):
@@ -159,7 +159,7 @@ class ViT_AE(nn.Module):
         side = H // 14
         outs = self.vit(x)
         z = torch.cat([o[:, 5:, :] for o in outs], dim=2)
-        z = self.output_upscaling(z).reshape(B, side, side, 4, 4, self.out_dim)
+        z = ops.linear(z, self.output_upscaling).reshape(B, side, side, 4, 4, self.out_dim)
         return z.permute(0, 1, 3, 2, 4, 5).reshape(B, 4 * side, 4 * side, self.out_dim), (H, W)
 
     def pixel_features(self, x, choose):
@@ -227,7 +227,7 @@ class _AttentionOutput(nn.Module):
         self.norm = nn.LayerNorm(d)
 
     def forward(self, x):
-        y = self.squeeze(F.relu(self.expand(x)))
+        y = ops.linear(F.relu(ops.linear(x, self.expand)), self.squeeze)
         if x.is_cuda and torch.is_autocast_enabled():
             return ops.add_layernorm(x, y, self.norm)  # one pass, bf16 out (csrc/fused.hip)
         return self.norm(x + y)
@@ -248,7 +248,7 @@ class TransformerLayer(nn.Module):
         if x.is_cuda and torch.is_autocast_enabled():
             if ops.USE_FUSED_TAIL and x.shape[-1] == 256:
                 return ops.transformer_tail(h, x, self)
-            x = ops.add_layernorm(a.linear(h), x, a.norm)
+            x = ops.add_layernorm(ops.linear(h, a.linear), x, a.norm)
         else:
             x = a.norm(a.linear(h) + x)
         return self.output(x)
@@ -301,7 +301,7 @@ class LinearTransformerLayer(nn.Module):
         if x.is_cuda and torch.is_autocast_enabled():
             if ops.USE_FUSED_TAIL and x.shape[-1] == 256:
                 return ops.transformer_tail(h, x, self)
-            x = ops.add_layernorm(a.linear(h), x, a.norm)
+            x = ops.add_layernorm(ops.linear(h, a.linear), x, a.norm)
         else:
             x = a.norm(a.linear(h) + x)
         return self.output(x)

@@ -32,15 +32,15 @@ class CoarsePointMatchingOneRef(nn.Module):
         if self.training:
             raise NotImplementedError("training path is out of scope (SURVEY.md 8(f-4))")
         B, n1 = f1.shape[:2]
-        f1 = self.in_proj(f1)
-        f2 = self.in_proj(f2)
+        f1 = ops.linear(f1, self.in_proj)
+        f2 = ops.linear(f2, self.in_proj)
         bg = self.bg_token.expand(B, -1, -1).to(f1.dtype)
         f1 = torch.cat([bg, f1], dim=1)
         f2 = torch.cat([bg, f2], dim=1)
         for blk in self.transformers:
             f1, f2 = blk(f1, geo1, f2, geo2)
         scores = self.score_heads[self.nblock - 1](torch.cat((f1, f2), dim=1))
-        atten = ops.feature_similarity(self.out_proj(f1), self.out_proj(f2), self.cfg.temp)
+        atten = ops.feature_similarity(ops.linear(f1, self.out_proj), ops.linear(f2, self.out_proj), self.cfg.temp)
         score = _scores(scores, n1)
         n1p, n2p = self.cfg.nproposal1, self.cfg.nproposal2
         rand = end_points.get("coarse_rand")
@@ -77,15 +77,15 @@ class FinePointMatchingOneRef(nn.Module):
             p1_ = (p1 - end_points["init_t"].unsqueeze(1)) @ end_points["init_R"]
         else:
             p1_ = p1
-        f1 = self.in_proj(f1) + self.PE(p1_).to(f1.dtype)
-        f2 = self.in_proj(f2) + self.PE(p2).to(f2.dtype)
+        f1 = ops.linear(f1, self.in_proj) + self.PE(p1_).to(f1.dtype)
+        f2 = ops.linear(f2, self.in_proj) + self.PE(p2).to(f2.dtype)
         bg = self.bg_token.expand(B, -1, -1).to(f1.dtype)
         f1 = torch.cat([bg, f1], dim=1)
         f2 = torch.cat([bg, f2], dim=1)
         for blk in self.transformers:
             f1, f2 = blk(f1, geo1, fps_idx1, f2, geo2, fps_idx2)
         scores = self.score_heads[self.nblock - 1](torch.cat((f1, f2), dim=1))
-        atten = ops.feature_similarity(self.out_proj(f1), self.out_proj(f2), self.cfg.temp)
+        atten = ops.feature_similarity(ops.linear(f1, self.out_proj), ops.linear(f2, self.out_proj), self.cfg.temp)
         score = _scores(scores, n1)
         R, t, s = ops.fine_pose(atten, score, p1, p2)
         end_points["pred_R"] = R

@@ -67,6 +67,23 @@ import torch.nn.functional as F
 from .pointnet2 import _ext
 
 
+def linear(x, lin):
+    """nn.Linear under autocast without the per-call weight cast: bf16 copies of (weight, bias) are cached
+    on the module (keyed by the parameter version) and the GEMM is issued directly in bf16.  Outside
+    autocast this is just `lin(x)`."""
+    if not (torch.is_autocast_enabled() and x.is_cuda):
+        return lin(x)
+    key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.device)
+    cache = getattr(lin, "_bf16_cache", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            cache = (key, lin.weight.detach().to(torch.bfloat16).contiguous(),
+                     None if lin.bias is None else lin.bias.detach().to(torch.bfloat16).contiguous())
+        lin._bf16_cache = cache
+    with torch.autocast("cuda", enabled=False):
+        return F.linear(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), cache[1], cache[2])
+
+
 def gather_rows(feats, idx):
     """out[b,j,:] = feats[b, idx[b,j], :]  (the (B,N,C)-layout twin of gather_operation; avoids the two
     transpose copies around every reference call, model_utils.py:146-149, transformer.py:658)."""
@@ -266,17 +283,18 @@ def _token_attention_hip(x, mem, att, embed):
         else:
             yq = F.linear(xb, w_q, b_q)
             ykv = F.linear(mem.to(bf), w_kv, b_kv)
-    q = _c(yq[..., :C])
-    k = _c(ykv[..., :C])
+    # q | qp and k | v are consumed in place from the projection outputs (row strides passed to the kernel)
     vt = torch.zeros(B, C, _KEY_PAD, dtype=bf, device=x.device)
     vt[:, :, :m] = ykv[..., C:].transpose(1, 2)
-    qp = E = None
-    if rpe:
-        qp = _c(yq[..., C:])  # (B,n,4*256)
-        E = _c(embed.to(bf))
+    E = _c(embed.to(bf)) if rpe else None
     out = torch.empty(B, n, C, dtype=bf, device=x.device)
+    esz = 2
+    q_ptr = yq.data_ptr()
+    k_ptr = ykv.data_ptr()
+    import ctypes
     with torch.cuda.device(x.device):
-        call("unopose_token_attention", ptr(q), ptr(k), ptr(vt), ptr(qp) if qp is not None else None,
+        call("unopose_token_attention", ctypes.c_void_p(q_ptr), yq.stride(1), ctypes.c_void_p(k_ptr), ykv.stride(1),
+             ptr(vt), ctypes.c_void_p(q_ptr + C * esz) if rpe else None, yq.stride(1),
              ptr(E) if E is not None else None, B, n, m, 0.125, ptr(out), stream_ptr())
     return out
 
@@ -322,7 +340,7 @@ def _focused_linear_attention_hip(xq, xkv, att, focusing):
         cache = (key, w_kv, b_kv, inv_sp)
         att._hip_cache = cache
     _, w_kv, b_kv, inv_sp = cache
-    q = _c(att.proj_q(xq).to(bf))
+    q = _c(linear(xq, att.proj_q))
     with torch.autocast("cuda", enabled=False):
         ykv = F.linear(xkv.to(bf), w_kv, b_kv)
     kproj, v = _c(ykv[..., :C]), ykv[..., C:]
