@@ -223,6 +223,13 @@ int unopose_add_layernorm(const void *a, int a_bf16, const void *b, int b_bf16, 
                           const float *bias, long rows, int C, float eps, void *out, int out_bf16,
                           unopose_stream_t stream);
 
+/* Pixel features at the chosen pixels only: bilinear resize (align_corners=False) of the 4x up-projected
+ * ViT map to (H,W) fused with get_chosen_pixel_feats (oneref_feature_extraction.py:221-229,
+ * utils/model_utils.py:215-227).  z (B,side,side,4,4,256) float32 or bfloat16 = the up-projection output
+ * in its native order, choose (B,Np) int64 flat pixel indices, out (B,Np,256) float32. */
+int unopose_bilinear_sample(const void *z, int z_bf16, const long long *choose, int B, int side, int Np,
+                            int H, int W, float *out, unopose_stream_t stream);
+
 /* x (rows,C) float32 += gamma (C) * y (rows,C) bfloat16, in place: the LayerScale residual of a
  * timm ViT block (x = x + ls(branch(x))). */
 int unopose_scale_residual(float *x, const void *y_bf16, const float *gamma, long rows, int C,

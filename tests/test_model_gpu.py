@@ -359,3 +359,24 @@ def test_forward_autocast_bf16_vs_reference_golden(tamed):
     assert err(out["pred_t"], z["pred_t"]) < 2e-2, err(out["pred_t"], z["pred_t"])
     assert err(out["pred_R"][0], z["R_gt"]) < 2e-2
     assert out["pred_pose_score"].item() > 0.9
+
+
+@torch.no_grad()
+def test_fused_bilinear_pixel_sampling():
+    """HIP fused resize+gather on the native up-projection layout vs F.interpolate + gather (the
+    reference's formulation, oneref_feature_extraction.py:221-229)."""
+    import torch.nn.functional as F
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(12)
+    B, side, S = 2, 16, 224
+    z = torch.randn(B, side, side, 4, 4, 256, generator=g).cuda()
+    choose = torch.randint(0, S * S, (B, 3000), generator=g).cuda()
+    choose[0, :4] = torch.tensor([0, S - 1, S * (S - 1), S * S - 1])  # corners
+    full = z.permute(0, 5, 1, 3, 2, 4).reshape(B, 256, 4 * side, 4 * side)
+    ref = F.interpolate(full, (S, S), mode="bilinear", align_corners=False).reshape(B, 256, S * S)
+    ref = torch.gather(ref, 2, choose.unsqueeze(1).expand(-1, 256, -1)).transpose(1, 2)
+    out = ops.bilinear_sample_native(z, choose, S, S)
+    assert err(out, ref) < 5e-5  # fp32 round-off of the source-coordinate / lambda arithmetic
+    outb = ops.bilinear_sample_native(z.bfloat16(), choose, S, S)
+    assert err(outb, ref) < 3e-2

@@ -82,6 +82,55 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(float *__restrict__
   }
 }
 
+// Pixel features: F.interpolate(map, (H,W), bilinear, align_corners=False) + the pixel gather of
+// get_chosen_pixel_feats (oneref_feature_extraction.py:221-229, utils/model_utils.py:215-227) fused and
+// evaluated ONLY at the chosen pixels.  z is the up-projection output in its native order
+// (B, side, side, 4, 4, C): the reference's permute to (B,C,4side,4side) is folded into the index math.
+// One wavefront per output point; C = 256 -> 4 channels per lane.
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void bilinear_sample_kernel(const void *__restrict__ z,
+                                                              const long long *__restrict__ choose, int side, int Np,
+                                                              int H, int W, float *__restrict__ out) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= Np) return;
+  const long long pix = choose[(size_t)b * Np + p];
+  const int py = (int)(pix / W), px = (int)(pix - (long long)py * W);
+  const int hw = 4 * side;
+  // torch upsample_bilinear2d, align_corners=False: src = max(0, (dst + 0.5) * in/out - 0.5)
+  const float sy = fmaxf(((float)py + 0.5f) * ((float)hw / (float)H) - 0.5f, 0.f);
+  const float sx = fmaxf(((float)px + 0.5f) * ((float)hw / (float)W) - 0.5f, 0.f);
+  const int y0 = min((int)sy, hw - 1), x0 = min((int)sx, hw - 1);
+  const int y1 = y0 < hw - 1 ? y0 + 1 : y0, x1 = x0 < hw - 1 ? x0 + 1 : x0;
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  auto at = [&](int Y, int X) -> size_t {  // element offset of map pixel (Y,X), channel 0
+    return ((((size_t)b * side + (Y >> 2)) * side + (X >> 2)) * 16 + (Y & 3) * 4 + (X & 3)) * 256;
+  };
+  const size_t o00 = at(y0, x0), o01 = at(y0, x1), o10 = at(y1, x0), o11 = at(y1, x1);
+  float v[4][4];
+  const size_t offs[4] = {o00, o01, o10, o11};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (IN_BF16) {
+      const uint2 r = *reinterpret_cast<const uint2 *>(reinterpret_cast<const u16 *>(z) + offs[k] + lane * 4);
+      v[k][0] = fu_bf2f((u16)(r.x & 0xFFFF)); v[k][1] = fu_bf2f((u16)(r.x >> 16));
+      v[k][2] = fu_bf2f((u16)(r.y & 0xFFFF)); v[k][3] = fu_bf2f((u16)(r.y >> 16));
+    } else {
+      const float4 r = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(z) + offs[k] + lane * 4);
+      v[k][0] = r.x; v[k][1] = r.y; v[k][2] = r.z; v[k][3] = r.w;
+    }
+  }
+  float4 res;
+  float *rp = &res.x;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float top = (1.f - lx) * v[0][c] + lx * v[1][c];
+    const float bot = (1.f - lx) * v[2][c] + lx * v[3][c];
+    rp[c] = (1.f - ly) * top + ly * bot;
+  }
+  *reinterpret_cast<float4 *>(out + ((size_t)b * Np + p) * 256 + lane * 4) = res;
+}
+
 }  // namespace unopose
 
 using namespace unopose;
@@ -115,6 +164,21 @@ int unopose_add_layernorm(const void *a, int a_bf16, const void *b, int b_bf16, 
   }
 #undef UNOPOSE_LN
   return check_launch("add_layernorm");
+}
+
+int unopose_bilinear_sample(const void *z, int z_bf16, const long long *choose, int B, int side, int Np, int H, int W,
+                            float *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(z && choose && out, "bilinear_sample: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && side >= 1 && Np >= 0 && H >= 1 && W >= 1 && B <= 65535, "bilinear_sample: bad sizes");
+  if (B == 0 || Np == 0) return UNOPOSE_OK;
+  dim3 grid(cdiv(Np, 4), B);
+  if (z_bf16)
+    hipLaunchKernelGGL(bilinear_sample_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, choose, side, Np, H, W,
+                       out);
+  else
+    hipLaunchKernelGGL(bilinear_sample_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, choose, side, Np, H,
+                       W, out);
+  return check_launch("bilinear_sample");
 }
 
 int unopose_scale_residual(float *x, const void *y_bf16, const float *gamma, long rows, int C,

@@ -162,7 +162,18 @@ class ViT_AE(nn.Module):
         z = ops.linear(z, self.output_upscaling).reshape(B, side, side, 4, 4, self.out_dim)
         return z.permute(0, 1, 3, 2, 4, 5).reshape(B, 4 * side, 4 * side, self.out_dim), (H, W)
 
+    def upprojected(self, x):
+        """(B,3,S,S) -> up-projection output in its native order (B, side, side, 4, 4, 256)."""
+        B, _, H, W = x.shape
+        side = H // 14
+        outs = self.vit(x)
+        z = torch.cat([o[:, 5:, :] for o in outs], dim=2)
+        return ops.linear(z, self.output_upscaling).reshape(B, side, side, 4, 4, self.out_dim), (H, W)
+
     def pixel_features(self, x, choose):
+        if x.is_cuda and self.out_dim == 256:
+            z, (H, W) = self.upprojected(x)
+            return ops.bilinear_sample_native(z, choose, H, W)
         low, (H, W) = self.lowres_map(x)
         return ops.bilinear_sample_pixels(low, choose, H, W)
 

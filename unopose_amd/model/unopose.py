@@ -138,11 +138,11 @@ class UNOPose(nn.Module):
                 t.record_stream(main)
         # both crops through the ViT as ONE batch of 2B images
         B = rgb.shape[0]
-        low, (H, W) = net.lowres_map(torch.cat([rgb, tem_rgb], 0))
-        dense_fm = ops.bilinear_sample_pixels(low[:B], choose, H, W)
+        z, (H, W) = net.upprojected(torch.cat([rgb, tem_rgb], 0))
+        dense_fm = ops.bilinear_sample_native(z[:B], choose, H, W)
         main.wait_stream(side)
         # only the FPS-selected reference pixels are ever interpolated (gather commutes with sampling)
-        dense_fo = ops.bilinear_sample_pixels(low[B:], sel_choose, H, W)
+        dense_fo = ops.bilinear_sample_native(z[B:], sel_choose, H, W)
         return dense_pm, dense_fm, dense_po, dense_fo, radius
 
     def _side_stream(self, device):
