@@ -336,7 +336,7 @@ def focused_linear_attention(xq, xkv, att, heads, focusing):
     focusing + per-head contraction + z scaling run in ONE HIP kernel per side (csrc/linattn.hip);
     otherwise the op-by-op composite."""
     if torch.is_autocast_enabled() and heads == 4 and xq.shape[-1] == 256 and xq.is_cuda \
-            and float(focusing) == int(focusing):
+            and float(focusing) == 3.0:
         return _focused_linear_attention_hip(xq, xkv, att, int(focusing))
     return focused_linear_attention_torch(xq, xkv, att, heads, focusing)
 
