@@ -138,12 +138,26 @@ __global__ __launch_bounds__(GE_THREADS) void geo_embed_kernel(
   for (int c = wave; c < 4 * GE_PAIRS; c += GE_THREADS / 64) {
     const float idx = sidx[c];
     float s0, c0, s1, c1;
-    sincos_cw(idx * div0, s0, c0);
     const float w1 = idx * div1;
-    if (fabsf(idx) < 32.f) {  // wave-uniform
+    if (!SPLIT) {
+      // bf16 operands (8-bit mantissa): the hardware v_sin_f32 / v_cos_f32 (argument in revolutions,
+      // ~1e-6 absolute error) are far more accurate than the rounding that follows
+      const float r0 = idx * div0 * 0.15915494309189535f;
+      s0 = __builtin_amdgcn_sinf(r0);
+      c0 = __builtin_amdgcn_cosf(r0);
       sincos_small(w1, s1, c1);
+      if (fabsf(idx) >= 32.f) {  // wave-uniform, never taken for normalised clouds
+        const float r1 = w1 * 0.15915494309189535f;
+        s1 = __builtin_amdgcn_sinf(r1);
+        c1 = __builtin_amdgcn_cosf(r1);
+      }
     } else {
-      sincos_cw(w1, s1, c1);
+      sincos_cw(idx * div0, s0, c0);
+      if (fabsf(idx) < 32.f) {  // wave-uniform
+        sincos_small(w1, s1, c1);
+      } else {
+        sincos_cw(w1, s1, c1);
+      }
     }
     // channel 2t = sin(w_t), 2t+1 = cos(w_t)  (transformer.py:278-282)
     const int rbase = c;  // = set * GE_PAIRS + row
@@ -173,14 +187,35 @@ __global__ __launch_bounds__(GE_THREADS) void geo_embed_kernel(
   const bf16x8 *Wa_hi = reinterpret_cast<const bf16x8 *>(wa_hi) + wave * 64 + lane;
   const bf16x8 *Wd_lo = SPLIT ? reinterpret_cast<const bf16x8 *>(wd_lo) + wave * 64 + lane : nullptr;
   const bf16x8 *Wa_lo = SPLIT ? reinterpret_cast<const bf16x8 *>(wa_lo) + wave * 64 + lane : nullptr;
-#pragma unroll 2
+  // B (weight) fragments come from L2 (~500+ cycles): keep a 4-deep register prefetch ring ahead of the MFMAs
+  constexpr int PF = 4;
+  bf16x8 rbd[PF], rba[PF], rbdl[PF], rbal[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    rbd[i] = Wd_hi[i * 512];
+    rba[i] = Wa_hi[i * 512];
+    if (SPLIT) {
+      rbdl[i] = Wd_lo[i * 512];
+      rbal[i] = Wa_lo[i * 512];
+    }
+  }
+#pragma unroll
   for (int ks = 0; ks < GE_DIM / 16; ++ks) {
     const int kidx = ks * 2 + khalf;  // which group of 8 k's this lane holds
-    const bf16x8 bd = Wd_hi[ks * 512], ba = Wa_hi[ks * 512];
+    const int slot = ks % PF;
+    const bf16x8 bd = rbd[slot], ba = rba[slot];
     bf16x8 bdl, bal;
     if (SPLIT) {
-      bdl = Wd_lo[ks * 512];
-      bal = Wa_lo[ks * 512];
+      bdl = rbdl[slot];
+      bal = rbal[slot];
+    }
+    if (ks + PF < GE_DIM / 16) {
+      rbd[slot] = Wd_hi[(ks + PF) * 512];
+      rba[slot] = Wa_hi[(ks + PF) * 512];
+      if (SPLIT) {
+        rbdl[slot] = Wd_lo[(ks + PF) * 512];
+        rbal[slot] = Wa_lo[(ks + PF) * 512];
+      }
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
