@@ -211,6 +211,15 @@ int unopose_token_attention(const void *q, int ldq, const void *k, int ldk, cons
                             float scale, void *out, unopose_stream_t stream);
 int unopose_token_attention_key_pad(void);
 
+/* float32 twins of unopose_token_attention / unopose_vit_attention (same layouts, float32 data; vt zero-
+ * padded to unopose_token_attention_key_pad() keys): operands are split on the fly into hi + lo bfloat16
+ * and every product issued as 3 bf16 MFMAs (fp32 accumulation, ~2^-16 relative error), so the fp32
+ * configuration of the reference (configs/main_cfg.py:87-89) also runs on hand-written kernels. */
+int unopose_token_attention_f32(const float *q, int ldq, const float *k, int ldk, const float *vt,
+                                const float *qp, int ldqp, const float *E, int B, int n, int m,
+                                float scale, float *out, unopose_stream_t stream);
+int unopose_vit_attention_f32(const float *qkv, int B, int T, int H, float *out, unopose_stream_t stream);
+
 /* ViT attention core (timm Attention as driven by core/unopose/model/oneref_feature_extraction.py:38-41):
  * out (B,T,H*64) = softmax(q k^T / 8) v per head, flash-style.  qkv (B,T,3,H,64) = the fused qkv Linear
  * output; bfloat16 bit patterns. */

@@ -380,3 +380,25 @@ def test_fused_bilinear_pixel_sampling():
     assert err(out, ref) < 5e-5  # fp32 round-off of the source-coordinate / lambda arithmetic
     outb = ops.bilinear_sample_native(z.bfloat16(), choose, S, S)
     assert err(outb, ref) < 3e-2
+
+
+@torch.no_grad()
+def test_fp32_class_attention_kernels(model):
+    """hi/lo-split (bf16x3) attention kernels used by the fp32 configuration: token attention (RPE self
+    and cross) and ViT attention vs the op-by-op fp32 composites.  Tolerance 2e-4 (fp32-class)."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(43)
+    B, n = 2, 197
+    pts = torch.cat([torch.ones(B, 1, 3), torch.rand(B, n - 1, 3, generator=g) * 1.2 - 0.6], 1).cuda()
+    E = ops.geo_embedding(pts, model.geo_embedding)
+    x = torch.randn(B, n, 256, generator=g).cuda()
+    y = torch.randn(B, n, 256, generator=g).cuda()
+    l0 = model.coarse_point_matching.transformers[0].layers[0].attention.attention
+    l1 = model.coarse_point_matching.transformers[0].layers[1].attention.attention
+    assert err(ops.token_attention(x, x, l0, 4, E), ops.token_attention_torch(x, x, l0, 4, E)) < 2e-4
+    assert err(ops.token_attention(x, y, l1, 4, None), ops.token_attention_torch(x, y, l1, 4, None)) < 2e-4
+    for T in (261, 70):
+        qkv = torch.randn(2, T, 3 * 768, generator=g).cuda()
+        qkv[:, :, :768] *= 2.0
+        assert err(ops.vit_attention(qkv, 12), ops.vit_attention_torch(qkv, 12)) < 2e-4

@@ -40,6 +40,8 @@ SIGNATURES = {
     "unopose_coarse_scores": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P],
     "unopose_token_attention": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _F, _P, _P],
     "unopose_token_attention_key_pad": [],
+    "unopose_token_attention_f32": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _F, _P, _P],
+    "unopose_vit_attention_f32": [_P, _I, _I, _I, _P, _P],
     "unopose_vit_attention": [_P, _I, _I, _I, _P, _P],
     "unopose_add_layernorm": [_P, _I, _P, _I, _P, _P, ctypes.c_long, _I, _F, _P, _I, _P],
     "unopose_bilinear_sample": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P],

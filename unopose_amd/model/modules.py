@@ -239,8 +239,8 @@ class _AttentionOutput(nn.Module):
 
     def forward(self, x):
         y = ops.linear(F.relu(ops.linear(x, self.expand)), self.squeeze)
-        if x.is_cuda and torch.is_autocast_enabled():
-            return ops.add_layernorm(x, y, self.norm)  # one pass, bf16 out (csrc/fused.hip)
+        if x.is_cuda:
+            return ops.add_layernorm(x, y, self.norm)  # one pass (csrc/fused.hip); bf16 out under autocast
         return self.norm(x + y)
 
 
@@ -256,8 +256,8 @@ class TransformerLayer(nn.Module):
     def forward(self, x, mem, embed=None):
         a = self.attention
         h = ops.token_attention(x, mem, a.attention, self.heads, embed)
-        if x.is_cuda and torch.is_autocast_enabled():
-            if ops.USE_FUSED_TAIL and x.shape[-1] == 256:
+        if x.is_cuda:
+            if ops.USE_FUSED_TAIL and torch.is_autocast_enabled() and x.shape[-1] == 256:
                 return ops.transformer_tail(h, x, self)
             x = ops.add_layernorm(ops.linear(h, a.linear), x, a.norm)
         else:
@@ -309,8 +309,8 @@ class LinearTransformerLayer(nn.Module):
     def forward(self, x, mem):
         a = self.attention
         h = ops.focused_linear_attention(x, mem, a.attention, self.heads, self.focusing_factor)
-        if x.is_cuda and torch.is_autocast_enabled():
-            if ops.USE_FUSED_TAIL and x.shape[-1] == 256:
+        if x.is_cuda:
+            if ops.USE_FUSED_TAIL and torch.is_autocast_enabled() and x.shape[-1] == 256:
                 return ops.transformer_tail(h, x, self)
             x = ops.add_layernorm(ops.linear(h, a.linear), x, a.norm)
         else:

@@ -101,6 +101,13 @@ def vit_attention(qkv, heads):
         with torch.cuda.device(qkv.device):
             call("unopose_vit_attention", ptr(qkv), B, T, heads, ptr(out), stream_ptr())
         return out
+    if qkv.dtype == torch.float32 and qkv.is_cuda and qkv.shape[-1] == 3 * heads * 64:
+        B, T, C3 = qkv.shape
+        qkv = _c(qkv)
+        out = torch.empty(B, T, C3 // 3, dtype=torch.float32, device=qkv.device)
+        with torch.cuda.device(qkv.device):
+            call("unopose_vit_attention_f32", ptr(qkv), B, T, heads, ptr(out), stream_ptr())
+        return out
     return vit_attention_torch(qkv, heads)
 
 
@@ -245,13 +252,54 @@ def token_attention(x, mem, att, heads, embed=None):
     Under autocast(bf16) the whole core (q k^T, folded RPE term, softmax, P v) is ONE HIP kernel on the
     bf16 matrix cores (csrc/attn.hip) that streams E once; in fp32 the op-by-op composite below runs."""
     global _KEY_PAD
-    if torch.is_autocast_enabled() and heads == 4 and x.shape[-1] == 256:
+    if x.is_cuda and heads == 4 and x.shape[-1] == 256:
         if _KEY_PAD is None:
             from ._lib import lib
             _KEY_PAD = lib().unopose_token_attention_key_pad()
         if mem.shape[1] <= _KEY_PAD:
-            return _token_attention_hip(x, mem, att, embed)
+            if torch.is_autocast_enabled():
+                return _token_attention_hip(x, mem, att, embed)
+            if x.dtype == torch.float32:
+                return _token_attention_hip_f32(x, mem, att, embed)
     return token_attention_torch(x, mem, att, heads, embed)
+
+
+def _token_attention_hip_f32(x, mem, att, embed):
+    """fp32 path: same kernel scheme with hi/lo-split bf16 MFMAs (csrc/attn_f32.hip); projections in
+    fp32 with the RPE fold baked into the weights (exact algebra, fp32 rounding)."""
+    import ctypes
+
+    B, n, C = x.shape
+    m = mem.shape[1]
+    rpe = embed is not None
+    key = (att.proj_q.weight._version, att.proj_k.weight._version, att.proj_v.weight._version,
+           att.proj_q.weight.data_ptr(), rpe, "f32")
+    cache = getattr(att, "_hip_cache_f32", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            wq, bq = att.proj_q.weight.float(), att.proj_q.bias.float()
+            pw, pb = [wq], [bq]
+            if rpe:
+                wp = att.proj_p.weight.float().reshape(4, 64, 256)
+                pw.append(torch.einsum("hcd,hci->hdi", wp, wq.reshape(4, 64, 256)).reshape(1024, 256))
+                pb.append(torch.einsum("hcd,hc->hd", wp, bq.reshape(4, 64)).reshape(1024))
+            cache = (key, torch.cat(pw, 0).contiguous(), torch.cat(pb, 0).contiguous(),
+                     torch.cat([att.proj_k.weight.float(), att.proj_v.weight.float()], 0).contiguous(),
+                     torch.cat([att.proj_k.bias.float(), att.proj_v.bias.float()], 0).contiguous())
+        att._hip_cache_f32 = cache
+    _, w_q, b_q, w_kv, b_kv = cache
+    yq = F.linear(x, w_q, b_q)
+    ykv = F.linear(mem, w_kv, b_kv)
+    vt = torch.zeros(B, C, _KEY_PAD, dtype=torch.float32, device=x.device)
+    vt[:, :, :m] = ykv[..., C:].transpose(1, 2)
+    E = _c(embed.float()) if rpe else None
+    out = torch.empty(B, n, C, dtype=torch.float32, device=x.device)
+    qptr, kptr = yq.data_ptr(), ykv.data_ptr()
+    with torch.cuda.device(x.device):
+        call("unopose_token_attention_f32", ctypes.c_void_p(qptr), yq.stride(1), ctypes.c_void_p(kptr), ykv.stride(1),
+             ptr(vt), ctypes.c_void_p(qptr + C * 4) if rpe else None, yq.stride(1), ptr(E) if rpe else None, B, n, m,
+             0.125, ptr(out), stream_ptr())
+    return out
 
 
 def _attn_weights(att, rpe):
