@@ -255,6 +255,8 @@ class TransformerLayer(nn.Module):
 
     def forward(self, x, mem, embed=None):
         a = self.attention
+        if mem is None:  # self-attention
+            mem = x
         h = ops.token_attention(x, mem, a.attention, self.heads, embed)
         if x.is_cuda:
             if ops.USE_FUSED_TAIL and torch.is_autocast_enabled() and x.shape[-1] == 256:
@@ -273,11 +275,28 @@ class GeometricTransformer(nn.Module):
         self.layers = nn.ModuleList([TransformerLayer(d, True, heads), TransformerLayer(d, False, heads)])
 
     def forward(self, f0, e0, f1, e1):
-        f0 = self.layers[0](f0, f0, e0)
-        f1 = self.layers[0](f1, f1, e1)
+        e_all = _adjacent(e0, e1)
+        if e_all is not None and f0.shape == f1.shape:
+            # the self layer shares its weights between the clouds (T:498-499): run both as ONE batch of 2B
+            # (the embeddings of the two clouds were produced back to back in one buffer)
+            B = f0.shape[0]
+            f = self.layers[0](torch.cat([f0, f1], 0), None, e_all)
+            f0, f1 = f[:B], f[B:]
+        else:
+            f0 = self.layers[0](f0, f0, e0)
+            f1 = self.layers[0](f1, f1, e1)
         f0 = self.layers[1](f0, f1)
         f1 = self.layers[1](f1, f0)
         return f0, f1
+
+
+def _adjacent(e0, e1):
+    """(2B,...) view over e0 | e1 when they are contiguous halves of one allocation, else None."""
+    if (e0.shape != e1.shape or e0.dtype != e1.dtype or not e0.is_contiguous() or not e1.is_contiguous()
+            or e0.untyped_storage().data_ptr() != e1.untyped_storage().data_ptr()
+            or e1.storage_offset() != e0.storage_offset() + e0.numel()):
+        return None
+    return e0.as_strided((2 * e0.shape[0],) + tuple(e0.shape[1:]), e0.stride())
 
 
 class _LinearAttention(nn.Module):

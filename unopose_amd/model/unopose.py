@@ -77,8 +77,13 @@ class FinePointMatchingOneRef(nn.Module):
             p1_ = (p1 - end_points["init_t"].unsqueeze(1)) @ end_points["init_R"]
         else:
             p1_ = p1
-        f1 = ops.linear(f1, self.in_proj) + self.PE(p1_).to(f1.dtype)
-        f2 = ops.linear(f2, self.in_proj) + self.PE(p2).to(f2.dtype)
+        if p1_.shape == p2.shape:  # both clouds through the fused PE kernels as one batch of 2B
+            pe = self.PE(torch.cat([p1_, p2], 0))
+            pe1, pe2 = pe[:B], pe[B:]
+        else:
+            pe1, pe2 = self.PE(p1_), self.PE(p2)
+        f1 = ops.linear(f1, self.in_proj) + pe1.to(f1.dtype)
+        f2 = ops.linear(f2, self.in_proj) + pe2.to(f2.dtype)
         bg = self.bg_token.expand(B, -1, -1).to(f1.dtype)
         f1 = torch.cat([bg, f1], dim=1)
         f2 = torch.cat([bg, f2], dim=1)
@@ -170,10 +175,12 @@ class UNOPose(nn.Module):
         bg_point = torch.ones(B, 1, 3, device=dense_pm.device)
         sparse_pm, sparse_pm_lrf, sparse_fm, fps_idx_m = self._sample_wlrf(dense_pm, dense_pm_lrf, dense_fm,
                                                                          self.coarse_npoint)
-        geo_m = self.geo_embedding(torch.cat([bg_point, sparse_pm_lrf], dim=1))
         sparse_po, sparse_po_lrf, sparse_fo, fps_idx_o = self._sample_wlrf(dense_po, dense_po_lrf, dense_fo,
                                                                          self.coarse_npoint)
-        geo_o = self.geo_embedding(torch.cat([bg_point, sparse_po_lrf], dim=1))
+        # both clouds' embeddings from ONE launch into ONE buffer (the RPE self layers then run 2B at once)
+        geo = self.geo_embedding(torch.cat([torch.cat([bg_point, sparse_pm_lrf], dim=1),
+                                            torch.cat([bg_point, sparse_po_lrf], dim=1)], dim=0))
+        geo_m, geo_o = geo[:B], geo[B:]
         end_points = self.coarse_point_matching(sparse_pm, sparse_fm, geo_m, sparse_po, sparse_fo, geo_o, radius,
                                                 end_points)
         if self.test_coarse_only:
