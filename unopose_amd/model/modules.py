@@ -353,8 +353,13 @@ class SparseToDenseTransformer(nn.Module):
 
     def forward(self, d0, e0, i0, d1, e1, i1):
         f0, f1 = self.sparse_layer(self._sample(d0, i0), e0, self._sample(d1, i1), e1)
-        n0 = self.dense_layer(d0[:, 1:], f0[:, 1:])
-        n1 = self.dense_layer(d1[:, 1:], f1[:, 1:])
+        if d0.shape == d1.shape and f0.shape == f1.shape:  # weight-shared dense layer: both clouds as 2B
+            B = d0.shape[0]
+            nn_ = self.dense_layer(torch.cat([d0[:, 1:], d1[:, 1:]], 0), torch.cat([f0[:, 1:], f1[:, 1:]], 0))
+            n0, n1 = nn_[:B], nn_[B:]
+        else:
+            n0 = self.dense_layer(d0[:, 1:], f0[:, 1:])
+            n1 = self.dense_layer(d1[:, 1:], f1[:, 1:])
         return torch.cat([f0[:, 0:1], n0], 1), torch.cat([f1[:, 0:1], n1], 1)
 
 
