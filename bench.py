@@ -157,15 +157,10 @@ def main():
     torch.manual_seed(0)
     cfg = default_model_cfg(feature_extraction=dict(img_size=args.img))
     model = trained_like_(UNOPose(cfg)).to(dev).eval()
-    if world > 1:  # one broadcast of the flat weights from rank 0
-        flat = torch.cat([p.data.reshape(-1) for p in model.parameters()] +
-                         [b.data.float().reshape(-1) for b in model.buffers()])
-        dist.broadcast(flat, 0)
-        off = 0
-        for t in list(model.parameters()) + list(model.buffers()):
-            n = t.numel()
-            t.data.copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
-            off += n
+    if world > 1:  # one flat broadcast of the weights from rank 0 over RCCL / xGMI
+        from unopose_amd.runner import broadcast_module_
+
+        broadcast_module_(model, 0)
     B = args.batch
     batch, R_gt, t_gt = make_batch(B, 2048, 5000, args.img, seed=100 + rank, device=dev)
     batch["coarse_rand"] = torch.rand(B, 18000, device=dev)
