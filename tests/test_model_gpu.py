@@ -402,3 +402,46 @@ def test_fp32_class_attention_kernels(model):
         qkv = torch.randn(2, T, 3 * 768, generator=g).cuda()
         qkv[:, :, :768] *= 2.0
         assert err(ops.vit_attention(qkv, 12), ops.vit_attention_torch(qkv, 12)) < 2e-4
+
+
+@torch.no_grad()
+def test_forward_variants(tamed):
+    """The two optional branches of UNOPose.forward: `test_coarse_only` (M:56-60) and the precomputed
+    reference features `dense_po` / `dense_fo` (F:252-263)."""
+    from unopose_amd.model import UNOPose, default_model_cfg
+
+    z = load("forward_full")
+    model = tamed[2048]
+    ep = {k: z[k] for k in ("pts", "tem1_pts", "rgb", "tem1_rgb", "rgb_choose", "tem1_choose")}
+    ep["coarse_rand"] = z["rand"]
+    full = model(dict(ep))
+    model.test_coarse_only = True
+    try:
+        co = model(dict(ep))
+    finally:
+        model.test_coarse_only = False
+    assert err(co["pred_R"], full["init_R"]) < 1e-6 and err(co["pred_pose_score"], full["init_pose_score"]) < 1e-6
+    # precomputed reference: un-normalised FPS-2048 subset + its features
+    _, _, dense_po, dense_fo, radius = model._features(dict(ep))
+    ep2 = {k: ep[k] for k in ("pts", "rgb", "rgb_choose", "tem1_pts", "coarse_rand")}
+    ep2["dense_po"] = dense_po * (radius.reshape(-1, 1, 1) + 1e-6)
+    ep2["dense_fo"] = dense_fo
+    pre = model(ep2)
+    assert err(pre["pred_R"][0], z["R_gt"]) < 1e-2 and err(pre["pred_t"][0], z["t_gt"]) < 1e-2
+
+
+@torch.no_grad()
+def test_unsupported_shapes_fall_back_to_gpu_composites(model):
+    """Shapes the fused kernels are not built for run the op-by-op GPU composites (never a CPU path)."""
+    from unopose_amd import ops
+    from unopose_amd.model.modules import GeometricStructureEmbedding
+    from unopose_amd.model.config import Cfg
+
+    geo128 = GeometricStructureEmbedding(Cfg(sigma_d=0.2, sigma_a=15, angle_k=3, reduction_a="max", hidden_dim=128))
+    geo128 = geo128.cuda().eval()
+    pts = torch.rand(1, 20, 3).cuda()
+    out = geo128(pts)
+    assert out.shape == (1, 20, 20, 128) and out.is_cuda
+    x = torch.rand(1, 100, 3).cuda()
+    mlp = model.fine_point_matching.PE.mlp1
+    assert ops.pe_group_mlp_max(x, 0.3, 16, mlp).shape == (1, 100, 128)  # nsample not a multiple of 32

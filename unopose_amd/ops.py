@@ -189,6 +189,8 @@ def geo_embedding(points, m, out_dtype=None):
     (sinusoid generation -> MFMA -> max-over-k epilogue; csrc/embed.hip).  Under autocast(bf16) the
     result is bf16 with plain bf16 operands (what proj_d / proj_a produce under autocast in the
     reference); otherwise fp32 with hi/lo-split operands (fp32-class accuracy)."""
+    if m.proj_d.weight.shape != (256, 256) or m.angle_k != 3 or points.shape[1] < 4:
+        return geo_embedding_torch(points, m)  # other widths / k: op-by-op GPU composite
     points = _c(points.float())
     check_f32(points, "points")
     B, n, _ = points.shape
@@ -456,6 +458,8 @@ def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None):
     (or bf16x3=True) bf16 MFMA with hi/lo-split operands (~2^-16 relative error, ~5x the fp32 MFMA rate)."""
     if bf16x3 is None:
         bf16x3 = torch.is_autocast_enabled()
+    if [tuple(l.conv.weight.shape[:2]) for l in mlp.layers()] != [(32, 6), (64, 32), (128, 64)] or nsample % 32:
+        return pe_group_mlp_max_unfused(pts, radius, nsample, mlp)  # other widths: grouping kernel + GEMMs
     pts = _c(pts.float())
     check_f32(pts, "pts")
     B, N, _ = pts.shape
