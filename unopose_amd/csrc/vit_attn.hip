@@ -33,11 +33,20 @@ constexpr int VA_LDV = VA_CHUNK + 8;     // padded row of the V^T chunk [channel
 // The 4 waves of a workgroup share one (image, head): K and V of a 128-key chunk are loaded once with
 // coalesced 16-byte reads, K kept row-major and V transposed on the way into LDS (so the caller needs no
 // V^T copy), then every wave runs its 32 queries against the chunk.
-__global__ __launch_bounds__(256) void vit_attn_kernel(const u16 *__restrict__ qkv, int T, int H, float scale_log2e,
+__device__ __forceinline__ uint32_t va_cvt_pk(float a, float b) {  // packed RNE fp32 -> bf16 (gfx950)
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void vit_attn_kernel(const u16 *__restrict__ qkv, int T, int H, float scale_log2e,
                                                        u16 *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) u16 Ks[VA_CHUNK][VA_LDK];
-  __shared__ __attribute__((aligned(16))) u16 Vs[64][VA_LDV];
-  __shared__ __attribute__((aligned(16))) u16 Ot[4][32][72];  // per wave: 32 tokens x 64 channels (+8 pad)
+  // K chunk [key][ch] + V^T chunk [ch][key]; the same bytes serve as the output transpose buffer at the end
+  __shared__ __attribute__((aligned(16))) u16 smem[VA_CHUNK * VA_LDK + 64 * VA_LDV];
+  u16 (*Ks)[VA_LDK] = reinterpret_cast<u16 (*)[VA_LDK]>(smem);
+  u16 (*Vs)[VA_LDV] = reinterpret_cast<u16 (*)[VA_LDV]>(smem + VA_CHUNK * VA_LDK);
+  u16 (*Ot)[32][72] = reinterpret_cast<u16 (*)[32][72]>(smem);
+  static_assert(4 * 32 * 72 <= VA_CHUNK * VA_LDK + 64 * VA_LDV, "output staging must fit the chunk buffers");
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q0 = (blockIdx.x * 4 + wave) * 32;
@@ -45,7 +54,6 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const u16 *__restrict__ q
   const int col = lane & 31, hb = lane >> 5;
   const int C3 = 3 * H * 64;
   const u16 *base = qkv + (size_t)b * T * C3;
-  // Q as the B operand: lane (query col, hb) holds 8 consecutive channels per k-step
   bf16x8 qf[4];
   {
     const int tq = min(q0 + col, T - 1);
@@ -58,24 +66,37 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const u16 *__restrict__ q
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  // running max in the exp2 domain (score * scale * log2 e) and running sum
   float m_run = -3e38f, l_run = 0.f;
 
-  for (int c0 = 0; c0 < T; c0 += VA_CHUNK) {
-    __syncthreads();  // previous chunk fully consumed
-    // ---- stage the chunk: 128 keys x 128 B for K and for V (8 lanes per key row: coalesced)
+  // register-staged prefetch of a chunk: 128 keys x 128 B of K and of V, 8 lanes per key row (coalesced)
+  uint4 pk[4], pv[4];
+  auto chunk_load = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = tid + i * 256, key = e >> 3, c8 = e & 7;
-      const int tk = min(c0 + key, T - 1);
-      const u16 *src = base + (size_t)tk * C3 + h * 64 + c8 * 8;
-      const uint4 kv = *reinterpret_cast<const uint4 *>(src + H * 64);
+      const u16 *src = base + (size_t)min(c0 + key, T - 1) * C3 + h * 64 + c8 * 8;
+      pk[i] = *reinterpret_cast<const uint4 *>(src + H * 64);
+      pv[i] = *reinterpret_cast<const uint4 *>(src + 2 * H * 64);
+    }
+  };
+  auto chunk_store = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256, key = e >> 3, c8 = e & 7;
+      *reinterpret_cast<uint4 *>(&Ks[key][c8 * 8]) = pk[i];
       union { uint4 v; u16 u[8]; } vv;
-      vv.v = *reinterpret_cast<const uint4 *>(src + 2 * H * 64);
-      *reinterpret_cast<uint4 *>(&Ks[key][c8 * 8]) = kv;
+      vv.v = pv[i];
       const bool valid = c0 + key < T;  // keys beyond T contribute V = 0 (their P is 0 as well)
 #pragma unroll
       for (int j = 0; j < 8; ++j) Vs[c8 * 8 + j][key] = valid ? vv.u[j] : (u16)0;
     }
+  };
+  chunk_load(0);
+  for (int c0 = 0; c0 < T; c0 += VA_CHUNK) {
+    __syncthreads();  // previous chunk fully consumed
+    chunk_store(c0);
+    if (c0 + VA_CHUNK < T) chunk_load(c0 + VA_CHUNK);  // in flight under this chunk's MFMAs
     __syncthreads();
     if (!active) continue;
     const int nk = min(VA_CHUNK, T - c0);
@@ -90,36 +111,40 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const u16 *__restrict__ q
         const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(&Ks[kt + col][ks * 16 + hb * 8]);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
       }
-      // ---- online softmax for this lane's query over its 16 keys (+ the other half-wave's 16)
-      float mx = -3e38f;
+      if (k0 + 32 > T) {  // only the last tile can hold keys >= T (wave-uniform branch)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hb;
-        s[r] = key < T ? s[r] * scale_log2e : -3e38f;
-        mx = fmaxf(mx, s[r]);
+        for (int r = 0; r < 16; ++r)
+          if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hb >= T) s[r] = -3e38f;
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      // ---- online softmax for this lane's query over its 16 keys (+ the other half-wave's 16)
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;  // scale > 0: max commutes with it
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f(m_run - m_new);
       float ls = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = exp2f(s[r] - m_new);
+        s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_new));
         ls += s[r];
       }
       ls += __shfl_xor(ls, 32);
-      l_run = l_run * alpha + ls;
-      m_run = m_new;
+      if (__any(m_new > m_run)) {  // rescale the accumulators only when some query's max moved
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        m_run = m_new;
+      }
+      l_run += ls;
       // ---- O^T += V^T P^T ; k-step s2 = accumulator registers 8*s2 .. 8*s2+7 (permuted key order)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        union { bf16x8 v; u16 u[8]; } pf;
+        union { bf16x8 v; uint32_t w[4]; } pf;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pf.u[e] = va_f2bf(s[s2 * 8 + e]);
+        for (int e = 0; e < 4; ++e) pf.w[e] = va_cvt_pk(s[s2 * 8 + 2 * e], s[s2 * 8 + 2 * e + 1]);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           // A = V^T: row = channel t*32 + col, keys kt + 16 s2 + 4 hb + {0..3} and + 8 + {0..3}
@@ -132,6 +157,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const u16 *__restrict__ q
       }
     }
   }
+  __syncthreads();  // every wave is done with the K / V chunk before it becomes the output buffer
   if (!active) return;
   // ---- normalise, transpose through LDS, store token rows
   const float inv = 1.f / l_run;
