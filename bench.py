@@ -3,8 +3,8 @@
     python bench.py --gpus N --steps K --warmup W [--batch 32] [--img 224] [--dtype bf16|fp32]
 
 A "step" is one UNOPose.forward over a batch of B synthetic (query,ref) pairs already resident in HBM
-(BASELINE configs[1]: batch 32, 2048 query points, 5000->2048 reference points, 224x224 crops; the
-518x518 stress shape with --img 518).  N>1: one process per GPU (torchrun / RCCL), each rank owns its
+(BASELINE configs[1]: batch 32, 2048 query points, 5000->2048 reference points, 518x518 crops; the
+reference's own 224x224 contract with --img 224).  N>1: one process per GPU (torchrun / RCCL), each rank owns its
 own B pairs (the ref-target list shards embarrassingly: weak scaling), weights are broadcast from rank 0
 once, poses are gathered to rank 0 at the end of the timed region.
 Prints ONE JSON line on rank 0.
@@ -28,7 +28,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--img", type=int, default=518,
+                    help="crop side: 518 = BASELINE configs[1] / north_star (default); 224 = the reference's own contract")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (same GPU time: "
                     "the step is GPU-bound, not launch-bound, at every batch size measured)")

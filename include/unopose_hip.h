@@ -239,6 +239,12 @@ int unopose_add_layernorm(const void *a, int a_bf16, const void *b, int b_bf16, 
 int unopose_bilinear_sample(const void *z, int z_bf16, const long long *choose, int B, int side, int Np,
                             int H, int W, float *out, unopose_stream_t stream);
 
+/* x (rows,C) float32 += gamma * y (bfloat16) in place AND out (bfloat16) = LayerNorm(x) * w + bias: the
+ * LayerScale residual of one timm ViT branch fused with the LayerNorm that opens the next one. */
+int unopose_scale_residual_layernorm(float *x, const void *y_bf16, const float *gamma, const float *w,
+                                     const float *bias, long rows, int C, float eps, void *out_bf16,
+                                     unopose_stream_t stream);
+
 /* x (rows,C) float32 += gamma (C) * y (rows,C) bfloat16, in place: the LayerScale residual of a
  * timm ViT block (x = x + ls(branch(x))). */
 int unopose_scale_residual(float *x, const void *y_bf16, const float *gamma, long rows, int C,

@@ -66,6 +66,65 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const void *__restri
   }
 }
 
+// x[r,:] += gamma * y[r,:] (fp32 residual stream, in place) AND out[r,:] = LayerNorm(x[r,:]) (bf16):
+// the LayerScale residual of one ViT branch fused with the LayerNorm that opens the next branch, so the
+// residual stream is read once instead of twice.  One wavefront per row, C <= 1024.
+__global__ __launch_bounds__(256) void scale_residual_layernorm_kernel(float *__restrict__ x, const u16 *__restrict__ y,
+                                                                       const float *__restrict__ gamma,
+                                                                       const float *__restrict__ w,
+                                                                       const float *__restrict__ bias, long rows,
+                                                                       int C, float eps, u16 *__restrict__ out) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // 4 channels per lane per step: 16-byte / 8-byte accesses
+    const int c = (i * 64 + lane) * 4;
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+      xv = *reinterpret_cast<const float4 *>(x + (size_t)r * C + c);
+      const uint2 yv = *reinterpret_cast<const uint2 *>(y + (size_t)r * C + c);
+      const float4 g = *reinterpret_cast<const float4 *>(gamma + c);
+      xv.x += g.x * fu_bf2f((u16)(yv.x & 0xFFFF));
+      xv.y += g.y * fu_bf2f((u16)(yv.x >> 16));
+      xv.z += g.z * fu_bf2f((u16)(yv.y & 0xFFFF));
+      xv.w += g.w * fu_bf2f((u16)(yv.y >> 16));
+      *reinterpret_cast<float4 *>(x + (size_t)r * C + c) = xv;
+    }
+    v[i * 4 + 0] = xv.x; v[i * 4 + 1] = xv.y; v[i * 4 + 2] = xv.z; v[i * 4 + 3] = xv.w;
+    s += (xv.x + xv.y) + (xv.z + xv.w);
+  }
+  const float mean = wave_sum_f32(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i * 4 + e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum_f32(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+      const float4 wv = *reinterpret_cast<const float4 *>(w + c), bv = *reinterpret_cast<const float4 *>(bias + c);
+      uint2 o;
+      o.x = (uint32_t)fu_f2bf((v[i * 4 + 0] - mean) * rstd * wv.x + bv.x) |
+            ((uint32_t)fu_f2bf((v[i * 4 + 1] - mean) * rstd * wv.y + bv.y) << 16);
+      o.y = (uint32_t)fu_f2bf((v[i * 4 + 2] - mean) * rstd * wv.z + bv.z) |
+            ((uint32_t)fu_f2bf((v[i * 4 + 3] - mean) * rstd * wv.w + bv.w) << 16);
+      *reinterpret_cast<uint2 *>(out + (size_t)r * C + c) = o;
+    }
+  }
+}
+
 // x[r,:] += gamma[:] * y[r,:]   (x fp32 in place, y bf16)  -- LayerScale residual of a ViT block
 __global__ __launch_bounds__(256) void scale_residual_kernel(float *__restrict__ x, const u16 *__restrict__ y,
                                                              const float *__restrict__ gamma, long n4, int C) {
@@ -179,6 +238,16 @@ int unopose_bilinear_sample(const void *z, int z_bf16, const long long *choose, 
     hipLaunchKernelGGL(bilinear_sample_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, choose, side, Np, H,
                        W, out);
   return check_launch("bilinear_sample");
+}
+
+int unopose_scale_residual_layernorm(float *x, const void *y_bf16, const float *gamma, const float *w, const float *bias,
+                                     long rows, int C, float eps, void *out_bf16, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(x && y_bf16 && gamma && w && bias && out_bf16, "scale_residual_layernorm: null pointer");
+  UNOPOSE_REQUIRE(rows >= 0 && C >= 4 && C % 4 == 0 && C <= 1024, "scale_residual_layernorm: C must be a multiple of 4, <= 1024");
+  if (rows == 0) return UNOPOSE_OK;
+  hipLaunchKernelGGL(scale_residual_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, x, (const u16 *)y_bf16, gamma, w, bias, rows, C, eps, (u16 *)out_bf16);
+  return check_launch("scale_residual_layernorm");
 }
 
 int unopose_scale_residual(float *x, const void *y_bf16, const float *gamma, long rows, int C,

@@ -56,6 +56,18 @@ class _Block(nn.Module):
         self.mlp = _Mlp(dim)
         self.ls2 = _LayerScale(dim)
 
+    def forward_fused(self, x, n1, next_norm):
+        """autocast path with the residual stream read once per branch: `n1` = norm1(x) (bf16) is handed
+        in by the previous block, and this block returns norm(x_out) for the next consumer (`next_norm`:
+        the next block's norm1, or None at the end)."""
+        y = self.attn(n1)
+        n2 = ops.scale_residual_layernorm_(x, y, self.ls1.gamma, self.norm2)
+        y = self.mlp(n2)
+        if next_norm is None:
+            ops.scale_residual_(x, y, self.ls2.gamma)
+            return x, None
+        return x, ops.scale_residual_layernorm_(x, y, self.ls2.gamma, next_norm)
+
     def forward(self, x):
         if torch.is_autocast_enabled() and x.dtype == torch.float32 and x.is_cuda:
             # fused glue (csrc/fused.hip): LayerNorm -> bf16 in one pass, LayerScale residual in one pass;
@@ -105,6 +117,16 @@ class ViT(nn.Module):
         n = self.depth // 4
         taps = {self.depth - 1, self.depth - n - 1, self.depth - 2 * n - 1, self.depth - 3 * n - 1}
         outs = []
+        if x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32 and x.shape[-1] % 4 == 0:
+            # fused glue: each block's LayerScale residual also produces the next LayerNorm (csrc/fused.hip)
+            x = x.contiguous()
+            n1 = ops.add_layernorm(x, None, self.blocks[0].norm1, torch.bfloat16)
+            for i, blk in enumerate(self.blocks):
+                nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None
+                x, n1 = blk.forward_fused(x, n1, nxt)
+                if i in taps:
+                    outs.append(ops.add_layernorm(x, None, self.norm))
+            return outs
         for i, blk in enumerate(self.blocks):
             x = blk(x)
             if i in taps:

@@ -705,3 +705,15 @@ def transformer_tail(h, x, layer):
         call("unopose_transformer_tail", ptr(h), ptr(x), rows, ptr(wl), ptr(bl), ptr(l1w), ptr(l1b), ptr(we), ptr(be),
              ptr(ws), ptr(bs), ptr(l2w), ptr(l2b), float(a.norm.eps), ptr(out), stream_ptr())
     return out
+
+
+def scale_residual_layernorm_(x, y, gamma, norm):
+    """x (fp32) += gamma * y (bf16) in place; returns LayerNorm(x) in bf16 -- one pass over the residual stream."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and y.dtype == torch.bfloat16
+    y = _c(y)
+    C = x.shape[-1]
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        call("unopose_scale_residual_layernorm", ptr(x), ptr(y), ptr(gamma), ptr(norm.weight), ptr(norm.bias),
+             x.numel() // C, C, float(norm.eps), ptr(out), stream_ptr())
+    return out
