@@ -27,7 +27,12 @@ __device__ __forceinline__ u16 va_f2bf(float f) {
 
 constexpr int VA_CHUNK = 128;            // keys staged per LDS chunk
 constexpr int VA_LDK = 64 + 8;           // padded row of the K chunk  [key][channel]
-constexpr int VA_LDV = VA_CHUNK + 8;     // padded row of the V^T chunk [channel][key]
+// V chunk image: 4 sub-tiles [128 keys][16 channels] (row = 32 B), sub-tile stride 4224 B.  Read with the
+// gfx950 transpose read ds_read_b64_tr_b16: a 16-lane group fetches a [4 keys][16 channels] block (128
+// contiguous bytes = 32 banks) and lane c receives the 4 keys of channel c -- the A fragment of V^T
+// without ever transposing V in LDS.  Lanes 16-31 read the next sub-tile, 4224 B = 32 banks further on.
+constexpr int VA_VSUB = 128 * 16 + 64;   // u16 per sub-tile (4096 B + 128 B bank skew)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // qkv: (B, T, 3, H, 64) bf16 (the fused qkv Linear output); out: (B, T, H*64) bf16.
 // The 4 waves of a workgroup share one (image, head): K and V of a 128-key chunk are loaded once with
@@ -39,147 +44,259 @@ __device__ __forceinline__ uint32_t va_cvt_pk(float a, float b) {  // packed RNE
   return r;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void vit_attn_kernel(const u16 *__restrict__ qkv, int T, int H, float scale_log2e,
-                                                       u16 *__restrict__ out) {
-  // K chunk [key][ch] + V^T chunk [ch][key]; the same bytes serve as the output transpose buffer at the end
-  __shared__ __attribute__((aligned(16))) u16 smem[VA_CHUNK * VA_LDK + 64 * VA_LDV];
-  u16 (*Ks)[VA_LDK] = reinterpret_cast<u16 (*)[VA_LDK]>(smem);
-  u16 (*Vs)[VA_LDV] = reinterpret_cast<u16 (*)[VA_LDV]>(smem + VA_CHUNK * VA_LDK);
+constexpr int VA_BUF = VA_CHUNK * VA_LDK + 4 * VA_VSUB;  // u16 per chunk buffer (K rows + V sub-tiles)
+
+// QB = 32-query blocks per wave (a workgroup owns 128 QB queries of one (image, head)); NBUF = LDS chunk
+// buffers.  QB = 2 reads every K / V fragment once for two independent score tiles -- half the LDS traffic
+// per MFMA and two dependency chains per wave for the scheduler to interleave (QK^T of one block under
+// the softmax VALU work of the other); it takes ~2x the registers, so it runs 2 waves/SIMD with a
+// double-buffered chunk (one barrier per chunk).  QB = 1 keeps short sequences (T = 261) from wasting
+// half-empty workgroups.
+// Workgroup -> (image, head, query block): the linear id is dealt round-robin over the 8 XCDs by the
+// dispatcher, so id%8 picks the XCD and all query blocks of one (image, head) are given the same id%8:
+// its K / V are then fetched into ONE XCD's L2 instead of every L2.
+template <int QB, int NBUF, bool PIPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 1 ? 3 : 2, QB == 1 ? 4 : 2))) void vit_attn_kernel(const u16 *__restrict__ qkv, int T, int H, int BH, int nq,
+                                                       float scale_log2e, u16 *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16 (*Ot)[32][72] = reinterpret_cast<u16 (*)[32][72]>(smem);
-  static_assert(4 * 32 * 72 <= VA_CHUNK * VA_LDK + 64 * VA_LDV, "output staging must fit the chunk buffers");
-  const int b = blockIdx.z, h = blockIdx.y;
+  static_assert(4 * 32 * 72 <= VA_BUF, "output staging must fit one chunk buffer");
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bh = (slot / nq) * 8 + xcd, qblk = slot % nq;
+  if (bh >= BH) return;
+  const int b = bh / H, h = bh % H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int q0 = (qblk * 4 + wave) * (32 * QB);
   const bool active = q0 < T;  // inactive waves still help staging and hit every barrier
   const int col = lane & 31, hb = lane >> 5;
   const int C3 = 3 * H * 64;
   const u16 *base = qkv + (size_t)b * T * C3;
-  bf16x8 qf[4];
-  {
-    const int tq = min(q0 + col, T - 1);
+  bf16x8 qf[QB][4];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int tq = min(q0 + qb * 32 + col, T - 1);
     const u16 *qp = base + (size_t)tq * C3 + h * 64 + hb * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qp + ks * 16);
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8 *>(qp + ks * 16);
   }
-  f32x16 o[2];
+  // Pin the Q loads as complete HERE: otherwise the compiler waits for them with vmcnt(0) at their first
+  // use inside the tile loop, which also drains the K / V chunk prefetch issued in the meantime.
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[qb][ks]));
+  f32x16 o[QB][2];
   // running max in the exp2 domain (score * scale * log2 e) and running sum
-  float m_run = -3e38f, l_run = 0.f;
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -3e38f;
+    l_run[qb] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qb][t][r] = 0.f;
+  }
 
-  // register-staged prefetch of a chunk: 128 keys x 128 B of K and of V, 8 lanes per key row (coalesced)
-  uint4 pk[4], pv[4];
+  // register-staged prefetch of a chunk: 128 keys x 128 B of K and of V.
+  //   K: 8 lanes per key row (contiguous 128 B; the 16-byte LDS stores of 8 lanes cover all 32 banks)
+  //   V: 8 lanes = 4 keys x the two 16-byte halves of one 16-channel sub-tile row (same property)
+  // (named registers, not arrays: an array captured by the lambdas below ends up in scratch)
+  uint4 pk0, pk1, pk2, pk3, pv0, pv1, pv2, pv3;
+#define VA_LOAD(i, PK, PV)                                                                                       \
+  {                                                                                                              \
+    const int e = tid + i * 256, key = e >> 3, c8 = e & 7;                                                       \
+    PK = *reinterpret_cast<const uint4 *>(base + (size_t)min(c0 + key, T - 1) * C3 + H * 64 + h * 64 + c8 * 8);  \
+    const int vkey = (e >> 5) * 4 + ((e >> 1) & 3), vc = ((e >> 3) & 3) * 16 + (e & 1) * 8;                      \
+    PV = *reinterpret_cast<const uint4 *>(base + (size_t)min(c0 + vkey, T - 1) * C3 + 2 * H * 64 + h * 64 + vc); \
+  }
+#define VA_STORE(i, PK, PV)                                                                  \
+  {                                                                                          \
+    const int e = tid + i * 256, key = e >> 3, c8 = e & 7;                                   \
+    *reinterpret_cast<uint4 *>(buf + key * VA_LDK + c8 * 8) = PK;                            \
+    const int vkey = (e >> 5) * 4 + ((e >> 1) & 3);                                          \
+    /* keys beyond T contribute V = 0 (their P is 0 as well) */                              \
+    *reinterpret_cast<uint4 *>(buf + VA_CHUNK * VA_LDK + ((e >> 3) & 3) * VA_VSUB + vkey * 16 + (e & 1) * 8) = \
+        c0 + vkey < T ? PV : make_uint4(0u, 0u, 0u, 0u);                                     \
+  }
   auto chunk_load = [&](int c0) {
+    VA_LOAD(0, pk0, pv0) VA_LOAD(1, pk1, pv1) VA_LOAD(2, pk2, pv2) VA_LOAD(3, pk3, pv3)
+  };
+  auto chunk_store = [&](int c0, u16 *buf) {
+    VA_STORE(0, pk0, pv0) VA_STORE(1, pk1, pv1) VA_STORE(2, pk2, pv2) VA_STORE(3, pk3, pv3)
+  };
+#undef VA_LOAD
+#undef VA_STORE
+  // this lane's slot in the transpose read: sub-tile (lane>>4)&1, key row 4 hb + ((lane&15)>>2), 8-byte chunk lane&3
+  const int vlane_off = VA_CHUNK * VA_LDK + ((lane >> 4) & 1) * VA_VSUB + (4 * hb + ((lane & 15) >> 2)) * 16 + (lane & 3) * 4;
+
+  // ---- pieces of one 32-key tile ------------------------------------------------------------------
+  // S^T = K Q^T: rows = 32 keys, cols = 32 queries, for every query block of the wave
+  auto qk_tile = [&](const u16 *buf, int kt, f32x16 (&s)[QB]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256, key = e >> 3, c8 = e & 7;
-      const u16 *src = base + (size_t)min(c0 + key, T - 1) * C3 + h * 64 + c8 * 8;
-      pk[i] = *reinterpret_cast<const uint4 *>(src + H * 64);
-      pv[i] = *reinterpret_cast<const uint4 *>(src + 2 * H * 64);
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[qb][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(buf + (kt + col) * VA_LDK + ks * 16 + hb * 8);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], s[qb], 0, 0, 0);
     }
   };
-  auto chunk_store = [&](int c0) {
+  // running-max update for all query blocks; the accumulators are rescaled only when some query's max
+  // moved (one wave-uniform branch per tile, rare after the first few tiles)
+  auto tile_max = [&](const f32x16 (&s)[QB]) {
+    float m_new[QB];
+    bool moved = false;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256, key = e >> 3, c8 = e & 7;
-      *reinterpret_cast<uint4 *>(&Ks[key][c8 * 8]) = pk[i];
-      union { uint4 v; u16 u[8]; } vv;
-      vv.v = pv[i];
-      const bool valid = c0 + key < T;  // keys beyond T contribute V = 0 (their P is 0 as well)
+    for (int qb = 0; qb < QB; ++qb) {
+      float mx = s[qb][0];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) Vs[c8 * 8 + j][key] = valid ? vv.u[j] : (u16)0;
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qb][r]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * scale_log2e;  // scale > 0: max commutes with it
+      m_new[qb] = fmaxf(m_run[qb], mx);
+      moved |= m_new[qb] > m_run[qb];
     }
-  };
-  chunk_load(0);
-  for (int c0 = 0; c0 < T; c0 += VA_CHUNK) {
-    __syncthreads();  // previous chunk fully consumed
-    chunk_store(c0);
-    if (c0 + VA_CHUNK < T) chunk_load(c0 + VA_CHUNK);  // in flight under this chunk's MFMAs
-    __syncthreads();
-    if (!active) continue;
-    const int nk = min(VA_CHUNK, T - c0);
-    for (int kt = 0; kt < nk; kt += 32) {
-      const int k0 = c0 + kt;
-      // ---- S^T tile: rows = 32 keys, cols = 32 queries
-      f32x16 s;
+    if (__any(moved)) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(&Ks[kt + col][ks * 16 + hb * 8]);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-      }
-      if (k0 + 32 > T) {  // only the last tile can hold keys >= T (wave-uniform branch)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hb >= T) s[r] = -3e38f;
-      }
-      // ---- online softmax for this lane's query over its 16 keys (+ the other half-wave's 16)
-      float mx = s[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;  // scale > 0: max commutes with it
-      const float m_new = fmaxf(m_run, mx);
-      float ls = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_new));
-        ls += s[r];
-      }
-      ls += __shfl_xor(ls, 32);
-      if (__any(m_new > m_run)) {  // rescale the accumulators only when some query's max moved
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
+      for (int qb = 0; qb < QB; ++qb) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new[qb]);
+        l_run[qb] *= alpha;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-        m_run = m_new;
+          for (int r = 0; r < 16; ++r) o[qb][t][r] *= alpha;
+        m_run[qb] = m_new[qb];
       }
-      l_run += ls;
-      // ---- O^T += V^T P^T ; k-step s2 = accumulator registers 8*s2 .. 8*s2+7 (permuted key order)
+    }
+  };
+  // P = exp2(S * scale - m), row sums, and O^T += V^T P^T.  k-step s2 of the P.V product = accumulator
+  // registers 8*s2 .. 8*s2+7 of S (a fixed permuted key order that the V fragment reads follow)
+  auto pv_tile = [&](const u16 *buf, int kt, f32x16 (&s)[QB]) {
+    const u16 *vlane = buf + vlane_off;
+    union PF { bf16x8 v; uint32_t w[4]; } pf[QB][2];
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        union { bf16x8 v; uint32_t w[4]; } pf;
+    for (int qb = 0; qb < QB; ++qb) {
+      float ls = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pf.w[e] = va_cvt_pk(s[s2 * 8 + 2 * e], s[s2 * 8 + 2 * e + 1]);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          // A = V^T: row = channel t*32 + col, keys kt + 16 s2 + 4 hb + {0..3} and + 8 + {0..3}
-          const u16 *vp = &Vs[t * 32 + col][kt + s2 * 16 + 4 * hb];
-          union { bf16x8 v; bf16x4 h4[2]; } vf;
-          vf.h4[0] = *reinterpret_cast<const bf16x4 *>(vp);
-          vf.h4[1] = *reinterpret_cast<const bf16x4 *>(vp + 8);
-          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[t], 0, 0, 0);
-        }
+      for (int r = 0; r < 16; ++r) {
+        s[qb][r] = __builtin_amdgcn_exp2f(fmaf(s[qb][r], scale_log2e, -m_run[qb]));
+        ls += s[qb][r];
       }
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
+      l_run[qb] += __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf[qb][s2].w[e] = va_cvt_pk(s[qb][s2 * 8 + 2 * e], s[qb][s2 * 8 + 2 * e + 1]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        // A = V^T: row = channel t*32 + col, keys kt + 16 s2 + 4 hb + {0..3} and + 8 + {0..3}
+        const u16 *vp = vlane + t * 2 * VA_VSUB + (kt + s2 * 16) * 16;
+        union { bf16x8 v; s16x4 h4[2]; } vf;
+        vf.h4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp));
+        vf.h4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp + 8 * 16));
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+          o[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf[qb][s2].v, o[qb][t], 0, 0, 0);
+      }
+    }
+  };
+
+  auto chunk_compute = [&](int c0, const u16 *buf) {
+    const int nk = min(VA_CHUNK, T - c0);
+    if (PIPE && nk == VA_CHUNK) {
+      // full chunk, software-pipelined: the score MFMAs of tile i+1 are issued in the same basic block as
+      // the exp / sum / convert VALU work of tile i, so the matrix core runs under the softmax
+      f32x16 sa[QB], sb[QB];
+      qk_tile(buf, 0, sa);
+      tile_max(sa);
+      qk_tile(buf, 32, sb);
+      pv_tile(buf, 0, sa);
+      tile_max(sb);
+      qk_tile(buf, 64, sa);
+      pv_tile(buf, 32, sb);
+      tile_max(sa);
+      qk_tile(buf, 96, sb);
+      pv_tile(buf, 64, sa);
+      tile_max(sb);
+      pv_tile(buf, 96, sb);
+      return;
+    }
+    for (int kt = 0; kt < nk; kt += 32) {
+      const int k0 = c0 + kt;
+      f32x16 s[QB];
+      qk_tile(buf, kt, s);
+      if (k0 + 32 > T) {  // only the last tile can hold keys >= T (wave-uniform branch)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hb >= T) s[qb][r] = -3e38f;
+      }
+      tile_max(s);
+      pv_tile(buf, kt, s);
+    }
+  };
+
+  const int nchunks = (T + VA_CHUNK - 1) / VA_CHUNK;
+  if (NBUF == 1) {
+    chunk_load(0);
+    for (int c = 0; c < nchunks; ++c) {
+      __syncthreads();  // previous chunk fully consumed
+      chunk_store(c * VA_CHUNK, smem);
+      if (c + 1 < nchunks) chunk_load((c + 1) * VA_CHUNK);  // in flight under this chunk's MFMAs
+      __syncthreads();
+      if (active) chunk_compute(c * VA_CHUNK, smem);
+    }
+  } else {
+    chunk_load(0);
+    chunk_store(0, smem);
+    if (nchunks > 1) chunk_load(VA_CHUNK);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+      if (active) chunk_compute(c * VA_CHUNK, smem + (c & 1) * VA_BUF);
+      if (c + 1 < nchunks) {  // the other buffer was last read before the previous barrier
+        chunk_store((c + 1) * VA_CHUNK, smem + ((c + 1) & 1) * VA_BUF);
+        if (c + 2 < nchunks) chunk_load((c + 2) * VA_CHUNK);
+      }
+      __syncthreads();
     }
   }
-  __syncthreads();  // every wave is done with the K / V chunk before it becomes the output buffer
+  __syncthreads();  // every wave is done with the K / V chunks before they become the output buffer
   if (!active) return;
   // ---- normalise, transpose through LDS, store token rows
-  const float inv = 1.f / l_run;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int qb = 0; qb < QB; ++qb) {
+    const float inv = 1.f / l_run[qb];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
-      Ot[wave][col][c] = va_f2bf(o[t][r] * inv);
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+        Ot[wave][col][c] = va_f2bf(o[qb][t][r] * inv);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // 32 rows x 128 B: each lane moves 16 B; 8 lanes cover one row
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3), seg = lane & 7;
+      const int tq = q0 + qb * 32 + row;
+      if (tq < T) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(&Ot[wave][row][seg * 8]);
+        *reinterpret_cast<uint4 *>(out + ((size_t)b * T + tq) * (H * 64) + h * 64 + seg * 8) = v;
+      }
     }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // 32 rows x 128 B: each lane moves 16 B; 8 lanes cover one row
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int row = it * 8 + (lane >> 3), seg = lane & 7;
-    const int tq = q0 + row;
-    if (tq < T) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(&Ot[wave][row][seg * 8]);
-      *reinterpret_cast<uint4 *>(out + ((size_t)b * T + tq) * (H * 64) + h * 64 + seg * 8) = v;
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -187,17 +304,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 
 using namespace unopose;
 
+template <int QB, int NBUF, bool PIPE>
+static int launch_vit_attn(const void *qkv, int B, int T, int H, void *out, hipStream_t stream) {
+  static bool attr_set = false;  // > 64 KiB of LDS needs the opt-in (idempotent; benign if raced)
+  const size_t lds = (size_t)NBUF * VA_BUF * sizeof(u16);
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vit_attn_kernel<QB, NBUF, PIPE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("vit_attention: cannot reserve %zu bytes of LDS", lds);
+      return UNOPOSE_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int BH = B * H, nq = cdiv(T, 128 * QB);
+  const float scale_log2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+  const long blocks = (long)cdiv(BH, 8) * nq * 8;
+  hipLaunchKernelGGL((vit_attn_kernel<QB, NBUF, PIPE>), dim3((unsigned)blocks), dim3(256), lds, stream, (const u16 *)qkv, T,
+                     H, BH, nq, scale_log2e, (u16 *)out);
+  return check_launch("vit_attention");
+}
+
 extern "C" {
 
 int unopose_vit_attention(const void *qkv, int B, int T, int H, void *out, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(qkv && out, "vit_attention: null pointer");
-  UNOPOSE_REQUIRE(B >= 0 && T >= 1 && H >= 1 && B <= 65535 && H <= 65535, "vit_attention: bad sizes");
+  UNOPOSE_REQUIRE(B >= 0 && T >= 1 && H >= 1 && (long)B * H * cdiv(T, 128) < (1L << 31), "vit_attention: bad sizes");
   if (B == 0) return UNOPOSE_OK;
-  const float scale_log2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
-  dim3 grid(cdiv(T, 128), H, B);
-  hipLaunchKernelGGL(vit_attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)qkv, T, H, scale_log2e,
-                     (u16 *)out);
-  return check_launch("vit_attention");
+  if (T >= 512) return launch_vit_attn<2, 2, false>(qkv, B, T, H, out, (hipStream_t)stream);
+  return launch_vit_attn<1, 1, false>(qkv, B, T, H, out, (hipStream_t)stream);
 }
 
 }  // extern "C"
