@@ -54,10 +54,11 @@ def hip_event_time(fn, iters, stream):
     return s.elapsed_time(e) * 1e-3 / iters
 
 
-def roofline_leg(model, batch):
-    """Roofline of the dominant hand-written kernel of the step (the S=256 launch of the fused
-    positional-encoding kernel), timed live with HIP events on the stream it runs on, plus the other rows
-    BASELINE's north star prices.  Work models: DESIGN.md section 4."""
+def roofline_leg(model, batch, img):
+    """Roofline of the dominant hand-written kernel of the step, timed live with HIP events on the stream
+    it runs on: the ViT patch attention at 518x518 crops (12 launches = the largest share of the step
+    after the library GEMMs), the fused positional-encoding kernel (S=256 launch) at 224x224.  The other
+    rows BASELINE's north star prices follow in `roofline_other`.  Work models: DESIGN.md section 4."""
     from unopose_amd import ops
     from unopose_amd.pointnet2 import _ext
 
@@ -79,7 +80,14 @@ def roofline_leg(model, batch):
         rows.append(r)
         return r
 
-    # dominant: PE, S=256, bf16 hi/lo-split matrix cores; 20864 flop per neighbour row
+    # ViT patch attention: 4 T^2 64 flop per (image, head), 2B images x 12 heads, T = 5 + (img/14)^2 tokens
+    T = 5 + (img // 14) ** 2
+    qkv = torch.randn(2 * B, T, 2304, device=x.device).bfloat16()
+    t = hip_event_time(lambda: ops.vit_attention(qkv, 12), 10, stream)
+    vit = row("vit_attn_kernel(T=%d)" % T, "mfma", 2.0 * B * 12 * 4.0 * T * T * 64, 1e12, 2500.0, "TFLOP/s", t,
+              "QK^T + PV flops; softmax exp/sum VALU work shares the issue port with the matrix core")
+    del qkv
+    # PE, S=256, bf16 hi/lo-split matrix cores; 20864 flop per neighbour row
     t = hip_event_time(lambda: ops.pe_group_mlp_max(x, pe.r2, pe.ns2, pe.mlp2, bf16x3=True), 10, stream)
     dom = row("pe_group_mlp_max_bf16x3_kernel(S=%d)" % pe.ns2, "mfma", B * N * pe.ns2 * 20864.0, 1e12, 2500.0,
               "TFLOP/s", t, "algorithmic fp32-equivalent flops; the kernel issues 3 bf16 MFMAs per product")
@@ -101,10 +109,14 @@ def roofline_leg(model, batch):
     tem = batch["tem1_pts"].float().contiguous()
     t = hip_event_time(lambda: _ext.furthest_point_sampling(tem, 2048), 3, stream)
     rows.append(dict(kernel="fps_kernel(5000->2048)", bound="latency", us=t * 1e6, us_per_iteration=t * 1e6 / 2047))
+    if img >= 448:  # 12 attention launches outweigh the 2 PE launches once T^2 grows
+        dom, key = vit, "vit_attn_kernel"
+    else:
+        key = "pe_group_mlp_max_bf16x3_kernel"
+    traffic = _pmc_traffic(key, B) if (key != "vit_attn_kernel" or T == 1374) else None
     out = dict(roofline=dict(bound=dom["bound"], kernel=dom["kernel"], achieved=dom["achieved"], peak=dom["peak"],
-                             unit=dom["unit"], frac=dom["frac"], traffic=_pmc_traffic("pe_group_mlp_max_bf16x3_kernel", B),
-                             note=dom["note"]),
-               roofline_other=rows[1:])
+                             unit=dom["unit"], frac=dom["frac"], traffic=traffic, note=dom["note"]),
+               roofline_other=[r for r in rows if r is not dom])
     return out
 
 
@@ -228,7 +240,7 @@ def main():
     }
     if rank == 0 and world == 1:
         if not args.no_roofline:
-            res.update(roofline_leg(model, batch))
+            res.update(roofline_leg(model, batch, args.img))
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_leg(args.img)
     if rank == 0:

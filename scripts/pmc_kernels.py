@@ -32,5 +32,9 @@ for _ in range(3):
     f = torch.randn(B, n, 256, device=dev)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         ops.token_attention(f, f, model.coarse_point_matching.transformers[0].layers[0].attention.attention, 4, E)
+# the ViT patch attention at the 518x518 token count (2B images x 1374 tokens x 12 heads)
+qkv = torch.randn(2 * B, 1374, 2304, device=dev).bfloat16()
+for _ in range(3):
+    ops.vit_attention(qkv, 12)
 torch.cuda.synchronize()
 print("done")
