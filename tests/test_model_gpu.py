@@ -431,6 +431,34 @@ def test_forward_variants(tamed):
 
 
 @torch.no_grad()
+def test_reference_cache_equals_uncached_forward(tamed):
+    """`encode_reference` + the runner's ReferenceCache give the uncached forward's poses
+    (the reference view's FPS subset, features, radius and LRF depend on that view alone)."""
+    from unopose_amd.runner import ReferenceCache, run_image
+
+    z = load("forward_full")
+    model = tamed[2048]
+    ep = {k: z[k] for k in ("pts", "tem1_pts", "rgb", "tem1_rgb", "rgb_choose", "tem1_choose")}
+    ep["coarse_rand"] = z["rand"]
+    full = model(dict(ep))
+    enc = model.encode_reference(ep["tem1_rgb"], ep["tem1_choose"], ep["tem1_pts"])
+    ep2 = {k: ep[k] for k in ("pts", "rgb", "rgb_choose", "coarse_rand")}
+    ep2.update(enc)
+    cached = model(ep2)
+    assert err(cached["pred_R"], full["pred_R"]) < 1e-4 and err(cached["pred_t"], full["pred_t"]) < 1e-4
+    assert err(cached["init_R"], full["init_R"]) < 1e-4
+    # runner level: 3 instances of one image sharing ONE reference view -> one encode, two hits
+    data = {k: torch.cat([v] * 3, 0)[None] for k, v in ep.items() if k != "coarse_rand"}
+    data["score"] = torch.ones(1, 3, 1).cuda()
+    data["ref_keys"] = [(48, 1, 5)] * 3
+    cache = ReferenceCache(model)
+    Rs, ts, _ = run_image(model, data, instance_batch_size=2, ref_cache=cache)
+    assert (cache.misses, cache.hits) == (1, 2)
+    Ru, tu, _ = run_image(model, data, instance_batch_size=2)
+    assert np.abs(Rs - Ru).max() < 1e-2 and np.abs(ts - tu).max() < 1.0  # coarse draw differs per call (torch.rand)
+
+
+@torch.no_grad()
 def test_unsupported_shapes_fall_back_to_gpu_composites(model):
     """Shapes the fused kernels are not built for run the op-by-op GPU composites (never a CPU path)."""
     from unopose_amd import ops

@@ -126,6 +126,10 @@ class UNOPose(nn.Module):
             dense_pm = dense_pm / (radius.reshape(-1, 1, 1) + 1e-6)
             dense_po = dense_po / (radius.reshape(-1, 1, 1) + 1e-6)
             return dense_pm, dense_fm, dense_po, dense_fo, radius
+        if "ref_dense_po" in end_points:  # encode_reference() output: same numbers as the full path below
+            radius = end_points["ref_radius"]
+            dense_pm = dense_pm / (radius.reshape(-1, 1, 1) + 1e-6)
+            return dense_pm, net.pixel_features(rgb, choose), end_points["ref_dense_po"], end_points["ref_dense_fo"], radius
         tem_rgb, tem_choose, tem_pts = end_points["tem1_rgb"], end_points["tem1_choose"], end_points["tem1_pts"]
         radius = torch.norm(tem_pts - tem_pts.mean(1, keepdim=True), dim=2).max(1)[0]
         dense_pm = dense_pm / (radius.reshape(-1, 1, 1) + 1e-6)
@@ -150,6 +154,23 @@ class UNOPose(nn.Module):
         dense_fo = ops.bilinear_sample_native(z[B:], sel_choose, H, W)
         return dense_pm, dense_fm, dense_po, dense_fo, radius
 
+    @torch.no_grad()
+    def encode_reference(self, tem1_rgb, tem1_choose, tem1_pts):
+        """Everything `forward` derives from the reference view ALONE: the FPS-2048 subset
+        of the radius-normalised cloud, its pixel features, the radius, and the LRF-frame coordinates of
+        the FULL cloud (M:30).  Feeding the returned dict back through `end_points` skips the reference
+        crop's ViT pass, the 5000->2048 FPS and the reference LRF; unlike the reference's own
+        `dense_po`/`dense_fo` shortcut (F:252-263, which re-derives the radius from the subset) the
+        results equal the uncached forward."""
+        radius = torch.norm(tem1_pts - tem1_pts.mean(1, keepdim=True), dim=2).max(1)[0]
+        tem_n = tem1_pts / (radius.reshape(-1, 1, 1) + 1e-6)
+        idx_o = ops.furthest_point_sample(tem_n, self.fine_npoint)
+        sel_choose = torch.gather(tem1_choose, 1, idx_o.long())
+        net = self.feature_extraction.rgb_net
+        z, (H, W) = net.upprojected(tem1_rgb)
+        return dict(ref_dense_po=ops.gather_rows(tem_n, idx_o), ref_dense_fo=ops.bilinear_sample_native(z, sel_choose, H, W),
+                    ref_radius=radius, ref_lrf=ops.lrf_global(tem1_pts, self.use_ref_rad))
+
     def _side_stream(self, device):
         s = getattr(self, "_side", None)
         if s is None or s.device != device:
@@ -169,8 +190,11 @@ class UNOPose(nn.Module):
         dense_pm_lrf = ops.lrf_global(end_points["pts"], self.use_ref_rad)
         # NB (App-E.1): LRF of the FULL tem1 cloud (5000 rows) gathered below with indices into the
         # FPS-2048 subset, exactly as the reference does (M:30, U:167-171).
-        dense_po_lrf = ops.lrf_global(end_points["tem1_pts"], self.use_ref_rad) if "tem1_pts" in end_points \
-            else ops.lrf_global(end_points["dense_po"], self.use_ref_rad)
+        if "ref_lrf" in end_points:
+            dense_po_lrf = end_points["ref_lrf"]
+        else:
+            dense_po_lrf = ops.lrf_global(end_points["tem1_pts"], self.use_ref_rad) if "tem1_pts" in end_points \
+                else ops.lrf_global(end_points["dense_po"], self.use_ref_rad)
         B = dense_pm.size(0)
         bg_point = torch.ones(B, 1, 3, device=dense_pm.device)
         sparse_pm, sparse_pm_lrf, sparse_fm, fps_idx_m = self._sample_wlrf(dense_pm, dense_pm_lrf, dense_fm,

@@ -47,11 +47,41 @@ def csv_line(scene_id, img_id, obj_id, score, R9, t3_mm, image_time):
 
 
 _INPUT_KEYS = ("pts", "rgb", "rgb_choose", "fps_idx_m", "tem1_rgb", "tem1_choose", "tem1_pts", "fps_idx_o")
+_REF_KEYS = ("ref_dense_po", "ref_dense_fo", "ref_radius", "ref_lrf")
+
+
+class ReferenceCache:
+    """Per-reference-view features kept across images: BOP test sets pair many
+    query instances with few reference views, and everything `UNOPose.encode_reference` returns depends
+    on the reference view alone.  Keys are whatever identifies a view to the caller (e.g.
+    ``(ref_scene_id, ref_im_id, obj_id)``); entries live on the model's device, oldest evicted first."""
+
+    def __init__(self, model, max_items=256):
+        self.model, self.max_items, self.store = model, max_items, {}
+        self.hits = self.misses = 0
+
+    def lookup(self, keys, tem1_rgb, tem1_choose, tem1_pts):
+        miss = [i for i, k in enumerate(keys) if k not in self.store]
+        first = {}
+        for i in miss:
+            first.setdefault(keys[i], i)  # one encode per distinct missing view
+        if first:
+            sel = torch.as_tensor(list(first.values()), device=tem1_pts.device)
+            enc = self.model.encode_reference(tem1_rgb[sel], tem1_choose[sel], tem1_pts[sel])
+            for j, k in enumerate(first):
+                self.store[k] = {name: v[j] for name, v in enc.items()}
+            while len(self.store) > max(self.max_items, len(set(keys))):
+                self.store.pop(next(iter(self.store)))
+        self.misses += len(first)
+        self.hits += len(keys) - len(first)
+        return {name: torch.stack([self.store[k][name] for k in keys]) for name in _REF_KEYS}
 
 
 @torch.no_grad()
-def run_image(model, data, instance_batch_size=16, device=None):
-    """One image = data[key] with a leading image dim of 1 and n_instance instances (:36-100)."""
+def run_image(model, data, instance_batch_size=16, device=None, ref_cache=None):
+    """One image = data[key] with a leading image dim of 1 and n_instance instances (:36-100).
+    With `ref_cache` (a ReferenceCache) and `data["ref_keys"]` (one hashable per instance) the reference
+    side of every pair comes from the cache."""
     if device is not None:
         data = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in data.items()}
     n = data["pts"].size(1)
@@ -59,6 +89,9 @@ def run_image(model, data, instance_batch_size=16, device=None):
     for s in range(0, n, instance_batch_size):
         e = min(n, s + instance_batch_size)
         inputs = {k: data[k][0][s:e].contiguous() for k in _INPUT_KEYS if k in data}
+        if ref_cache is not None and "ref_keys" in data:
+            inputs.update(ref_cache.lookup(list(data["ref_keys"][s:e]), inputs["tem1_rgb"], inputs["tem1_choose"],
+                                           inputs["tem1_pts"]))
         out = model(inputs)
         R, t = compose_pose(out["pred_R"], out["pred_t"],
                             data["tem1_pose"][0][s:e].contiguous() if "tem1_pose" in data else None)
@@ -71,7 +104,7 @@ def run_image(model, data, instance_batch_size=16, device=None):
     return Rs, ts, scores
 
 
-def inference_and_save(model, images, save_path, instance_batch_size=16, device=None, sync=None):
+def inference_and_save(model, images, save_path, instance_batch_size=16, device=None, sync=None, ref_cache=None):
     """`images`: an indexable of per-image dicts (the reference's test dataset items, batch dim 1).
     Every rank processes its InferenceSampler shard; rows are gathered to rank 0, which writes the CSV
     (and the detections JSON) in global image order.  Returns the rows on rank 0, None elsewhere."""
@@ -83,7 +116,7 @@ def inference_and_save(model, images, save_path, instance_batch_size=16, device=
         if sync is not None:
             sync()
         t0 = time.perf_counter()
-        Rs, ts, scores = run_image(model, data, instance_batch_size, device)
+        Rs, ts, scores = run_image(model, data, instance_batch_size, device, ref_cache)
         if sync is not None:
             sync()
         image_time = time.perf_counter() - t0 + float(data["seg_time"]) if "seg_time" in data else \
