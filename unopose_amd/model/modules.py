@@ -260,7 +260,7 @@ class _AttentionOutput(nn.Module):
         self.norm = nn.LayerNorm(d)
 
     def forward(self, x):
-        y = ops.linear(F.relu(ops.linear(x, self.expand)), self.squeeze)
+        y = ops.linear(ops.linear(x, self.expand, relu=True), self.squeeze)
         if x.is_cuda:
             return ops.add_layernorm(x, y, self.norm)  # one pass (csrc/fused.hip); bf16 out under autocast
         return self.norm(x + y)

@@ -67,12 +67,13 @@ import torch.nn.functional as F
 from .pointnet2 import _ext
 
 
-def linear(x, lin):
+def linear(x, lin, relu=False):
     """nn.Linear under autocast without the per-call weight cast: bf16 copies of (weight, bias) are cached
     on the module (keyed by the parameter version) and the GEMM is issued directly in bf16.  Outside
-    autocast this is just `lin(x)`."""
+    autocast this is just `lin(x)`.  `relu=True` asks for relu(lin(x)); on the bf16 path the ReLU rides in
+    the GEMM epilogue (hipBLASLt RELU_BIAS through torch._addmm_activation) instead of a separate pass."""
     if not (torch.is_autocast_enabled() and x.is_cuda):
-        return lin(x)
+        return F.relu(lin(x)) if relu else lin(x)
     key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.device)
     cache = getattr(lin, "_bf16_cache", None)
     if cache is None or cache[0] != key:
@@ -81,7 +82,12 @@ def linear(x, lin):
                      None if lin.bias is None else lin.bias.detach().to(torch.bfloat16).contiguous())
         lin._bf16_cache = cache
     with torch.autocast("cuda", enabled=False):
-        return F.linear(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), cache[1], cache[2])
+        xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+        if relu and cache[2] is not None:
+            x2 = xb.reshape(-1, xb.shape[-1])
+            return torch._addmm_activation(cache[2], x2, cache[1].t()).reshape(*xb.shape[:-1], cache[1].shape[0])
+        y = F.linear(xb, cache[1], cache[2])
+        return F.relu(y) if relu else y
 
 
 def gather_rows(feats, idx):
