@@ -154,6 +154,44 @@ def test_forward_end_to_end_golden(tamed, tag, n):
 
 
 @torch.no_grad()
+def test_forward_518_crops_vs_oracle_and_ground_truth():
+    """BASELINE configs[1] crop side (518x518: T = 1374 tokens, 37x37 patch grid -- a shape the reference
+    itself cannot run, F:62-63, so the checker is the oracle restatement): fp32 refined pose within 1e-4 of
+    the oracle on one pair; the autocast(bf16) forward (the benched configuration: 64-query-per-wave flash
+    attention, fused LayerScale/LayerNorm glue) solves a batch of congruent pairs."""
+    from oracle import unopose_ref as R
+    from oracle.pointnet2_oracle import ext as oext
+    from unopose_amd.model import UNOPose, default_model_cfg
+    from unopose_amd.synthetic import congruent_pair, make_batch
+
+    g = torch.Generator().manual_seed(2)
+    ep, R_gt, t_gt = congruent_pair(g, 2048, 5000, 518, 5e-4)
+    cfg = R.default_cfg()
+    sd = R.random_state_dict(cfg, seed=0, img_size=518, tame=0.1)
+    rand = torch.rand(1, 18000, generator=g)
+    ref = R.unopose_forward(ep, sd, cfg, rand, oext)
+    model = UNOPose(default_model_cfg(feature_extraction=dict(img_size=518)))
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    inp = {k: v.cuda() for k, v in ep.items()}
+    inp["coarse_rand"] = rand.cuda()
+    out = model(inp)
+    for k in ("pred_R", "pred_t"):
+        assert err(out[k].cpu(), ref[k]) < 1e-4, (k, err(out[k].cpu(), ref[k]))
+    # The coarse pose is the arg-max over 6000 sampled hypotheses: at T = 1374 the fp32 ViT features of the
+    # two implementations differ by ~1e-5 relative (summation order over 12 layers), which moves a few CDF
+    # look-ups and can change WHICH good hypothesis wins; both must be good, the refined pose must agree.
+    assert err(out["init_R"][0].cpu(), R_gt) < 6e-2 and err(ref["init_R"][0], R_gt) < 6e-2
+    assert err(out["pred_R"][0].cpu(), R_gt) < 5e-3
+    batch, Rg, tg = make_batch(4, 2048, 5000, 518, seed=21, device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ob = model(batch)
+    rot_err = (ob["pred_R"] - Rg).abs().amax(dim=(1, 2))
+    assert (rot_err < 5e-2).all(), rot_err
+    assert ((ob["pred_t"] - tg).abs().amax(dim=1) < 2e-2).all()
+
+
+@torch.no_grad()
 def test_geo_embedding_kernel_full_size_fp32_and_bf16(model):
     """Fused HIP embedding vs the op-by-op torch composite at n = 197 (196 coarse points + bg), both
     precisions: fp32 output / hi-lo split operands (tolerance 1e-4 off the diagonal) and the

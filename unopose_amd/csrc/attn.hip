@@ -55,12 +55,13 @@ constexpr int TA_MP = TA_NT * 16;  // padded key count (V^T and the P staging us
 // RW = query rows per wavefront (4 fills the 16-row MFMA tile; 2 doubles the number of wavefronts that
 // stream E concurrently -- the kernel is bound by HBM latency x occupancy, not by the matrix pipe)
 template <bool RPE, int RW>
-__global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__ q, int ldq,
+__global__ __launch_bounds__(256, 2) void token_attn_kernel(const u16 *__restrict__ q, int ldq,
                                                          const u16 *__restrict__ k, int ldk,
                                                          const u16 *__restrict__ vt, const u16 *__restrict__ qp,
                                                          int ldqp, const u16 *__restrict__ E, int n, int m,
                                                          float scale, u16 *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) u16 Pl[4][16][TA_MP];
+  __shared__ __attribute__((aligned(16))) u16 Al[RPE ? 4 : 1][8][64][8];  // RPE: A fragments of the current query row
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = (blockIdx.x * 4 + wave) * RW;  // first of this wave's RW query rows
   if (n0 >= n) return;
@@ -74,18 +75,32 @@ __global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__
 #pragma unroll
   for (int t = 0; t < TA_NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- q k^T: block-diagonal A (row (n_l,h) only sees head h's 64 channels), B = K
+  // ---- q k^T: block-diagonal A (row (n_l,h) only sees head h's 64 channels), B = K.
+  // K is L2-resident but every fragment load still costs an L2 round trip: the 14 key-tile loads of
+  // k-step ks+1 are all issued before the 14 MFMAs of k-step ks (double-buffered), not one by one.
+  {
+    bf16x8 qa[8];
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    const int kk = ks * 32 + kg * 8;
-    bf16x8 a = zero8();
-    if (a_valid && (kk >> 6) == a_h) a = *reinterpret_cast<const bf16x8 *>(Q + kk);
+    for (int ks = 0; ks < 8; ++ks) {
+      const int kk = ks * 32 + kg * 8;
+      qa[ks] = zero8();
+      if (a_valid && (kk >> 6) == a_h) qa[ks] = *reinterpret_cast<const bf16x8 *>(Q + kk);
+    }
+    bf16x8 kb[2][TA_NT];
+    auto load_k = [&](int ks, bf16x8 (&dst)[TA_NT]) {
 #pragma unroll
-    for (int t = 0; t < TA_NT; ++t) {
-      const int mm = t * 16 + li;
-      bf16x8 bv = zero8();
-      if (mm < m) bv = *reinterpret_cast<const bf16x8 *>(K + (size_t)mm * ldk + kk);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bv, acc[t], 0, 0, 0);
+      for (int t = 0; t < TA_NT; ++t) {
+        // keys >= m read the last key's row instead of branching per load: their scores are masked below
+        const int mm = min(t * 16 + li, m - 1);
+        dst[t] = *reinterpret_cast<const bf16x8 *>(K + (size_t)mm * ldk + ks * 32 + kg * 8);
+      }
+    };
+    load_k(0, kb[0]);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) load_k(ks + 1, kb[(ks + 1) & 1]);
+#pragma unroll
+      for (int t = 0; t < TA_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kb[ks & 1][t], acc[t], 0, 0, 0);
     }
   }
   // ---- RPE term: for each of the 4 query rows, (q W_p)[n] . E[n,m,:]
@@ -94,34 +109,35 @@ __global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__
       if (n0 + nl >= n) break;  // wave-uniform
       const u16 *QP = qp + ((size_t)b * n + n0 + nl) * ldqp + a_h * 256;
       const u16 *En = E + ((size_t)b * n + n0 + nl) * (size_t)m * 256;
-      bf16x8 a[8];
+      // this query row's folded (q W_p) fragments live in LDS (8 KiB per wave), not in 32 VGPRs: the
+      // registers buy a second E tile in flight instead (the kernel is bound by HBM latency x bytes in
+      // flight: 2 waves/SIMD x 16 KiB each)
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        a[ks] = zero8();
-        if (a_nl == nl) a[ks] = *reinterpret_cast<const bf16x8 *>(QP + ks * 32 + kg * 8);
+        bf16x8 av = zero8();
+        if (a_nl == nl) av = *reinterpret_cast<const bf16x8 *>(QP + ks * 32 + kg * 8);
+        *reinterpret_cast<bf16x8 *>(&Al[wave][ks][lane][0]) = av;
       }
-      // software-pipelined over key tiles: the 8 fragment loads (8 KiB per wave) of tile t+1 are in
-      // flight while the 8 MFMAs of tile t issue -- E is the only HBM-sized stream of this kernel
+      // software-pipelined over key tiles, two tiles (2 x 8 KiB per wave) ahead of the MFMAs -- E is the
+      // only HBM-sized stream of this kernel
       const int nt_valid = (m + 15) >> 4;
-      bf16x8 cur[8], nxt[8];
-      {
-        const u16 *Er = En + (size_t)min(li, m - 1) * 256 + kg * 8;
+      bf16x8 buf[3][8];
+      auto load_tile = [&](int t, bf16x8 (&dst)[8]) {
+        const u16 *Er = En + (size_t)min(t * 16 + li, m - 1) * 256 + kg * 8;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) cur[ks] = *reinterpret_cast<const bf16x8 *>(Er + ks * 32);
-      }
+        for (int ks = 0; ks < 8; ++ks) dst[ks] = *reinterpret_cast<const bf16x8 *>(Er + ks * 32);
+      };
+      load_tile(0, buf[0]);
+      if (1 < nt_valid) load_tile(1, buf[1]);
 #pragma unroll
       for (int t = 0; t < TA_NT; ++t) {
         if (t >= nt_valid) continue;  // uniform: tile entirely beyond the keys
-        if (t + 1 < nt_valid) {
-          const u16 *Er = En + (size_t)min((t + 1) * 16 + li, m - 1) * 256 + kg * 8;
+        if (t + 2 < nt_valid) load_tile(t + 2, buf[(t + 2) % 3]);
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks) nxt[ks] = *reinterpret_cast<const bf16x8 *>(Er + ks * 32);
+        for (int ks = 0; ks < 8; ++ks) {
+          const bf16x8 av = *reinterpret_cast<const bf16x8 *>(&Al[wave][ks][lane][0]);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, buf[t % 3][ks], acc[t], 0, 0, 0);
         }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], cur[ks], acc[t], 0, 0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) cur[ks] = nxt[ks];
       }
     }
   }
@@ -168,15 +184,20 @@ __global__ __launch_bounds__(256) void token_attn_kernel(const u16 *__restrict__
   for (int ks = 0; ks < TA_MP / 32; ++ks)
     pa[ks] = *reinterpret_cast<const bf16x8 *>(&Pl[wave][li][ks * 32 + kg * 8]);
   const u16 *VT = vt + (size_t)b * 256 * TA_MP;
-#pragma unroll
-  for (int nt = 0; nt < 16; ++nt) {
-    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int PK = TA_MP / 32;
+  bf16x8 vb[2][PK];
+  auto load_v = [&](int nt, bf16x8 (&dst)[PK]) {
     const u16 *Vr = VT + (size_t)(nt * 16 + li) * TA_MP + kg * 8;
 #pragma unroll
-    for (int ks = 0; ks < TA_MP / 32; ++ks) {
-      const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(Vr + ks * 32);
-      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[ks], bv, o, 0, 0, 0);
-    }
+    for (int ks = 0; ks < PK; ++ks) dst[ks] = *reinterpret_cast<const bf16x8 *>(Vr + ks * 32);
+  };
+  load_v(0, vb[0]);
+#pragma unroll
+  for (int nt = 0; nt < 16; ++nt) {
+    if (nt + 1 < 16) load_v(nt + 1, vb[(nt + 1) & 1]);  // next channel tile's V^T fragments in flight
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < PK; ++ks) o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[ks], vb[nt & 1][ks], o, 0, 0, 0);
     // D row = (query row kg, head reg); channel tile nt belongs to head nt >> 2
     if (kg < RW && n0 + kg < n) out[((size_t)b * n + n0 + kg) * 256 + nt * 16 + li] = f2bf_rn(o[nt >> 2]);
   }
