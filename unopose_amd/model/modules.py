@@ -311,6 +311,16 @@ class GeometricTransformer(nn.Module):
         f1 = self.layers[1](f1, f0)
         return f0, f1
 
+    def forward_stacked(self, f, e_all):
+        """Both clouds as one (2B, n, C) batch (cloud 0 = first half) with their embeddings stacked the
+        same way; returns (f0, f1)."""
+        B = f.shape[0] // 2
+        f = self.layers[0](f, None, e_all)
+        f0, f1 = f[:B], f[B:]
+        f0 = self.layers[1](f0, f1)
+        f1 = self.layers[1](f1, f0)
+        return f0, f1
+
 
 def _adjacent(e0, e1):
     """(2B,...) view over e0 | e1 when they are contiguous halves of one allocation, else None."""
@@ -383,6 +393,18 @@ class SparseToDenseTransformer(nn.Module):
             n0 = self.dense_layer(d0[:, 1:], f0[:, 1:])
             n1 = self.dense_layer(d1[:, 1:], f1[:, 1:])
         return torch.cat([f0[:, 0:1], n0], 1), torch.cat([f1[:, 0:1], n1], 1)
+
+    def forward_stacked(self, dense, bg, e_all, idx_all):
+        """Same block with the two clouds stacked as one batch of 2B and the background token kept BESIDE
+        the dense features -- dense (2B,N,C) contiguous, bg (2B,1,C) -- so that no (B,N+1,C) tensor is
+        re-assembled per block (the reference's layout costs two 134 MB concatenations per block at B=32).
+        Returns the new (dense, bg)."""
+        # T:655-662 with App-E.2's off-by-one: index i addresses row i of [bg | dense], i.e. bg for i == 0
+        g = ops.gather_rows(dense, (idx_all - 1).clamp(min=0))
+        g = torch.where((idx_all == 0).unsqueeze(-1), bg.to(g.dtype), g)
+        f0, f1 = self.sparse_layer.forward_stacked(torch.cat([bg.to(g.dtype), g], 1), e_all)
+        new = self.dense_layer(dense, torch.cat([f0[:, 1:], f1[:, 1:]], 0))
+        return new, torch.cat([f0[:, 0:1], f1[:, 0:1]], 0)
 
 
 # -------------------------------------------------------------- PE ----------

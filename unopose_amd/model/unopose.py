@@ -8,7 +8,7 @@ import torch.nn as nn
 from .. import ops
 from .config import to_cfg
 from .modules import (GeometricStructureEmbedding, GeometricTransformer, PositionalEncoding,
-                      SparseToDenseTransformer, ViTEncoderOneRef)
+                      SparseToDenseTransformer, ViTEncoderOneRef, _adjacent)
 
 
 def _scores(scores, n1):
@@ -77,20 +77,38 @@ class FinePointMatchingOneRef(nn.Module):
             p1_ = (p1 - end_points["init_t"].unsqueeze(1)) @ end_points["init_R"]
         else:
             p1_ = p1
-        if p1_.shape == p2.shape:  # both clouds through the fused PE kernels as one batch of 2B
+        e_all, f_all = _adjacent(geo1, geo2), _adjacent(f1, f2)
+        if p1_.shape == p2.shape and p1.is_cuda and e_all is not None and fps_idx1.shape == fps_idx2.shape:
+            # both clouds as ONE batch of 2B through PE, in_proj and the three blocks; the background token
+            # rides beside the dense features and is put in front only once, at the end
             pe = self.PE(torch.cat([p1_, p2], 0))
-            pe1, pe2 = pe[:B], pe[B:]
+            d = ops.linear(f_all if f_all is not None else torch.cat([f1, f2], 0), self.in_proj)
+            d = d + pe.to(d.dtype)
+            bg = self.bg_token.expand(2 * B, -1, -1).to(d.dtype)
+            idx_all = torch.cat([fps_idx1, fps_idx2], 0).long()
+            for blk in self.transformers:
+                d, bg = blk.forward_stacked(d, bg, e_all, idx_all)
+            f = torch.cat([bg, d], dim=1)
+            f1, f2 = f[:B], f[B:]
+            sc = self.score_heads[self.nblock - 1](f)
+            scores = torch.cat((sc[:B], sc[B:]), dim=1)
+            o = ops.linear(f, self.out_proj)
+            atten = ops.feature_similarity(o[:B], o[B:], self.cfg.temp)
         else:
-            pe1, pe2 = self.PE(p1_), self.PE(p2)
-        f1 = ops.linear(f1, self.in_proj) + pe1.to(f1.dtype)
-        f2 = ops.linear(f2, self.in_proj) + pe2.to(f2.dtype)
-        bg = self.bg_token.expand(B, -1, -1).to(f1.dtype)
-        f1 = torch.cat([bg, f1], dim=1)
-        f2 = torch.cat([bg, f2], dim=1)
-        for blk in self.transformers:
-            f1, f2 = blk(f1, geo1, fps_idx1, f2, geo2, fps_idx2)
-        scores = self.score_heads[self.nblock - 1](torch.cat((f1, f2), dim=1))
-        atten = ops.feature_similarity(ops.linear(f1, self.out_proj), ops.linear(f2, self.out_proj), self.cfg.temp)
+            if p1_.shape == p2.shape:  # both clouds through the fused PE kernels as one batch of 2B
+                pe = self.PE(torch.cat([p1_, p2], 0))
+                pe1, pe2 = pe[:B], pe[B:]
+            else:
+                pe1, pe2 = self.PE(p1_), self.PE(p2)
+            f1 = ops.linear(f1, self.in_proj) + pe1.to(f1.dtype)
+            f2 = ops.linear(f2, self.in_proj) + pe2.to(f2.dtype)
+            bg = self.bg_token.expand(B, -1, -1).to(f1.dtype)
+            f1 = torch.cat([bg, f1], dim=1)
+            f2 = torch.cat([bg, f2], dim=1)
+            for blk in self.transformers:
+                f1, f2 = blk(f1, geo1, fps_idx1, f2, geo2, fps_idx2)
+            scores = self.score_heads[self.nblock - 1](torch.cat((f1, f2), dim=1))
+            atten = ops.feature_similarity(ops.linear(f1, self.out_proj), ops.linear(f2, self.out_proj), self.cfg.temp)
         score = _scores(scores, n1)
         R, t, s = ops.fine_pose(atten, score, p1, p2)
         end_points["pred_R"] = R
@@ -148,10 +166,13 @@ class UNOPose(nn.Module):
         # both crops through the ViT as ONE batch of 2B images
         B = rgb.shape[0]
         z, (H, W) = net.upprojected(torch.cat([rgb, tem_rgb], 0))
-        dense_fm = ops.bilinear_sample_native(z[:B], choose, H, W)
+        # query | reference features land in ONE (2B,N,256) buffer: the fine matcher takes them stacked
+        both = torch.empty(2 * B, choose.shape[1], 256, dtype=torch.float32, device=z.device) \
+            if sel_choose.shape == choose.shape else None
+        dense_fm = ops.bilinear_sample_native(z[:B], choose, H, W, out=None if both is None else both[:B])
         main.wait_stream(side)
         # only the FPS-selected reference pixels are ever interpolated (gather commutes with sampling)
-        dense_fo = ops.bilinear_sample_native(z[B:], sel_choose, H, W)
+        dense_fo = ops.bilinear_sample_native(z[B:], sel_choose, H, W, out=None if both is None else both[B:])
         return dense_pm, dense_fm, dense_po, dense_fo, radius
 
     @torch.no_grad()

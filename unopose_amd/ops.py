@@ -127,15 +127,18 @@ def vit_attention_torch(qkv, heads):
     return a.transpose(1, 2).reshape(B, T, C)
 
 
-def bilinear_sample_native(z, choose, H, W):
+def bilinear_sample_native(z, choose, H, W, out=None):
     """Fused HIP version of bilinear_sample_pixels on the up-projection output in its NATIVE order
-    z (B, side, side, 4, 4, 256) (no permute copy): (B,Np) int64 pixel indices -> (B,Np,256) fp32."""
+    z (B, side, side, 4, 4, 256) (no permute copy): (B,Np) int64 pixel indices -> (B,Np,256) fp32
+    (written into `out` when given: a contiguous fp32 (B,Np,256) view)."""
     z = _c(z)
     assert z.shape[-1] == 256 and z.shape[3] == 4 and z.shape[4] == 4 and z.dtype in (torch.float32, torch.bfloat16)
     B, side = z.shape[0], z.shape[1]
     choose = _c(choose.long())
     Np = choose.shape[1]
-    out = torch.empty(B, Np, 256, dtype=torch.float32, device=z.device)
+    if out is None:
+        out = torch.empty(B, Np, 256, dtype=torch.float32, device=z.device)
+    assert out.shape == (B, Np, 256) and out.dtype == torch.float32 and out.is_contiguous()
     with torch.cuda.device(z.device):
         call("unopose_bilinear_sample", ptr(z), int(z.dtype == torch.bfloat16), ptr(choose), B, side, Np, int(H), int(W),
              ptr(out), stream_ptr())
