@@ -2,6 +2,8 @@
 core/unopose/model/oneref_grf_predator_pose_estimation_model.py:11-76 (M), with
 C = oneref_predator_coarse_point_matching.py, Fi = oneref_predator_fine_point_matching.py,
 F = oneref_feature_extraction.py, U = utils/model_utils.py.  Inference only (eval branch)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -9,6 +11,9 @@ from .. import ops
 from .config import to_cfg
 from .modules import (GeometricStructureEmbedding, GeometricTransformer, PositionalEncoding,
                       SparseToDenseTransformer, ViTEncoderOneRef, _adjacent)
+
+
+STACKED_FINE = os.environ.get("UNOPOSE_STACKED_FINE", "1") == "1"  # A/B switch for the 2B-stacked fine matcher
 
 
 def _scores(scores, n1):
@@ -78,7 +83,8 @@ class FinePointMatchingOneRef(nn.Module):
         else:
             p1_ = p1
         e_all, f_all = _adjacent(geo1, geo2), _adjacent(f1, f2)
-        if p1_.shape == p2.shape and p1.is_cuda and e_all is not None and fps_idx1.shape == fps_idx2.shape:
+        if (STACKED_FINE and p1_.shape == p2.shape and p1.is_cuda and e_all is not None
+                and fps_idx1.shape == fps_idx2.shape):
             # both clouds as ONE batch of 2B through PE, in_proj and the three blocks; the background token
             # rides beside the dense features and is put in front only once, at the end
             pe = self.PE(torch.cat([p1_, p2], 0))
