@@ -520,8 +520,15 @@ def furthest_point_sample(pts, npoint):
 
 
 def feature_similarity(f1, f2, temp):
-    """compute_feature_similarity, cosine + normalize (model_utils.py:260-282)."""
-    return (F.normalize(f1.float(), p=2, dim=2) @ F.normalize(f2.float(), p=2, dim=2).transpose(1, 2)) / temp
+    """compute_feature_similarity, cosine + normalize (model_utils.py:260-282).
+    Under autocast on the GPU the bf16 GEMM writes its fp32 accumulators straight out (`out_dtype`) with
+    1/temp folded into the (small) left operand: one 4-byte write of the (B,N1,N2) matrix instead of a
+    bf16 write, a division pass and the fp32 cast the pose heads ask for (1.6 GB per step at B=32)."""
+    a, b = F.normalize(f1.float(), p=2, dim=2), F.normalize(f2.float(), p=2, dim=2)
+    if f1.is_cuda and torch.is_autocast_enabled():
+        with torch.autocast("cuda", enabled=False):
+            return torch.bmm((a / temp).to(torch.bfloat16), b.to(torch.bfloat16).transpose(1, 2), out_dtype=torch.float32)
+    return (a @ b.transpose(1, 2)) / temp
 
 
 def soft_assignment(atten, score1, score2):
