@@ -112,6 +112,43 @@ def test_three_nn_interpolate(hip_ext, oracle_ext):
                                oracle_ext.three_interpolate_grad(go, i_ref, w, 70), rtol=1e-4, atol=1e-4)
 
 
+def test_full_size_batch_properties(hip_ext, oracle_ext):
+    """BASELINE configs[1] sizes (32 clouds x 2048 points, nsample 256): properties that hold at any size.
+    ball_query rows are ascending up to the first repeat of the row's first index (the padding rule),
+    every listed neighbour is inside the radius, results do not depend on the batch composition;
+    group_points equals an index gather; one element is compared with the oracle bit for bit."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.stack([object_cloud(g, 2048) for _ in range(32)])
+    x = (x / x.norm(dim=2).amax(1).reshape(-1, 1, 1)).contiguous()
+    xd = _dev(x)
+    idx = hip_ext.ball_query(xd, xd, 0.2, 256)
+    assert idx.shape == (32, 2048, 256) and idx.dtype == torch.int32
+    assert torch.equal(idx[5:6], hip_ext.ball_query(xd[5:6].contiguous(), xd[5:6].contiguous(), 0.2, 256))
+    assert torch.equal(idx[7].cpu(), oracle_ext.ball_query(x[7:8], x[7:8], 0.2, 256)[0])
+    li = idx.long()
+    nb = torch.gather(xd.unsqueeze(1).expand(-1, 2048, -1, -1), 2, li.unsqueeze(-1).expand(-1, -1, -1, 3))
+    d2 = ((nb - xd.unsqueeze(2)) ** 2).sum(-1)
+    assert (d2 < 0.2 * 0.2 + 1e-7).all()
+    pad = li == li[:, :, :1]  # padding repeats the first hit
+    inc = li[:, :, 1:] > li[:, :, :-1]
+    assert (inc | pad[:, :, 1:]).all()
+    xt = xd.transpose(1, 2).contiguous()
+    grp = hip_ext.group_points(xt, idx)
+    assert torch.equal(grp, nb.permute(0, 3, 1, 2))
+    fps = hip_ext.furthest_point_sampling(xd, 196)
+    assert torch.equal(fps[11:12], hip_ext.furthest_point_sampling(xd[11:12].contiguous(), 196))
+
+
+def test_empty_batch(hip_ext):
+    """B = 0 (an image whose detections were all rejected): every operator returns an empty tensor."""
+    z = torch.zeros(0, 64, 3).cuda()
+    assert hip_ext.furthest_point_sampling(z, 8).shape == (0, 8)
+    assert hip_ext.ball_query(z, z, 0.1, 4).shape == (0, 64, 4)
+    f = torch.zeros(0, 5, 64).cuda()
+    assert hip_ext.gather_points(f, torch.zeros(0, 8, dtype=torch.int32).cuda()).shape == (0, 5, 8)
+    assert hip_ext.group_points(f, torch.zeros(0, 8, 4, dtype=torch.int32).cuda()).shape == (0, 5, 8, 4)
+
+
 def test_reference_error_behaviour(hip_ext):
     x = torch.randn(1, 10, 3)
     with pytest.raises(RuntimeError, match="CPU not supported"):

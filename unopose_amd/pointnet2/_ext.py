@@ -18,6 +18,8 @@ def furthest_point_sampling(points, nsamples):
     check_f32(points, "points")
     B, N, _ = points.shape
     out = torch.zeros(B, nsamples, dtype=torch.int32, device=points.device)
+    if out.numel() == 0:  # empty batch: nothing to launch
+        return out
     with torch.cuda.device(points.device):
         call("unopose_furthest_point_sampling", ptr(points), B, N, int(nsamples), ptr(out), stream_ptr())
     return out
@@ -29,6 +31,8 @@ def gather_points(points, idx):
     B, C, N = points.shape
     M = idx.shape[1]
     out = torch.empty(B, C, M, dtype=torch.float32, device=points.device)
+    if out.numel() == 0:  # empty batch: nothing to launch
+        return out
     with torch.cuda.device(points.device):
         call("unopose_gather_points", ptr(points), ptr(idx), B, C, N, M, ptr(out), stream_ptr())
     return out
@@ -39,6 +43,8 @@ def gather_points_grad(grad_out, idx, n):
     check_i32(idx, "idx")
     B, C, M = grad_out.shape
     out = torch.zeros(B, C, int(n), dtype=torch.float32, device=grad_out.device)
+    if out.numel() == 0:  # empty batch: nothing to launch
+        return out
     with torch.cuda.device(grad_out.device):
         call("unopose_gather_points_grad", ptr(grad_out), ptr(idx), B, C, int(n), M, ptr(out), stream_ptr())
     return out
@@ -50,6 +56,8 @@ def ball_query(new_xyz, xyz, radius, nsample):
     B, M, _ = new_xyz.shape
     N = xyz.shape[1]
     idx = torch.empty(B, M, int(nsample), dtype=torch.int32, device=new_xyz.device)
+    if idx.numel() == 0:  # empty batch: nothing to launch
+        return idx
     with torch.cuda.device(new_xyz.device):
         call("unopose_ball_query", ptr(new_xyz), ptr(xyz), B, N, M, float(radius), int(nsample), ptr(idx),
              stream_ptr())
@@ -62,6 +70,8 @@ def group_points(points, idx):
     B, C, N = points.shape
     _, M, S = idx.shape
     out = torch.empty(B, C, M, S, dtype=torch.float32, device=points.device)
+    if out.numel() == 0:  # empty batch: nothing to launch
+        return out
     with torch.cuda.device(points.device):
         call("unopose_group_points", ptr(points), ptr(idx), B, C, N, M, S, ptr(out), stream_ptr())
     return out
@@ -72,6 +82,8 @@ def group_points_grad(grad_out, idx, n):
     check_i32(idx, "idx")
     B, C, M, S = grad_out.shape
     out = torch.zeros(B, C, int(n), dtype=torch.float32, device=grad_out.device)
+    if out.numel() == 0:  # empty batch: nothing to launch
+        return out
     with torch.cuda.device(grad_out.device):
         call("unopose_group_points_grad", ptr(grad_out), ptr(idx), B, C, int(n), M, S, ptr(out), stream_ptr())
     return out
@@ -84,6 +96,8 @@ def three_nn(unknowns, knows):
     m = knows.shape[1]
     dist2 = torch.zeros(B, n, 3, dtype=torch.float32, device=unknowns.device)
     idx = torch.zeros(B, n, 3, dtype=torch.int32, device=unknowns.device)
+    if dist2.numel() == 0:  # empty batch / no query points: nothing to launch
+        return [dist2, idx]
     with torch.cuda.device(unknowns.device):
         call("unopose_three_nn", ptr(unknowns), ptr(knows), B, n, m, ptr(dist2), ptr(idx), stream_ptr())
     return [dist2, idx]
@@ -96,6 +110,8 @@ def three_interpolate(points, idx, weight):
     B, c, m = points.shape
     n = idx.shape[1]
     out = torch.empty(B, c, n, dtype=torch.float32, device=points.device)
+    if out.numel() == 0:  # empty batch: nothing to launch
+        return out
     with torch.cuda.device(points.device):
         call("unopose_three_interpolate", ptr(points), ptr(idx), ptr(weight), B, c, m, n, ptr(out), stream_ptr())
     return out
@@ -107,6 +123,8 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     check_f32(weight, "weight")
     B, c, n = grad_out.shape
     out = torch.zeros(B, c, int(m), dtype=torch.float32, device=grad_out.device)
+    if out.numel() == 0:  # empty batch: nothing to launch
+        return out
     with torch.cuda.device(grad_out.device):
         call("unopose_three_interpolate_grad", ptr(grad_out), ptr(idx), ptr(weight), B, c, n, int(m), ptr(out),
              stream_ptr())
