@@ -5,7 +5,7 @@ here = os.path.dirname(os.path.abspath(__file__))
 T = 1374
 qkv = torch.randn(64, T, 2304, device="cuda").bfloat16()
 out = torch.empty(64, T, 768, device="cuda", dtype=torch.bfloat16)
-names = {0: "full", 1: "no exp", 2: "no PV MFMA", 3: "no S MFMA", 4: "no max, no rescale", 5: "max but never rescale", 6: "no chunk staging",
+names = {0: "full", 1: "no exp", 2: "no PV MFMA", 3: "no S MFMA", 4: "never move m, no fix-up", 5: "no fix-up block", 6: "no chunk staging",
          7: "no barriers", 8: "no LDS fragment reads"}
 for n, name in names.items():
     lib = ctypes.CDLL(os.path.join(here, f"vit_abl{n}.so"))

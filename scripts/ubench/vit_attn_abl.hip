@@ -160,94 +160,103 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
       }
     }
   };
-  // Running-max update for all query blocks with a DEFERRED rescale: the accumulators are rescaled only
-  // when some query's maximum grew by more than 2^VA_DEFER since its last rescale (one wave-uniform branch
-  // per tile).  Until then P = exp2(s - m_run) may reach 2^VA_DEFER instead of 1 -- harmless in the fp32
-  // accumulators, and bf16 rounds P with the same RELATIVE error at any magnitude; the quotient O / l does
-  // not depend on the reference point.  On unstructured scores the plain `max moved` test fires in ~80 % of
-  // the tiles (64 queries per wave) and the rescale was 1/3 of the kernel by ablation.
-  auto tile_max = [&](const f32x16 (&s)[QB]) {
-    if (ABL == 4) return;
-    float m_new[QB];
+  // Online softmax + P.V of one tile, written so that the COMMON path is one basic block from the score
+  // MFMAs to the P.V MFMAs (a wave-uniform rescale branch in the middle of the tile cost 1/3 of the kernel
+  // by ablation: it splits the block the scheduler interleaves MFMA, exp and VALU work in).
+  //  * Deferred reference point: a query's reference m_run moves only when its tile maximum exceeds it by
+  //    more than 2^VA_DEFER; until then P = exp2(s - m_run) may reach 2^VA_DEFER instead of 1 -- harmless in
+  //    the fp32 accumulators, bf16 rounds P with the same RELATIVE error at any magnitude, and O / l does not
+  //    depend on the reference point.  The choice is a per-lane select, not a branch.
+  //  * l is kept exact branch-free: l = l * alpha + sum(P) with alpha = exp2(m_old - m_new) (= 1 if unmoved).
+  //  * O is accumulated as if alpha were 1; if ANY query of the wave moved (first tile, then rare) a fix-up
+  //    at the END of the tile recomputes this tile's P.V into a scratch accumulator D and sets
+  //    O = (O - D) * alpha + D.  (O - D) is the old accumulator up to one rounding of the much larger new
+  //    terms, and it is scaled by alpha <= 2^-VA_DEFER (or by 0 on the first tile, where O - D is exactly 0).
+  auto softmax_pv_tile = [&](const u16 *buf, int kt, f32x16 (&s)[QB]) {
+    const u16 *vlane = buf + vlane_off;
+    union PF { bf16x8 v; uint32_t w[4]; } pf[QB][2];
+    float alpha[QB];
     bool moved = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       float mx = s[qb][0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qb][r]);
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * scale_log2e;  // scale > 0: max commutes with it
-      m_new[qb] = fmaxf(m_run[qb], mx);
-      moved |= mx > m_run[qb] + VA_DEFER;
-    }
-    if (ABL != 5 && __any(moved)) {
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new[qb]);
-        l_run[qb] *= alpha;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[qb][t][r] *= alpha;
-        m_run[qb] = m_new[qb];
-      }
-    }
-  };
-  // P = exp2(S * scale - m), row sums, and O^T += V^T P^T.  k-step s2 of the P.V product = accumulator
-  // registers 8*s2 .. 8*s2+7 of S (a fixed permuted key order that the V fragment reads follow)
-  auto pv_tile = [&](const u16 *buf, int kt, f32x16 (&s)[QB]) {
-    const u16 *vlane = buf + vlane_off;
-    union PF { bf16x8 v; uint32_t w[4]; } pf[QB][2];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
+      const auto sm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sm[0]), __uint_as_float(sm[1])) * scale_log2e;  // scale > 0: max commutes with it
+      const bool grow = (ABL != 4) && mx > m_run[qb] + VA_DEFER;
+      const float m_use = grow ? mx : m_run[qb];
+      alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
+      m_run[qb] = m_use;
+      moved |= grow;
       float ls = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[qb][r] = (ABL == 1) ? fmaf(s[qb][r], scale_log2e, -m_run[qb]) : __builtin_amdgcn_exp2f(fmaf(s[qb][r], scale_log2e, -m_run[qb]));
+        s[qb][r] = (ABL == 1) ? fmaf(s[qb][r], scale_log2e, -m_use) : __builtin_amdgcn_exp2f(fmaf(s[qb][r], scale_log2e, -m_use));
         ls += s[qb][r];
       }
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
-      l_run[qb] += __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      l_run[qb] = fmaf(l_run[qb], alpha[qb], __uint_as_float(sw[0]) + __uint_as_float(sw[1]));
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int e = 0; e < 4; ++e) pf[qb][s2].w[e] = va_cvt_pk(s[qb][s2 * 8 + 2 * e], s[qb][s2 * 8 + 2 * e + 1]);
     }
+    // ---- O^T += V^T P^T ; k-step s2 = accumulator registers 8*s2 .. 8*s2+7 of S (permuted key order that
+    // the V fragment reads follow); A = V^T: row = channel t*32 + col, keys kt + 16 s2 + 4 hb + {0..3}, + 8
+    auto v_frag = [&](int s2, int t) {
+      const u16 *vp = vlane + t * 2 * VA_VSUB + (kt + s2 * 16) * 16;
+      union { bf16x8 v; s16x4 h4[2]; } vf;
+      if (ABL == 8) return qf[0][t];
+      vf.h4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp));
+      vf.h4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp + 8 * 16));
+      return vf.v;
+    };
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        // A = V^T: row = channel t*32 + col, keys kt + 16 s2 + 4 hb + {0..3} and + 8 + {0..3}
-        const u16 *vp = vlane + t * 2 * VA_VSUB + (kt + s2 * 16) * 16;
-        union { bf16x8 v; s16x4 h4[2]; } vf;
-        if (ABL == 8) vf.v = qf[0][t];
-        else {
-        vf.h4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp));
-        vf.h4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp + 8 * 16));
-        }
+        const bf16x8 vf = v_frag(s2, t);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
-          if (ABL == 2) { o[qb][t][0] += (float)vf.v[0] + (float)pf[qb][s2].v[0]; }
-          else o[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf[qb][s2].v, o[qb][t], 0, 0, 0);
+          if (ABL == 2) { o[qb][t][0] += (float)vf[0] + (float)pf[qb][s2].v[0]; }
+          else o[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][s2].v, o[qb][t], 0, 0, 0);
+      }
+    if (ABL != 5 && ABL != 4 && __any(moved)) {  // rare after the first tile: re-reference the accumulators of the queries that moved
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 v0 = v_frag(0, t), v1 = v_frag(1, t);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          f32x16 d;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[r] = 0.f;
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[qb][0].v, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[qb][1].v, d, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[qb][t][r] = fmaf(o[qb][t][r] - d[r], alpha[qb], d[r]);
+        }
       }
     }
   };
 
   auto chunk_compute = [&](int c0, const u16 *buf) {
-    const int nk = min(VA_CHUNK, T - c0);
-    for (int kt = 0; kt < nk; kt += 32) {
-      const int k0 = c0 + kt;
+    const int nk = min(VA_CHUNK, T - c0);  // valid keys of this chunk
+    int kt = 0;
+    for (; kt + 32 <= nk; kt += 32) {  // full tiles: no masking, no branch between the MFMA groups
       f32x16 s[QB];
       qk_tile(buf, kt, s);
-      if (k0 + 32 > T) {  // only the last tile can hold keys >= T (wave-uniform branch)
+      softmax_pv_tile(buf, kt, s);
+    }
+    if (kt < nk) {  // the one partial tile of the sequence: keys >= T are masked out
+      f32x16 s[QB];
+      qk_tile(buf, kt, s);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
+      for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hb >= T) s[qb][r] = -3e38f;
-      }
-      tile_max(s);
-      pv_tile(buf, kt, s);
+        for (int r = 0; r < 16; ++r)
+          if (c0 + kt + (r & 3) + 8 * (r >> 2) + 4 * hb >= T) s[qb][r] = -3e38f;
+      softmax_pv_tile(buf, kt, s);
     }
   };
 

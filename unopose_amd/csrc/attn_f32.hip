@@ -13,9 +13,7 @@ namespace unopose {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ uint32_t af_cvt_pk(float a, float b) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+  return cvt_pk_bf16_f32(a, b);
 }
 struct HL {
   bf16x8 hi, lo;

@@ -33,6 +33,22 @@ inline int check_launch(const char *what) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Packed RNE fp32 -> bf16 (low half = a, high half = b): lowers to ONE v_cvt_pk_bf16_f32 on gfx950.
+// Deliberately the compiler's own vector conversion, not inline asm: the hazard recogniser does not look
+// inside asm statements, and an asm VALU op next to an in-flight MFMA on overlapping registers silently
+// corrupts results (found with a software-pipelined attention variant; scripts/ubench).
+typedef float unopose_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 unopose_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16_f32(float a, float b) {
+  const unopose_f32x2 v = {a, b};
+  union {
+    unopose_bf16x2 h;
+    uint32_t u;
+  } r;
+  r.h = __builtin_convertvector(v, unopose_bf16x2);
+  return r.u;
+}
+
 // ---- wave64 DPP reductions (gfx9 row_shr / row_bcast) ----------------------
 // dpp_ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
 template <int CTRL, int ROW_MASK>

@@ -28,9 +28,7 @@ __device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
 // gfx950 packed fp32 -> bf16 conversion (RNE): low half = cvt(a), high half = cvt(b)
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+  return cvt_pk_bf16_f32(a, b);
 }
 
 // sin and cos of |x| <~ 1e3 with ~1e-7 absolute error: 3-term Cody-Waite reduction by pi/2 + cephes

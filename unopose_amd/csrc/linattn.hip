@@ -36,7 +36,6 @@ __global__ __launch_bounds__(256) void linear_attn_kernel(const u16 *__restrict_
   const int t0 = (blockIdx.x * 4 + wave) * 32;
   if (t0 >= N) return;
   const int col = lane & 31, hb = lane >> 5;
-  const int tok = min(t0 + col, N - 1);
   {
     const u16 *src = x + ((size_t)b * N + t0) * 256;
     const int nrows = min(32, N - t0);

@@ -241,9 +241,7 @@ struct PeLdsB {
 
 // gfx950 packed fp32 -> bf16 conversion (RNE): low half = cvt(a), high half = cvt(b)
 __device__ __forceinline__ uint32_t pe_cvt_pk(float a, float b) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+  return cvt_pk_bf16_f32(a, b);
 }
 
 // split 8 fp32 values into packed bf16 hi / lo fragments: v ~ hi + lo

@@ -40,9 +40,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // coalesced 16-byte reads, K kept row-major and V transposed on the way into LDS (so the caller needs no
 // V^T copy), then every wave runs its 32 queries against the chunk.
 __device__ __forceinline__ uint32_t va_cvt_pk(float a, float b) {  // packed RNE fp32 -> bf16 (gfx950)
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+  return cvt_pk_bf16_f32(a, b);
 }
 
 constexpr float VA_DEFER = 8.f;  // log2 of the largest P the deferred rescale lets through
@@ -214,7 +212,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
         for (int qb = 0; qb < QB; ++qb)
           o[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][s2].v, o[qb][t], 0, 0, 0);
       }
-    if (__any(moved)) {  // rare after the first tile: re-reference the accumulators of the queries that moved
+    if (__builtin_expect(__any(moved), 0)) {  // rare after the first tile: re-reference the accumulators of the queries that moved
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const bf16x8 v0 = v_frag(0, t), v1 = v_frag(1, t);
