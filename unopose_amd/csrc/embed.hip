@@ -14,6 +14,7 @@
 // SPLIT=true keeps fp32-class accuracy on the bf16 matrix cores by splitting both operands into
 // hi + lo bf16 parts (3 MFMAs per product, ~2^-16 relative error); SPLIT=false is the autocast(bf16) path.
 #include "common.h"
+#include <type_traits>
 
 namespace unopose {
 
@@ -140,15 +141,13 @@ __global__ __launch_bounds__(GE_THREADS) void geo_embed_kernel(
     if (!SPLIT) {
       // bf16 operands (8-bit mantissa): the hardware v_sin_f32 / v_cos_f32 (argument in revolutions,
       // ~1e-6 absolute error) are far more accurate than the rounding that follows
-      const float r0 = idx * div0 * 0.15915494309189535f;
+      // (both frequency halves: the polynomial for the small-argument half cost ~20 VALU instructions per
+      // pair against two transcendental issues, and VALU issue is what bounds this kernel)
+      const float r0 = idx * div0 * 0.15915494309189535f, r1 = w1 * 0.15915494309189535f;
       s0 = __builtin_amdgcn_sinf(r0);
       c0 = __builtin_amdgcn_cosf(r0);
-      sincos_small(w1, s1, c1);
-      if (fabsf(idx) >= 32.f) {  // wave-uniform, never taken for normalised clouds
-        const float r1 = w1 * 0.15915494309189535f;
-        s1 = __builtin_amdgcn_sinf(r1);
-        c1 = __builtin_amdgcn_cosf(r1);
-      }
+      s1 = __builtin_amdgcn_sinf(r1);
+      c1 = __builtin_amdgcn_cosf(r1);
     } else {
       sincos_cw(idx * div0, s0, c0);
       if (fabsf(idx) < 32.f) {  // wave-uniform
@@ -230,21 +229,30 @@ __global__ __launch_bounds__(GE_THREADS) void geo_embed_kernel(
   }
 
   // ---------------- phase 3: E = d + reduce_k(a_k) + (b_d + b_a)
+  // (one base address per lane + a row stride, the tail check only in a cloud's last tile, the reduction
+  // flag hoisted out of the register loop: the epilogue was the largest VALU block of the kernel)
   const float bsum = bias[ch];
+  const size_t obase = ((size_t)b * nn + pair0 + 4 * khalf) * GE_DIM + ch;
+  const bool full = pair0 + GE_PAIRS <= nn;  // wave-uniform
+  auto epilogue = [&](auto mean_tag) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;  // 32x32 C/D layout
-    const int pair = pair0 + row;
-    if (pair >= nn) continue;
-    float a = reduce_mean ? (acc[1][r] + acc[2][r] + acc[3][r]) * (1.f / 3.f)
-                          : fmaxf(fmaxf(acc[1][r], acc[2][r]), acc[3][r]);
-    const float v = acc[0][r] + a + bsum;
-    const size_t o = ((size_t)b * nn + pair) * GE_DIM + ch;
-    if (OUT_BF16)
-      reinterpret_cast<u16 *>(out_)[o] = f2bf(v);
-    else
-      reinterpret_cast<float *>(out_)[o] = v;
-  }
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2);  // 32x32 C/D layout (+ 4 * khalf, in the base)
+      const float a = decltype(mean_tag)::value ? (acc[1][r] + acc[2][r] + acc[3][r]) * (1.f / 3.f)
+                                                : fmaxf(fmaxf(acc[1][r], acc[2][r]), acc[3][r]);
+      const float v = acc[0][r] + a + bsum;
+      if (full || pair0 + 4 * khalf + row < nn) {
+        if (OUT_BF16)
+          reinterpret_cast<u16 *>(out_)[obase + (size_t)row * GE_DIM] = (u16)cvt_pk_bf16(v, v);
+        else
+          reinterpret_cast<float *>(out_)[obase + (size_t)row * GE_DIM] = v;
+      }
+    }
+  };
+  if (reduce_mean)
+    epilogue(std::true_type{});
+  else
+    epilogue(std::false_type{});
 }
 
 }  // namespace unopose
