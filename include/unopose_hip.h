@@ -166,7 +166,7 @@ int unopose_pe_group_mlp_max(const float *xyz, int B, int N, float radius, int n
  * a_ij = softmax_row * softmax_col * s1_i * s2_j (s*_0 = 1).
  *
  * assign_labels: streaming softmax statistics into stats_ws (2*B*(R+C) floats:
- * [rmax B*R | rsum B*R | cmax B*C | csum B*C]) and the foreground masks
+ * [rmax B*R | 1/rsum B*R | cmax B*C | 1/csum B*C], the sums of exp(x - max) stored as reciprocals) and the foreground masks
  * w1 (B,R-1) = [argmax_j a_ij > 0], w2 (B,C-1) = [argmax_i a_ij > 0]  (:444-447, :542-545). */
 int unopose_assign_labels(const float *atten, int B, int R, int C, const float *score1,
                           const float *score2, float *stats_ws, float *w1, float *w2,

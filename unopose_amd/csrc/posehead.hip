@@ -15,6 +15,12 @@
 
 namespace unopose {
 
+// exp(x) for x <= 0 on the transcendental unit: v_exp_f32(x * log2 e), ~2 ulp; the softmax statistics and
+// every later use of them go through the same function, so the normalisation stays self-consistent.  (The
+// libm expf + IEEE divisions cost ~60 VALU instructions per matrix element and made these passes
+// VALU-bound at 1.5-4 TB/s instead of HBM-bound.)
+__device__ __forceinline__ float ph_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 // ---- pass 1a: per-row max and sum-exp (one wavefront per row)
 __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ x, int R, int C,
                                                         float *__restrict__ rmax, float *__restrict__ rsum) {
@@ -26,11 +32,11 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
   for (int j = lane; j < C; j += 64) m = fmaxf(m, row[j]);
   m = wave_max_f32(m);
   float s = 0.f;
-  for (int j = lane; j < C; j += 64) s += expf(row[j] - m);
+  for (int j = lane; j < C; j += 64) s += ph_exp(row[j] - m);
   s = wave_sum_f32(s);
   if (lane == 0) {
     rmax[(size_t)b * R + i] = m;
-    rsum[(size_t)b * R + i] = s;
+    rsum[(size_t)b * R + i] = 1.f / s;  // the RECIPROCAL of the sum is what every consumer multiplies by
   }
 }
 
@@ -46,10 +52,10 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict_
     for (int i = ty; i < R; i += 4) {
       const float v = X[(size_t)i * C + j];
       if (v > m) {
-        s = s * expf(m - v) + 1.f;
+        s = s * ph_exp(m - v) + 1.f;
         m = v;
       } else {
-        s += expf(v - m);
+        s += ph_exp(v - m);
       }
     }
   }
@@ -60,15 +66,15 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict_
     float M = fmaxf(fmaxf(sm[0][tx], sm[1][tx]), fmaxf(sm[2][tx], sm[3][tx]));
     float S = 0.f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) S += ss[g][tx] * expf(sm[g][tx] - M);
+    for (int g = 0; g < 4; ++g) S += ss[g][tx] * ph_exp(sm[g][tx] - M);
     cmax[(size_t)b * C + j] = M;
-    csum[(size_t)b * C + j] = S;
+    csum[(size_t)b * C + j] = 1.f / S;
   }
 }
 
-__device__ __forceinline__ float assign_val(float v, float rm, float rs, float cm, float cs, float s1, float s2) {
+__device__ __forceinline__ float assign_val(float v, float rm, float irs, float cm, float ics, float s1, float s2) {
   // ((softmax_row * softmax_col) * s1) * s2, the reference's multiplication order
-  return ((expf(v - rm) / rs) * (expf(v - cm) / cs)) * s1 * s2;
+  return ((ph_exp(v - rm) * irs) * (ph_exp(v - cm) * ics)) * s1 * s2;  // irs, ics: reciprocal sums
 }
 
 // ---- pass 2a: w1_i = [max_{j>=1} a_ij > a_i0] for rows i >= 1 (first-index argmax tie rule)
@@ -127,6 +133,10 @@ __global__ __launch_bounds__(256) void col_label_kernel(const float *__restrict_
 
 // ---- pass 3 (fine): row weights and soft correspondences (model_utils.py:548-553)
 //   A_ij = a_ij w1_i w2_j;  weight_i = sum_j A_ij;  pred_i = sum_j A_ij q_j / (weight_i + 1e-6)
+// One wavefront owns FOUR rows: the per-column data (max, reciprocal sum, score, label, point) is loaded
+// once per 64-column step and reused by the four rows (1 + 7/4 loads per element instead of 8: the
+// one-row form was bound by the vector-memory pipe, not by HBM), and the two exponentials of a_ij are one:
+//   a_ij = exp(2 x - rmax_i - cmax_j) * (s1_i w1_i / rsum_i) * (s2_j w2_j / csum_j)
 __global__ __launch_bounds__(256) void fine_rows_kernel(const float *__restrict__ x, int R, int C,
                                                         const float *__restrict__ rmax,
                                                         const float *__restrict__ rsum,
@@ -138,39 +148,54 @@ __global__ __launch_bounds__(256) void fine_rows_kernel(const float *__restrict_
                                                         const float *__restrict__ pts2,  // (B,C-1,3)
                                                         float *__restrict__ weight,      // (B,R-1)
                                                         float *__restrict__ pred /* (B,R-1,3) */) {
+  constexpr float L2E = 1.4426950408889634f;
   const int b = blockIdx.y, lane = threadIdx.x & 63;
-  const int i = 1 + blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= R) return;
-  const size_t o = (size_t)b * (R - 1) + i - 1;
-  const float wi = w1[o];
-  float sw = 0.f, px = 0.f, py = 0.f, pz = 0.f;
-  if (wi != 0.f) {  // wave-uniform
-    const float *row = x + ((size_t)b * R + i) * C;
-    const float rm = rmax[(size_t)b * R + i], rs = rsum[(size_t)b * R + i];
-    const float s1 = score1[o];
+  const int i0 = 1 + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;  // first of this wave's 4 rows
+  if (i0 >= R) return;
+  float rfac[4], rml[4];
+  const float *row[4];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = min(i0 + k, R - 1);
+    const size_t o = (size_t)b * (R - 1) + i - 1;
+    const float wi = i0 + k < R ? w1[o] : 0.f;
+    rfac[k] = rsum[(size_t)b * R + i] * score1[o] * wi;  // rsum holds 1 / sum
+    rml[k] = rmax[(size_t)b * R + i] * L2E;
+    row[k] = x + ((size_t)b * R + i) * C;
+    any |= wi != 0.f;
+  }
+  float sw[4] = {0.f, 0.f, 0.f, 0.f}, px[4] = {0.f, 0.f, 0.f, 0.f}, py[4] = {0.f, 0.f, 0.f, 0.f}, pz[4] = {0.f, 0.f, 0.f, 0.f};
+  if (any) {  // wave-uniform: four background rows in a row are skipped without reading them
     const float *CM = cmax + (size_t)b * C, *CS = csum + (size_t)b * C, *S2 = score2 + (size_t)b * (C - 1);
     const float *W2 = w2 + (size_t)b * (C - 1), *Q = pts2 + (size_t)b * (C - 1) * 3;
     for (int j = 1 + lane; j < C; j += 64) {
-      const float wj = W2[j - 1];
-      if (wj != 0.f) {
-        const float a = assign_val(row[j], rm, rs, CM[j], CS[j], s1, S2[j - 1]) * wi * wj;
-        sw += a;
-        px += a * Q[(j - 1) * 3];
-        py += a * Q[(j - 1) * 3 + 1];
-        pz += a * Q[(j - 1) * 3 + 2];
+      const float g = CS[j] * S2[j - 1] * W2[j - 1];  // csum holds 1 / sum
+      const float cml = CM[j] * L2E;
+      const float qx = Q[(j - 1) * 3], qy = Q[(j - 1) * 3 + 1], qz = Q[(j - 1) * 3 + 2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(row[k][j], 2.f * L2E, -(rml[k] + cml)));
+        const float a = e * g;
+        sw[k] += a;
+        px[k] = fmaf(a, qx, px[k]);
+        py[k] = fmaf(a, qy, py[k]);
+        pz[k] = fmaf(a, qz, pz[k]);
       }
     }
-    sw = wave_sum_f32(sw);
-    px = wave_sum_f32(px);
-    py = wave_sum_f32(py);
-    pz = wave_sum_f32(pz);
   }
-  if (lane == 0) {
-    weight[o] = sw;
-    const float inv = 1.f / (sw + 1e-6f);
-    pred[o * 3] = px * inv;
-    pred[o * 3 + 1] = py * inv;
-    pred[o * 3 + 2] = pz * inv;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float s = wave_sum_f32(sw[k]) * rfac[k], ax = wave_sum_f32(px[k]) * rfac[k];
+    const float ay = wave_sum_f32(py[k]) * rfac[k], az = wave_sum_f32(pz[k]) * rfac[k];
+    if (lane == 0 && i0 + k < R) {
+      const size_t o = (size_t)b * (R - 1) + i0 + k - 1;
+      weight[o] = s;
+      const float inv = 1.f / (s + 1e-6f);
+      pred[o * 3] = ax * inv;
+      pred[o * 3 + 1] = ay * inv;
+      pred[o * 3 + 2] = az * inv;
+    }
   }
 }
 
@@ -406,7 +431,7 @@ int unopose_fine_correspondences(const float *atten, int B, int R, int C, const 
   if (B == 0) return UNOPOSE_OK;
   const float *rmax = stats_ws, *rsum = rmax + (size_t)B * R, *cmax = rsum + (size_t)B * R,
               *csum = cmax + (size_t)B * C;
-  hipLaunchKernelGGL(fine_rows_kernel, dim3(cdiv(R - 1, 4), B), dim3(256), 0, (hipStream_t)stream, atten, R, C, rmax,
+  hipLaunchKernelGGL(fine_rows_kernel, dim3(cdiv(R - 1, 16), B), dim3(256), 0, (hipStream_t)stream, atten, R, C, rmax,
                      rsum, cmax, csum, score1, score2, w1, w2, pts2, weight, pred);
   return check_launch("fine_correspondences");
 }
