@@ -232,12 +232,25 @@ int unopose_add_layernorm(const void *a, int a_bf16, const void *b, int b_bf16, 
                           const float *bias, long rows, int C, float eps, void *out, int out_bf16,
                           unopose_stream_t stream);
 
+/* Same with a row stride ld_out >= C (elements) on the OUTPUT: lets several LayerNorms write side by side into
+ * one wider row-major buffer (the four ViT taps that oneref_feature_extraction.py:213 concatenates). */
+int unopose_add_layernorm_strided(const void *a, int a_bf16, const void *b, int b_bf16, const float *w,
+                                  const float *bias, long rows, int C, float eps, void *out, int out_bf16,
+                                  long ld_out, unopose_stream_t stream);
+
 /* Pixel features at the chosen pixels only: bilinear resize (align_corners=False) of the 4x up-projected
  * ViT map to (H,W) fused with get_chosen_pixel_feats (oneref_feature_extraction.py:221-229,
  * utils/model_utils.py:215-227).  z (B,side,side,4,4,256) float32 or bfloat16 = the up-projection output
  * in its native order, choose (B,Np) int64 flat pixel indices, out (B,Np,256) float32. */
 int unopose_bilinear_sample(const void *z, int z_bf16, const long long *choose, int B, int side, int Np,
                             int H, int W, float *out, unopose_stream_t stream);
+
+/* Same on a token tensor that still carries prefix tokens: z (B, tok_stride, 4, 4, 256) with patch token p of
+ * image b at row tok_offset + p (the ViT's 5 class / register tokens are skipped by the index math instead
+ * of being sliced off with a copy). */
+int unopose_bilinear_sample_tokens(const void *z, int z_bf16, const long long *choose, int B, int side, int Np,
+                                   int H, int W, int tok_offset, int tok_stride, float *out,
+                                   unopose_stream_t stream);
 
 /* x (rows,C) float32 += gamma * y (bfloat16) in place AND out (bfloat16) = LayerNorm(x) * w + bias: the
  * LayerScale residual of one timm ViT branch fused with the LayerNorm that opens the next one. */

@@ -325,6 +325,12 @@ def test_fused_row_kernels():
         y = b.bfloat16()
         gam = torch.rand(C, generator=g).cuda()
         assert err(ops.scale_residual_(x, y, gam), a + gam * y.float()) < 1e-6
+        # two LayerNorms filling column blocks of one wider buffer (the ViT taps, no concatenation)
+        wide = torch.full((10, 100, 2 * C), 7.0).cuda()
+        a3 = a.reshape(10, 100, C)
+        ops.add_layernorm(a3, None, ln, out=wide[:, :, :C])
+        ops.add_layernorm(a3, b.reshape(10, 100, C), ln, out=wide[:, :, C:])
+        assert err(wide[:, :, :C], ln(a3)) < 2e-5 and err(wide[:, :, C:], ref.reshape(10, 100, C)) < 2e-5
 
 
 @torch.no_grad()
@@ -418,6 +424,9 @@ def test_fused_bilinear_pixel_sampling():
     assert err(out, ref) < 5e-5  # fp32 round-off of the source-coordinate / lambda arithmetic
     outb = ops.bilinear_sample_native(z.bfloat16(), choose, S, S)
     assert err(outb, ref) < 3e-2
+    # token form with the 5 class / register tokens still in front (skipped by index math, no slice copy)
+    tok = torch.cat([torch.full((B, 5, 4, 4, 256), 1e9).cuda(), z.reshape(B, side * side, 4, 4, 256)], 1)
+    assert torch.equal(ops.bilinear_sample_native(tok, choose, S, S, tok_offset=5), out)
 
 
 @torch.no_grad()

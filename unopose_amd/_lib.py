@@ -44,7 +44,9 @@ SIGNATURES = {
     "unopose_vit_attention_f32": [_P, _I, _I, _I, _P, _P],
     "unopose_vit_attention": [_P, _I, _I, _I, _P, _P],
     "unopose_add_layernorm": [_P, _I, _P, _I, _P, _P, ctypes.c_long, _I, _F, _P, _I, _P],
+    "unopose_add_layernorm_strided": [_P, _I, _P, _I, _P, _P, ctypes.c_long, _I, _F, _P, _I, ctypes.c_long, _P],
     "unopose_bilinear_sample": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P],
+    "unopose_bilinear_sample_tokens": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "unopose_scale_residual_layernorm": [_P, _P, _P, _P, _P, ctypes.c_long, _I, _F, _P, _P],
     "unopose_scale_residual": [_P, _P, _P, ctypes.c_long, _I, _P],
     "unopose_linear_attention": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],

@@ -27,7 +27,7 @@ template <bool A_BF16, bool B_BF16, bool HAS_B, bool OUT_BF16>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const void *__restrict__ a, const void *__restrict__ b,
                                                             const float *__restrict__ w,
                                                             const float *__restrict__ bias, long rows, int C,
-                                                            float eps, void *__restrict__ out) {
+                                                            float eps, void *__restrict__ out, long ldo) {
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -59,9 +59,9 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const void *__restri
     if (c < C) {
       const float y = (v[i] - mean) * rstd * w[c] + bias[c];
       if (OUT_BF16)
-        reinterpret_cast<u16 *>(out)[(size_t)r * C + c] = fu_f2bf(y);
+        reinterpret_cast<u16 *>(out)[(size_t)r * ldo + c] = fu_f2bf(y);
       else
-        reinterpret_cast<float *>(out)[(size_t)r * C + c] = y;
+        reinterpret_cast<float *>(out)[(size_t)r * ldo + c] = y;
     }
   }
 }
@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(float *__restrict__
 template <bool IN_BF16>
 __global__ __launch_bounds__(256) void bilinear_sample_kernel(const void *__restrict__ z,
                                                               const long long *__restrict__ choose, int side, int Np,
-                                                              int H, int W, float *__restrict__ out) {
+                                                              int H, int W, int tok_off, int tok_stride,
+                                                              float *__restrict__ out) {
   const int b = blockIdx.y, lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= Np) return;
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(256) void bilinear_sample_kernel(const void *__rest
   const int y1 = y0 < hw - 1 ? y0 + 1 : y0, x1 = x0 < hw - 1 ? x0 + 1 : x0;
   const float ly = sy - (float)y0, lx = sx - (float)x0;
   auto at = [&](int Y, int X) -> size_t {  // element offset of map pixel (Y,X), channel 0
-    return ((((size_t)b * side + (Y >> 2)) * side + (X >> 2)) * 16 + (Y & 3) * 4 + (X & 3)) * 256;
+    // patch token (Y>>2, X>>2) of image b sits at row tok_off + index of a (B, tok_stride, 16, 256) tensor
+    return ((((size_t)b * tok_stride + tok_off + (size_t)(Y >> 2) * side + (X >> 2))) * 16 + (Y & 3) * 4 + (X & 3)) * 256;
   };
   const size_t o00 = at(y0, x0), o01 = at(y0, x1), o10 = at(y1, x0), o11 = at(y1, x1);
   float v[4][4];
@@ -198,13 +200,19 @@ extern "C" {
 
 int unopose_add_layernorm(const void *a, int a_bf16, const void *b, int b_bf16, const float *w, const float *bias,
                           long rows, int C, float eps, void *out, int out_bf16, unopose_stream_t stream) {
+  return unopose_add_layernorm_strided(a, a_bf16, b, b_bf16, w, bias, rows, C, eps, out, out_bf16, C, stream);
+}
+
+int unopose_add_layernorm_strided(const void *a, int a_bf16, const void *b, int b_bf16, const float *w,
+                                  const float *bias, long rows, int C, float eps, void *out, int out_bf16, long ld_out,
+                                  unopose_stream_t stream) {
   UNOPOSE_REQUIRE(a && w && bias && out, "add_layernorm: null pointer");
-  UNOPOSE_REQUIRE(rows >= 0 && C >= 1 && C <= 1024, "add_layernorm: C=%d unsupported (<= 1024)", C);
+  UNOPOSE_REQUIRE(rows >= 0 && C >= 1 && C <= 1024 && ld_out >= C, "add_layernorm: C=%d unsupported (<= 1024, ld_out >= C)", C);
   if (rows == 0) return UNOPOSE_OK;
   dim3 grid((unsigned)((rows + 3) / 4));
   hipStream_t s = (hipStream_t)stream;
 #define UNOPOSE_LN(AB, BB, HB, OB)                                                                         \
-  hipLaunchKernelGGL((add_layernorm_kernel<AB, BB, HB, OB>), grid, dim3(256), 0, s, a, b, w, bias, rows, C, eps, out)
+  hipLaunchKernelGGL((add_layernorm_kernel<AB, BB, HB, OB>), grid, dim3(256), 0, s, a, b, w, bias, rows, C, eps, out, ld_out)
   const int key = (a_bf16 ? 8 : 0) | (b ? (b_bf16 ? 4 : 0) | 2 : 0) | (out_bf16 ? 1 : 0);
   switch (key) {
     case 0: UNOPOSE_LN(false, false, false, false); break;
@@ -227,16 +235,23 @@ int unopose_add_layernorm(const void *a, int a_bf16, const void *b, int b_bf16, 
 
 int unopose_bilinear_sample(const void *z, int z_bf16, const long long *choose, int B, int side, int Np, int H, int W,
                             float *out, unopose_stream_t stream) {
+  return unopose_bilinear_sample_tokens(z, z_bf16, choose, B, side, Np, H, W, 0, side * side, out, stream);
+}
+
+int unopose_bilinear_sample_tokens(const void *z, int z_bf16, const long long *choose, int B, int side, int Np, int H,
+                                   int W, int tok_offset, int tok_stride, float *out, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(z && choose && out, "bilinear_sample: null pointer");
-  UNOPOSE_REQUIRE(B >= 0 && side >= 1 && Np >= 0 && H >= 1 && W >= 1 && B <= 65535, "bilinear_sample: bad sizes");
+  UNOPOSE_REQUIRE(B >= 0 && side >= 1 && Np >= 0 && H >= 1 && W >= 1 && B <= 65535 && tok_offset >= 0 &&
+                      tok_stride >= tok_offset + side * side,
+                  "bilinear_sample: bad sizes");
   if (B == 0 || Np == 0) return UNOPOSE_OK;
   dim3 grid(cdiv(Np, 4), B);
   if (z_bf16)
     hipLaunchKernelGGL(bilinear_sample_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, choose, side, Np, H, W,
-                       out);
+                       tok_offset, tok_stride, out);
   else
     hipLaunchKernelGGL(bilinear_sample_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, choose, side, Np, H,
-                       W, out);
+                       W, tok_offset, tok_stride, out);
   return check_launch("bilinear_sample");
 }
 

@@ -104,7 +104,10 @@ class ViT(nn.Module):
         self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
         self.head = nn.Linear(embed_dim, 1000)  # unused; kept so released checkpoints load strictly
 
-    def forward(self, x):
+    def forward(self, x, taps_side_by_side=False):
+        """-> the four tapped LayerNorm outputs (F:24-42).  With `taps_side_by_side` on the fused autocast path
+        they are returned as ONE (B, T, 4*D) tensor (tap k in columns [k*D, (k+1)*D)), written in place by the
+        four LayerNorm launches instead of being concatenated afterwards."""
         B = x.shape[0]
         p = self.patch_size
         # patch conv 14x14/14 as one GEMM: (B, P, 3*14*14) @ W^T
@@ -121,12 +124,16 @@ class ViT(nn.Module):
             # fused glue: each block's LayerScale residual also produces the next LayerNorm (csrc/fused.hip)
             x = x.contiguous()
             n1 = ops.add_layernorm(x, None, self.blocks[0].norm1, torch.bfloat16)
+            D = x.shape[-1]
+            wide = torch.empty(B, x.shape[1], len(taps) * D, dtype=torch.bfloat16, device=x.device) \
+                if taps_side_by_side else None
             for i, blk in enumerate(self.blocks):
                 nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None
                 x, n1 = blk.forward_fused(x, n1, nxt)
                 if i in taps:
-                    outs.append(ops.add_layernorm(x, None, self.norm))
-            return outs
+                    k = len(outs)
+                    outs.append(ops.add_layernorm(x, None, self.norm, out=None if wide is None else wide[:, :, k * D:(k + 1) * D]))
+            return outs if wide is None else wide
         for i, blk in enumerate(self.blocks):
             x = blk(x)
             if i in taps:
@@ -192,10 +199,23 @@ class ViT_AE(nn.Module):
         z = torch.cat([o[:, 5:, :] for o in outs], dim=2)
         return ops.linear(z, self.output_upscaling).reshape(B, side, side, 4, 4, self.out_dim), (H, W)
 
+    def upprojected_tokens(self, x):
+        """(B,3,S,S) -> (z (B, tokens, 4, 4, 256), (H, W), tok_offset): the up-projection applied to the token
+        tensor as the ViT leaves it.  On the fused autocast path the four taps were written side by side and
+        the 5 class / register tokens stay in place (tok_offset = 5: the pixel sampler skips them by index
+        math), so neither the tap concatenation nor the prefix slice (F:213) costs a copy."""
+        B, _, H, W = x.shape
+        outs = self.vit(x, taps_side_by_side=True)
+        if torch.is_tensor(outs):
+            z = ops.linear(outs, self.output_upscaling)
+            return z.reshape(B, outs.shape[1], 4, 4, self.out_dim), (H, W), outs.shape[1] - (H // 14) * (W // 14)
+        z = ops.linear(torch.cat([o[:, 5:, :] for o in outs], dim=2), self.output_upscaling)
+        return z.reshape(B, -1, 4, 4, self.out_dim), (H, W), 0
+
     def pixel_features(self, x, choose):
         if x.is_cuda and self.out_dim == 256:
-            z, (H, W) = self.upprojected(x)
-            return ops.bilinear_sample_native(z, choose, H, W)
+            z, (H, W), off = self.upprojected_tokens(x)
+            return ops.bilinear_sample_native(z, choose, H, W, tok_offset=off)
         low, (H, W) = self.lowres_map(x)
         return ops.bilinear_sample_pixels(low, choose, H, W)
 

@@ -171,14 +171,14 @@ class UNOPose(nn.Module):
                 t.record_stream(main)
         # both crops through the ViT as ONE batch of 2B images
         B = rgb.shape[0]
-        z, (H, W) = net.upprojected(torch.cat([rgb, tem_rgb], 0))
+        z, (H, W), off = net.upprojected_tokens(torch.cat([rgb, tem_rgb], 0))
         # query | reference features land in ONE (2B,N,256) buffer: the fine matcher takes them stacked
         both = torch.empty(2 * B, choose.shape[1], 256, dtype=torch.float32, device=z.device) \
             if sel_choose.shape == choose.shape else None
-        dense_fm = ops.bilinear_sample_native(z[:B], choose, H, W, out=None if both is None else both[:B])
+        dense_fm = ops.bilinear_sample_native(z[:B], choose, H, W, out=None if both is None else both[:B], tok_offset=off)
         main.wait_stream(side)
         # only the FPS-selected reference pixels are ever interpolated (gather commutes with sampling)
-        dense_fo = ops.bilinear_sample_native(z[B:], sel_choose, H, W, out=None if both is None else both[B:])
+        dense_fo = ops.bilinear_sample_native(z[B:], sel_choose, H, W, out=None if both is None else both[B:], tok_offset=off)
         return dense_pm, dense_fm, dense_po, dense_fo, radius
 
     @torch.no_grad()
@@ -194,8 +194,8 @@ class UNOPose(nn.Module):
         idx_o = ops.furthest_point_sample(tem_n, self.fine_npoint)
         sel_choose = torch.gather(tem1_choose, 1, idx_o.long())
         net = self.feature_extraction.rgb_net
-        z, (H, W) = net.upprojected(tem1_rgb)
-        return dict(ref_dense_po=ops.gather_rows(tem_n, idx_o), ref_dense_fo=ops.bilinear_sample_native(z, sel_choose, H, W),
+        z, (H, W), off = net.upprojected_tokens(tem1_rgb)
+        return dict(ref_dense_po=ops.gather_rows(tem_n, idx_o), ref_dense_fo=ops.bilinear_sample_native(z, sel_choose, H, W, tok_offset=off),
                     ref_radius=radius, ref_lrf=ops.lrf_global(tem1_pts, self.use_ref_rad))
 
     def _side_stream(self, device):

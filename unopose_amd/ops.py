@@ -127,21 +127,31 @@ def vit_attention_torch(qkv, heads):
     return a.transpose(1, 2).reshape(B, T, C)
 
 
-def bilinear_sample_native(z, choose, H, W, out=None):
+def bilinear_sample_native(z, choose, H, W, out=None, tok_offset=0):
     """Fused HIP version of bilinear_sample_pixels on the up-projection output in its NATIVE order
     z (B, side, side, 4, 4, 256) (no permute copy): (B,Np) int64 pixel indices -> (B,Np,256) fp32
-    (written into `out` when given: a contiguous fp32 (B,Np,256) view)."""
+    (written into `out` when given: a contiguous fp32 (B,Np,256) view).  With `tok_offset` > 0, z is
+    (B, tok_offset + side*side, 4, 4, 256): the token tensor with its prefix (class / register) tokens left
+    in place."""
     z = _c(z)
-    assert z.shape[-1] == 256 and z.shape[3] == 4 and z.shape[4] == 4 and z.dtype in (torch.float32, torch.bfloat16)
-    B, side = z.shape[0], z.shape[1]
+    assert z.shape[-1] == 256 and z.shape[-2] == 4 and z.shape[-3] == 4 and z.dtype in (torch.float32, torch.bfloat16)
+    B = z.shape[0]
+    if z.dim() == 5:  # (B, tokens, 4, 4, 256)
+        tok_stride = z.shape[1]
+        side = int(round((tok_stride - tok_offset) ** 0.5))
+        assert side * side + tok_offset == tok_stride
+    else:
+        assert z.dim() == 6 and tok_offset == 0
+        side = z.shape[1]
+        tok_stride = side * side
     choose = _c(choose.long())
     Np = choose.shape[1]
     if out is None:
         out = torch.empty(B, Np, 256, dtype=torch.float32, device=z.device)
     assert out.shape == (B, Np, 256) and out.dtype == torch.float32 and out.is_contiguous()
     with torch.cuda.device(z.device):
-        call("unopose_bilinear_sample", ptr(z), int(z.dtype == torch.bfloat16), ptr(choose), B, side, Np, int(H), int(W),
-             ptr(out), stream_ptr())
+        call("unopose_bilinear_sample_tokens", ptr(z), int(z.dtype == torch.bfloat16), ptr(choose), B, side, Np, int(H),
+             int(W), int(tok_offset), int(tok_stride), ptr(out), stream_ptr())
     return out
 
 
@@ -657,24 +667,36 @@ def fine_pose(atten, score, pts1, pts2, dis_thres=0.15):
     return R, t, ps * w1.mean(1)
 
 
-def add_layernorm(a, b, norm, out_dtype=None):
+def add_layernorm(a, b, norm, out_dtype=None, out=None):
     """LayerNorm(a + b) in one HIP pass (b may be None); a/b fp32 or bf16, output `out_dtype`
-    (default: bf16 under autocast, else a.dtype).  norm: nn.LayerNorm."""
-    if out_dtype is None:
-        out_dtype = torch.bfloat16 if torch.is_autocast_enabled() else a.dtype
+    (default: bf16 under autocast, else a.dtype).  norm: nn.LayerNorm.  `out`: optional destination, a view
+    of shape a.shape whose rows are `ld` elements apart in one row-major buffer (last dim contiguous) --
+    several LayerNorms can then fill column blocks of one wider tensor without a concatenation."""
     a = _c(a)
     C = a.shape[-1]
     rows = a.numel() // C
     if b is not None:
         b = _c(b)
         assert b.shape == a.shape
-    out = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+    if out is None:
+        if out_dtype is None:
+            out_dtype = torch.bfloat16 if torch.is_autocast_enabled() else a.dtype
+        out = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+        ld = C
+    else:
+        out_dtype = out.dtype
+        ld = out.stride(-2)
+        assert out.shape == a.shape and out.stride(-1) == 1 and ld >= C
+        exp = ld
+        for d in range(out.dim() - 2, -1, -1):  # every leading dim must continue the same row pitch
+            assert out.stride(d) == exp or out.shape[d] == 1, "out rows must be uniformly strided"
+            exp *= out.shape[d]
     ok = (torch.float32, torch.bfloat16)
     assert a.dtype in ok and out_dtype in ok and (b is None or b.dtype in ok) and a.is_cuda
     with torch.cuda.device(a.device):
-        call("unopose_add_layernorm", ptr(a), int(a.dtype == torch.bfloat16), ptr(b) if b is not None else None,
+        call("unopose_add_layernorm_strided", ptr(a), int(a.dtype == torch.bfloat16), ptr(b) if b is not None else None,
              int(b is not None and b.dtype == torch.bfloat16), ptr(norm.weight), ptr(norm.bias), rows, C,
-             float(norm.eps), ptr(out), int(out_dtype == torch.bfloat16), stream_ptr())
+             float(norm.eps), ptr(out), int(out_dtype == torch.bfloat16), int(ld), stream_ptr())
     return out
 
 
