@@ -135,6 +135,16 @@ int unopose_pe_pack_weights(const float *w1, const float *b1, const float *w2, c
 int unopose_pe_group_mlp_max_packed(const float *xyz, int B, int N, float radius, int nsample,
                                     const void *image, float *out, unopose_stream_t stream);
 
+/* Same with a neighbour-list hand-off between the two scales of PositionalEncoding: a pass may write, per
+ * centre, its (padded) neighbour list cand_out (B,N,nsample) int32 and cand_cnt_out (B,N) = number of points
+ * inside the radius, or -1 if that exceeded nsample; a later pass over the SAME cloud with a SMALLER radius
+ * may read them (cand_in with row stride cand_stride, cand_cnt_in) and test only those candidates instead of
+ * scanning all N points.  Results are identical to the full scan.  Any of the pairs may be NULL. */
+int unopose_pe_group_mlp_max_packed_cand(const float *xyz, int B, int N, float radius, int nsample,
+                                         const void *image, const int *cand_in, const int *cand_cnt_in,
+                                         int cand_stride, int *cand_out, int *cand_cnt_out, float *out,
+                                         unopose_stream_t stream);
+
 /* GeometricStructureEmbedding.forward (core/unopose/model/transformer.py:303-350):
  * points (B,n,3) -> out (B,n,n,256), float32 or bfloat16 (out_bf16).  hidden_dim = 256,
  * angle_k = 3.  Weights are passed as bfloat16 bit patterns in MFMA-fragment order

@@ -235,6 +235,30 @@ def test_fused_pe_kernel_vs_unfused(model, r, ns):
 
 
 @torch.no_grad()
+def test_pe_neighbour_list_handoff_is_exact(model, oracle_ext):
+    """The narrow PE scale fed with the wide scale's neighbour lists (csrc/pe.hip cand_in / cand_out) gives
+    bit-identical features to its own full scan; the lists themselves are the reference ball query's rows
+    (bit-exact indices, padding included); a wide list that overflows (count -1) falls back to the scan."""
+    from test_geom_gpu import norm_clouds
+    from unopose_amd import ops
+
+    x = norm_clouds(2048, 3, seed=5)
+    x[1, 1000:1400] = x[1, :400]  # duplicate points (sampling with replacement)
+    xc = x.cuda()
+    pe = model.fine_point_matching.PE
+    wide, (lists, counts) = ops.pe_group_mlp_max(xc, 0.2, 256, pe.mlp2, bf16x3=True, want_cand=True)
+    ref_idx = oracle_ext.ball_query(x, x, 0.2, 256)
+    assert torch.equal(lists.cpu(), ref_idx)
+    assert (counts >= 1).all()  # every centre is its own neighbour; none overflows at this density
+    narrow = ops.pe_group_mlp_max(xc, 0.1, 64, pe.mlp1, bf16x3=True)
+    assert torch.equal(ops.pe_group_mlp_max(xc, 0.1, 64, pe.mlp1, bf16x3=True, cand_in=(lists, counts)), narrow)
+    # overflow: with 32-entry lists at radius 0.5 nearly every centre has more neighbours than fit
+    _, (l2, c2) = ops.pe_group_mlp_max(xc, 0.5, 32, pe.mlp1, bf16x3=True, want_cand=True)
+    assert (c2 == -1).float().mean() > 0.9
+    assert torch.equal(ops.pe_group_mlp_max(xc, 0.1, 64, pe.mlp1, bf16x3=True, cand_in=(l2, c2)), narrow)
+
+
+@torch.no_grad()
 def test_pose_head_kernels_vs_torch_composite():
     """HIP pose heads vs the op-by-op torch composite on the constructed-similarity fixtures, plus a
     full-size (2049x2049) fine head."""

@@ -54,6 +54,7 @@ SIGNATURES = {
     "unopose_pe_image_bytes": [],
     "unopose_pe_pack_weights": [_P, _P, _P, _P, _P, _P, _P, _P],
     "unopose_pe_group_mlp_max_packed": [_P, _I, _I, _F, _I, _P, _P, _P],
+    "unopose_pe_group_mlp_max_packed_cand": [_P, _I, _I, _F, _I, _P, _P, _P, _I, _P, _P, _P, _P],
     "unopose_pe_group_mlp_max": [_P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "unopose_geo_embedding": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P, _P, _P],
 }

@@ -22,15 +22,23 @@ __device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >>
 
 // Ball query (pointnet2 ball_query_gpu.cu:14-49 semantics) into the wave's LDS neighbour list and the
 // local reference frame of LRF_batch (pointnet2_utils.py:436-481) for one centre; wave-collective.
-__device__ __forceinline__ void pe_centre_frame(const float *sx, const float *sy, const float *sz, int N, int S,
-                                                float radius, float r2, int lane, float cx, float cy, float cz,
-                                                int *nbr, Vec3 &xp, Vec3 &yp, Vec3 &zp) {
+// `cand` / `ncand`: optional list of candidate indices IN INDEX ORDER that is known to contain every point
+// within the radius (the neighbour list a larger-radius pass of the same cloud wrote, see cand_out below);
+// ncand < 0 = scan the whole cloud.  Returns the number of points inside the radius if the list holds them
+// all, a value > S otherwise.
+__device__ __forceinline__ int pe_centre_frame(const float *sx, const float *sy, const float *sz, int N, int S,
+                                               float radius, float r2, int lane, float cx, float cy, float cz,
+                                               int *nbr, Vec3 &xp, Vec3 &yp, Vec3 &zp, const int *cand = nullptr,
+                                               int ncand = -1) {
   // ---- ball query (pointnet2 ball_query_gpu.cu:14-49 semantics)
   int cnt = 0, first = 0;
-  for (int k0 = 0; k0 < N && cnt < S; k0 += 64) {
-    const int k = k0 + lane;
+  const int nscan = ncand >= 0 ? ncand : N;
+  int k0 = 0;
+  for (; k0 < nscan && cnt < S; k0 += 64) {
+    int k = k0 + lane;
     bool hit = false;
-    if (k < N) {
+    if (k < nscan) {
+      if (ncand >= 0) k = cand[k];
       const float x = sx[k], y = sy[k], z = sz[k];
       const float d2 = (cx - x) * (cx - x) + (cy - y) * (cy - y) + (cz - z) * (cz - z);
       hit = d2 < r2;
@@ -41,10 +49,14 @@ __device__ __forceinline__ void pe_centre_frame(const float *sx, const float *sy
           (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
       const int pos = cnt + pre;
       if (hit && pos < S) nbr[pos] = k;
-      if (cnt == 0) first = k0 + __builtin_ctzll(mask);
+      if (cnt == 0) {
+        const int fl = __builtin_ctzll(mask);  // lane of the first hit
+        first = ncand >= 0 ? __builtin_amdgcn_readlane(k, fl) : k0 + fl;
+      }
       cnt += __builtin_popcountll(mask);
     }
   }
+  if (k0 < nscan) cnt = S + 1;  // stopped early at a full list: the rest of the cloud was not looked at
   for (int l = min(cnt, S) + lane; l < S; l += 64) nbr[l] = first;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -89,6 +101,7 @@ __device__ __forceinline__ void pe_centre_frame(const float *sx, const float *sy
   const float nacc = sqrtf(vx * vx + vy * vy + vz * vz) + 1e-10f;
   xp = v3(vx / nacc, vy / nacc, vz / nacc);
   yp = cross(xp, zp);
+  return cnt;
 }
 
 struct PeLds {
@@ -299,7 +312,8 @@ __global__ __launch_bounds__(256) void pe_pack_weights_kernel(const float *__res
 
 __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
     const float *__restrict__ xyz, int N, float radius, int S, int cpw, const uint4 *__restrict__ image,
-    float *__restrict__ out) {
+    const int *__restrict__ cand_in, const int *__restrict__ cand_cnt_in, int cand_stride, int *__restrict__ cand_out,
+    int *__restrict__ cand_cnt_out, float *__restrict__ out) {
   extern __shared__ float4 smem4[];
   PeLdsB *L = reinterpret_cast<PeLdsB *>(smem4);
   float *sx = reinterpret_cast<float *>(L + 1);
@@ -328,7 +342,20 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
     if (j >= N) break;  // wave-uniform
     const float cx = sx[j], cy = sy[j], cz = sz[j];
     Vec3 xp, yp, zp;
-    pe_centre_frame(sx, sy, sz, N, S, radius, r2, lane, cx, cy, cz, nbr, xp, yp, zp);
+    // The larger-radius pass of a cloud hands its neighbour list to the smaller-radius pass: that one then
+    // tests <= S_large candidates instead of scanning all N points (the full scan is ~1/3 of a small-S launch).
+    const int *cand = nullptr;
+    int ncand = -1;
+    if (cand_in) {
+      ncand = cand_cnt_in[(size_t)b * N + j];  // -1: the producer's list overflowed, scan everything
+      cand = cand_in + ((size_t)b * N + j) * cand_stride;
+    }
+    const int cnt = pe_centre_frame(sx, sy, sz, N, S, radius, r2, lane, cx, cy, cz, nbr, xp, yp, zp, cand, ncand);
+    if (cand_out) {
+      int *co = cand_out + ((size_t)b * N + j) * S;
+      for (int l = lane; l < S; l += 64) co[l] = nbr[l];
+      if (lane == 0) cand_cnt_out[(size_t)b * N + j] = cnt <= S ? cnt : -1;
+    }
 
     f32x16 rmax[4];
 #pragma unroll
@@ -450,7 +477,17 @@ int unopose_pe_pack_weights(const float *w1, const float *b1, const float *w2, c
 
 int unopose_pe_group_mlp_max_packed(const float *xyz, int B, int N, float radius, int nsample, const void *image,
                                     float *out, unopose_stream_t stream) {
+  return unopose_pe_group_mlp_max_packed_cand(xyz, B, N, radius, nsample, image, nullptr, nullptr, 0, nullptr, nullptr,
+                                              out, stream);
+}
+
+int unopose_pe_group_mlp_max_packed_cand(const float *xyz, int B, int N, float radius, int nsample, const void *image,
+                                         const int *cand_in, const int *cand_cnt_in, int cand_stride, int *cand_out,
+                                         int *cand_cnt_out, float *out, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(xyz && image && out, "pe_group_mlp_max_packed: null pointer");
+  UNOPOSE_REQUIRE((cand_in == nullptr) == (cand_cnt_in == nullptr) && (cand_out == nullptr) == (cand_cnt_out == nullptr) &&
+                      (!cand_in || cand_stride >= 1),
+                  "pe_group_mlp_max_packed: candidate list and its counts go together");
   UNOPOSE_REQUIRE(B >= 0 && N >= 1 && nsample >= 32 && nsample % 32 == 0 && B <= 65535,
                   "pe_group_mlp_max_packed: nsample must be a positive multiple of 32 (got %d)", nsample);
   if (B == 0) return UNOPOSE_OK;
@@ -466,7 +503,7 @@ int unopose_pe_group_mlp_max_packed(const float *xyz, int B, int N, float radius
   const int cpw = centres >= 65536 ? 16 : centres >= 32768 ? 8 : centres >= 8192 ? 4 : centres >= 2048 ? 2 : 1;
   dim3 grid(cdiv(N, 4 * cpw), B);
   hipLaunchKernelGGL(pe_group_mlp_max_bf16x3_kernel, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius, nsample,
-                     cpw, (const uint4 *)image, out);
+                     cpw, (const uint4 *)image, cand_in, cand_cnt_in, cand_stride, cand_out, cand_cnt_out, out);
   return check_launch("pe_group_mlp_max_packed");
 }
 

@@ -476,8 +476,13 @@ class PositionalEncoding(nn.Module):
 
     def forward(self, pts):
         pts = pts.float()
-        f1 = ops.pe_group_mlp_max(pts, self.r1, self.ns1, self.mlp1)  # (B,N,128)
-        f2 = ops.pe_group_mlp_max(pts, self.r2, self.ns2, self.mlp2)
+        if pts.is_cuda and torch.is_autocast_enabled() and self.r2 >= self.r1 and self.ns1 % 32 == 0 and self.ns2 % 32 == 0:
+            # the wide scale first: its neighbour lists are the candidates of the narrow scale (csrc/pe.hip)
+            f2, cand = ops.pe_group_mlp_max(pts, self.r2, self.ns2, self.mlp2, want_cand=True)
+            f1 = ops.pe_group_mlp_max(pts, self.r1, self.ns1, self.mlp1, cand_in=cand)
+        else:
+            f1 = ops.pe_group_mlp_max(pts, self.r1, self.ns1, self.mlp1)  # (B,N,128)
+            f2 = ops.pe_group_mlp_max(pts, self.r2, self.ns2, self.mlp2)
         feat = torch.cat([f1, f2], dim=2).float()
         w = self.mlp3.conv.weight.reshape(self.mlp3.conv.weight.shape[0], -1)
         with torch.autocast("cuda", enabled=False):  # Fi:163-165 forces fp32 for the whole PE

@@ -470,11 +470,14 @@ def focused_linear_attention_torch(xq, xkv, att, heads, focusing):
     return x.reshape(B, i, C).to(dt)
 
 
-def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None):
+def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None, cand_in=None, want_cand=False):
     """QueryAndLRFGroup -> SharedMLP[6,32,64,128] -> max over neighbours (fine matcher PE, Fi:167-174)
     as ONE HIP kernel (csrc/pe.hip): neighbour lists, frames and all MLP activations stay on chip;
     (B,N,3) -> (B,N,128) fp32.  Matrix-core precision: exact fp32 MFMA by default; under autocast(bf16)
-    (or bf16x3=True) bf16 MFMA with hi/lo-split operands (~2^-16 relative error, ~5x the fp32 MFMA rate)."""
+    (or bf16x3=True) bf16 MFMA with hi/lo-split operands (~2^-16 relative error, ~5x the fp32 MFMA rate).
+    Neighbour-list hand-off (bf16x3 kernel only): `want_cand=True` also returns (lists (B,N,nsample) int32,
+    counts (B,N) int32) of this pass; passing such a pair from a LARGER-radius pass over the same points as
+    `cand_in` lets this pass test those candidates instead of scanning the cloud (same result)."""
     if bf16x3 is None:
         bf16x3 = torch.is_autocast_enabled()
     if [tuple(l.conv.weight.shape[:2]) for l in mlp.layers()] != [(32, 6), (64, 32), (128, 64)] or nsample % 32:
@@ -500,14 +503,22 @@ def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None):
         mlp._hip_cache = cache
     w1, b1, w2, b2, w3, b3 = cache[1]
     out = torch.empty(B, N, 128, dtype=torch.float32, device=pts.device)
+    cand_out = None
     with torch.cuda.device(pts.device):
         if bf16x3:
-            call("unopose_pe_group_mlp_max_packed", ptr(pts), B, N, float(radius), int(nsample), ptr(cache[2]),
-                 ptr(out), stream_ptr())
+            if want_cand:
+                cand_out = (torch.empty(B, N, int(nsample), dtype=torch.int32, device=pts.device),
+                            torch.empty(B, N, dtype=torch.int32, device=pts.device))
+            ci = cand_in if cand_in is not None else (None, None)
+            assert ci[0] is None or (ci[0].is_contiguous() and ci[0].shape[:2] == (B, N) and ci[1].shape == (B, N))
+            call("unopose_pe_group_mlp_max_packed_cand", ptr(pts), B, N, float(radius), int(nsample), ptr(cache[2]),
+                 None if ci[0] is None else ptr(ci[0]), None if ci[0] is None else ptr(ci[1]),
+                 0 if ci[0] is None else int(ci[0].shape[2]), None if cand_out is None else ptr(cand_out[0]),
+                 None if cand_out is None else ptr(cand_out[1]), ptr(out), stream_ptr())
         else:
             call("unopose_pe_group_mlp_max", ptr(pts), B, N, float(radius), int(nsample), ptr(w1), ptr(b1), ptr(w2),
                  ptr(b2), ptr(w3), ptr(b3), 0, ptr(out), stream_ptr())
-    return out
+    return (out, cand_out) if want_cand else out
 
 
 def pe_group_mlp_max_unfused(pts, radius, nsample, mlp, chunk=4):
