@@ -158,10 +158,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # UNOPOSE_BENCH_BACKEND=gloo is a TEST hook: it lets the N>1 code path run with several ranks sharing one
+    # GPU (collectives staged through host memory); the driver's runs use the default, RCCL over xGMI.
+    backend = os.environ.get("UNOPOSE_BENCH_BACKEND", "nccl")
+    local = local if backend == "nccl" else local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from unopose_amd.model import UNOPose, default_model_cfg
     from unopose_amd.synthetic import make_batch, trained_like_
@@ -190,8 +198,7 @@ def main():
         if graphed is not None:  # inputs copied into the graph's static buffers, one hipGraphLaunch
             return graphed(ep)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            out = model(ep)
-        return out
+            return model(ep)
 
     for _ in range(args.warmup):
         out = step()
@@ -204,6 +211,7 @@ def main():
         out = step()
     poses = torch.cat([out["pred_R"].reshape(B, 9), out["pred_t"], out["pred_pose_score"].reshape(B, 1)], 1)
     if world > 1:  # gather of poses to rank 0 (the reference lacks it: every rank writes the same file)
+        poses = poses.to(comm_dev)
         gathered = [torch.empty_like(poses) for _ in range(world)] if rank == 0 else None
         dist.gather(poses, gathered, 0)
     torch.cuda.synchronize()
@@ -212,7 +220,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
 

@@ -156,7 +156,12 @@ def broadcast_module_(module, src=0):
     if not tensors:
         return module
     flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
-    dist.broadcast(flat, src)
+    if flat.is_cuda and dist.get_backend() != "nccl":  # host-memory backends (gloo in the tests)
+        host = flat.cpu()
+        dist.broadcast(host, src)
+        flat = host.to(flat.device)
+    else:
+        dist.broadcast(flat, src)
     off = 0
     for t in tensors:
         n = t.numel()
