@@ -160,6 +160,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # UNOPOSE_BENCH_BACKEND=gloo is a TEST hook: it lets the N>1 code path run with several ranks sharing one
     # GPU (collectives staged through host memory); the driver's runs use the default, RCCL over xGMI.
+    # Keep such shared-GPU runs short and at --img 224: concurrent stream-K library GEMMs of two processes can
+    # starve each other's workgroups.
     backend = os.environ.get("UNOPOSE_BENCH_BACKEND", "nccl")
     local = local if backend == "nccl" else local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
