@@ -14,6 +14,7 @@ from .modules import (GeometricStructureEmbedding, GeometricTransformer, Positio
 
 
 STACKED_FINE = os.environ.get("UNOPOSE_STACKED_FINE", "1") == "1"  # A/B switch for the 2B-stacked fine matcher
+PE_UNDER_COARSE = os.environ.get("UNOPOSE_PE_UNDER_COARSE", "1") == "1"  # A/B switch, see UNOPose.forward
 
 
 def _scores(scores, n1):
@@ -74,7 +75,7 @@ class FinePointMatchingOneRef(nn.Module):
         self.transformers = nn.ModuleList(
             [SparseToDenseTransformer(d, 4, cfg.focusing_factor) for _ in range(self.nblock)])
 
-    def forward(self, p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points):
+    def forward(self, p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points, pe2=None):
         if self.training:
             raise NotImplementedError("training path is out of scope (SURVEY.md 8(f-4))")
         B, n1 = p1.shape[:2]
@@ -87,7 +88,8 @@ class FinePointMatchingOneRef(nn.Module):
                 and fps_idx1.shape == fps_idx2.shape):
             # both clouds as ONE batch of 2B through PE, in_proj and the three blocks; the background token
             # rides beside the dense features and is put in front only once, at the end
-            pe = self.PE(torch.cat([p1_, p2], 0))
+            # pe2: the reference cloud's encoding when UNOPose.forward already computed it under the coarse stage
+            pe = self.PE(torch.cat([p1_, p2], 0)) if pe2 is None else torch.cat([self.PE(p1_), pe2], 0)
             d = ops.linear(f_all if f_all is not None else torch.cat([f1, f2], 0), self.in_proj)
             d = d + pe.to(d.dtype)
             bg = self.bg_token.expand(2 * B, -1, -1).to(d.dtype)
@@ -232,12 +234,27 @@ class UNOPose(nn.Module):
         geo = self.geo_embedding(torch.cat([torch.cat([bg_point, sparse_pm_lrf], dim=1),
                                             torch.cat([bg_point, sparse_po_lrf], dim=1)], dim=0))
         geo_m, geo_o = geo[:B], geo[B:]
+        # The reference cloud's positional encoding (Fi:77-80) does not depend on the coarse pose: it runs on
+        # the side stream UNDER the coarse stage, whose 197-token kernels and hypothesis search are latency-
+        # bound and leave most CUs idle (the PE kernel has no inter-workgroup waits, so sharing the GPU with
+        # the coarse stage's small library GEMMs is safe -- DESIGN.md section 7).
+        pe2 = None
+        if (PE_UNDER_COARSE and not self.test_coarse_only and dense_pm.is_cuda and torch.is_autocast_enabled()
+                and dense_pm.shape == dense_po.shape):
+            main = torch.cuda.current_stream()
+            side = self._side_stream(dense_po.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pe2 = self.fine_point_matching.PE(dense_po)
+                pe2.record_stream(main)
         end_points = self.coarse_point_matching(sparse_pm, sparse_fm, geo_m, sparse_po, sparse_fo, geo_o, radius,
                                                 end_points)
+        if pe2 is not None:
+            torch.cuda.current_stream().wait_stream(self._side_stream(dense_po.device))
         if self.test_coarse_only:
             end_points["pred_R"] = end_points["init_R"]
             end_points["pred_t"] = end_points["init_t"] * (radius.reshape(-1, 1) + 1e-6)
             end_points["pred_pose_score"] = end_points["init_pose_score"]
             return end_points
         return self.fine_point_matching(dense_pm, dense_fm, geo_m, fps_idx_m, dense_po, dense_fo, geo_o, fps_idx_o,
-                                        radius, end_points)
+                                        radius, end_points, pe2=pe2)
