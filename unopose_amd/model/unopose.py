@@ -15,6 +15,7 @@ from .modules import (GeometricStructureEmbedding, GeometricTransformer, Positio
 
 STACKED_FINE = os.environ.get("UNOPOSE_STACKED_FINE", "1") == "1"  # A/B switch for the 2B-stacked fine matcher
 PE_UNDER_COARSE = os.environ.get("UNOPOSE_PE_UNDER_COARSE", "1") == "1"  # A/B switch, see UNOPose.forward
+GEOM_UNDER_VIT = int(os.environ.get("UNOPOSE_GEOM_UNDER_VIT", "1"))  # 1: LRF / FPS-196 / gathers, 2: + embedding
 
 
 def _scores(scores, n1):
@@ -171,6 +172,25 @@ class UNOPose(nn.Module):
             sel_choose = torch.gather(tem_choose, 1, idx_o.long())
             for t in (idx_o, dense_po, sel_choose):
                 t.record_stream(main)
+            if GEOM_UNDER_VIT:
+                # the other latency-bound, feature-independent steps ride along: both global LRFs, the two
+                # 2048->196 FPS chains and the gathers of points / frame coordinates (M:28-47)
+                pre = {}
+                pm_lrf = ops.lrf_global(end_points["pts"], self.use_ref_rad)
+                po_lrf = ops.lrf_global(tem_pts, self.use_ref_rad)  # NB App-E.1: full 5000-point cloud
+                pre["idx_m"] = ops.furthest_point_sample(dense_pm, self.coarse_npoint)
+                pre["idx_o"] = ops.furthest_point_sample(dense_po, self.coarse_npoint)
+                pre["sparse_pm"] = ops.gather_rows(dense_pm.float(), pre["idx_m"])
+                pre["sparse_po"] = ops.gather_rows(dense_po.float(), pre["idx_o"])
+                pre["sparse_pm_lrf"] = ops.gather_rows(pm_lrf, pre["idx_m"])
+                pre["sparse_po_lrf"] = ops.gather_rows(po_lrf, pre["idx_o"])
+                if GEOM_UNDER_VIT > 1:
+                    bg_point = torch.ones(dense_pm.size(0), 1, 3, device=dense_pm.device)
+                    pre["geo"] = self.geo_embedding(torch.cat([torch.cat([bg_point, pre["sparse_pm_lrf"]], dim=1),
+                                                               torch.cat([bg_point, pre["sparse_po_lrf"]], dim=1)], dim=0))
+                for t in pre.values():
+                    t.record_stream(main)
+                self._pre = pre
         # both crops through the ViT as ONE batch of 2B images
         B = rgb.shape[0]
         z, (H, W), off = net.upprojected_tokens(torch.cat([rgb, tem_rgb], 0))
@@ -215,7 +235,11 @@ class UNOPose(nn.Module):
     def forward(self, end_points):
         if self.training:
             raise NotImplementedError("training path is out of scope (SURVEY.md 8(f-4))")
+        self._pre = None
         dense_pm, dense_fm, dense_po, dense_fo, radius = self._features(end_points)
+        pre, self._pre = self._pre, None
+        if pre is not None:
+            return self._forward_from(pre, end_points, dense_pm, dense_fm, dense_po, dense_fo, radius)
         dense_pm_lrf = ops.lrf_global(end_points["pts"], self.use_ref_rad)
         # NB (App-E.1): LRF of the FULL tem1 cloud (5000 rows) gathered below with indices into the
         # FPS-2048 subset, exactly as the reference does (M:30, U:167-171).
@@ -230,9 +254,33 @@ class UNOPose(nn.Module):
                                                                          self.coarse_npoint)
         sparse_po, sparse_po_lrf, sparse_fo, fps_idx_o = self._sample_wlrf(dense_po, dense_po_lrf, dense_fo,
                                                                          self.coarse_npoint)
+        pre = dict(idx_m=fps_idx_m, idx_o=fps_idx_o, sparse_pm=sparse_pm, sparse_po=sparse_po,
+                   sparse_pm_lrf=sparse_pm_lrf, sparse_po_lrf=sparse_po_lrf, sparse_fm=sparse_fm, sparse_fo=sparse_fo)
+        return self._forward_from(pre, end_points, dense_pm, dense_fm, dense_po, dense_fo, radius)
+
+    def _forward_from(self, pre, end_points, dense_pm, dense_fm, dense_po, dense_fo, radius):
+        """Coarse + fine stages given the sparse subsets (computed inline or ahead on the side stream)."""
+        B = dense_pm.size(0)
+        bg_point = torch.ones(B, 1, 3, device=dense_pm.device)
+        fps_idx_m, fps_idx_o = pre["idx_m"], pre["idx_o"]
+        sparse_pm, sparse_po, sparse_pm_lrf, sparse_po_lrf = (pre[k] for k in ("sparse_pm", "sparse_po", "sparse_pm_lrf",
+                                                                                  "sparse_po_lrf"))
+        sparse_fm = pre["sparse_fm"] if "sparse_fm" in pre else ops.gather_rows(dense_fm, fps_idx_m)
+        sparse_fo = pre["sparse_fo"] if "sparse_fo" in pre else ops.gather_rows(dense_fo, fps_idx_o)
+        if "geo" in pre:
+            geo = pre["geo"]
+        else:
+            geo = self._geo(bg_point, sparse_pm_lrf, sparse_po_lrf)
+        return self._matching(end_points, geo, B, sparse_pm, sparse_fm, sparse_po, sparse_fo, fps_idx_m, fps_idx_o,
+                              dense_pm, dense_fm, dense_po, dense_fo, radius)
+
+    def _geo(self, bg_point, sparse_pm_lrf, sparse_po_lrf):
         # both clouds' embeddings from ONE launch into ONE buffer (the RPE self layers then run 2B at once)
-        geo = self.geo_embedding(torch.cat([torch.cat([bg_point, sparse_pm_lrf], dim=1),
-                                            torch.cat([bg_point, sparse_po_lrf], dim=1)], dim=0))
+        return self.geo_embedding(torch.cat([torch.cat([bg_point, sparse_pm_lrf], dim=1),
+                                             torch.cat([bg_point, sparse_po_lrf], dim=1)], dim=0))
+
+    def _matching(self, end_points, geo, B, sparse_pm, sparse_fm, sparse_po, sparse_fo, fps_idx_m, fps_idx_o, dense_pm,
+                  dense_fm, dense_po, dense_fo, radius):
         geo_m, geo_o = geo[:B], geo[B:]
         # The reference cloud's positional encoding (Fi:77-80) does not depend on the coarse pose: it runs on
         # the side stream UNDER the coarse stage, whose 197-token kernels and hypothesis search are latency-
