@@ -1,31 +1,35 @@
 """bench.py -- (query,ref) pairs/s of UNOPose.forward on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--batch 32] [--img 224] [--dtype bf16|fp32]
+    python bench.py --gpus N --steps K --warmup W [--batch 32] [--img 518] [--dtype bf16|fp32]
 
 A "step" is one UNOPose.forward over a batch of B synthetic (query,ref) pairs already resident in HBM
 (BASELINE configs[1]: batch 32, 2048 query points, 5000->2048 reference points, 518x518 crops; the
-reference's own 224x224 contract with --img 224).  N>1: one process per GPU (torchrun / RCCL), each rank owns its
-own B pairs (the ref-target list shards embarrassingly: weak scaling), weights are broadcast from rank 0
-once, poses are gathered to rank 0 at the end of the timed region.
-Prints ONE JSON line on rank 0.
+reference's own 224x224 contract with --img 224).
+
+N > 1: one process per GPU over RCCL.  Launched either by the driver's
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (RANK / LOCAL_RANK / WORLD_SIZE in
+the environment) or directly as ``python bench.py --gpus N``: then THIS process touches no GPU, starts the N
+ranks as child processes (fresh interpreters, never an exec of a process that has initialised HIP) and exits
+with their status.  Each rank owns its own B pairs (the ref-target list shards embarrassingly: weak scaling,
+`runner.shard_range` = the reference's InferenceSampler rule), weights are broadcast from rank 0 once, poses
+are gathered to rank 0 at the end of the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--img", type=int, default=518,
@@ -35,12 +39,44 @@ def parse():
                     "the step is GPU-bound, not launch-bound, at every batch size measured)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-fp32", action="store_true", help="skip the extra fp32 (reference default precision) leg")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="TEST HOOK (tests/test_bench_cpu.py): replace the model step by a host stub so that the launch / "
+                         "rendezvous / barrier / gather / JSON path runs without a GPU (backend gloo); never a measurement")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks as children BEFORE anything touches the GPU
+# ------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """Start `n` fresh interpreters of this script, one per GPU, with the torchrun environment contract
+    (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT); rank 0 inherits stdout (the JSON line).
+    Returns the worst exit code.  The parent has not initialised HIP (argparse + subprocess only)."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def hip_event_time(fn, iters, stream):
     """Average duration (s) of `fn` measured with events recorded on `stream` (the stream the kernels
     are launched on)."""
+    import torch
+
     with torch.cuda.stream(stream):
         fn()
         stream.synchronize()
@@ -57,8 +93,10 @@ def hip_event_time(fn, iters, stream):
 def roofline_leg(model, batch, img):
     """Roofline of the dominant hand-written kernel of the step, timed live with HIP events on the stream
     it runs on: the ViT patch attention at 518x518 crops (12 launches = the largest share of the step
-    after the library GEMMs), the fused positional-encoding kernel (S=256 launch) at 224x224.  The other
+    after the GEMMs), the fused positional-encoding kernel (S=256 launch) at 224x224.  The other
     rows BASELINE's north star prices follow in `roofline_other`.  Work models: DESIGN.md section 4."""
+    import torch
+
     from unopose_amd import ops
     from unopose_amd.pointnet2 import _ext
 
@@ -87,6 +125,21 @@ def roofline_leg(model, batch, img):
     vit = row("vit_attn_kernel(T=%d)" % T, "mfma", 2.0 * B * 12 * 4.0 * T * T * 64, 1e12, 2500.0, "TFLOP/s", t,
               "QK^T + PV flops; softmax exp/sum VALU work shares the issue port with the matrix core")
     del qkv
+    # the ViT linears (the largest share of the step): the four shapes of one block, bf16, M = 2B x T rows
+    M = 2 * B * T
+    for name, K_, N_, gelu in (("qkv", 768, 2304, False), ("proj", 768, 768, False), ("fc1", 768, 3072, True),
+                               ("fc2", 3072, 768, False)):
+        a = torch.randn(M, K_, device=x.device).bfloat16()
+        lin = torch.nn.Linear(K_, N_).to(x.device)
+
+        def f():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return ops.linear(a, lin, gelu=True) if gelu else ops.linear(a, lin)
+
+        t = hip_event_time(f, 10, stream)
+        row("vit_linear_%s(M=%d,K=%d,N=%d%s)" % (name, M, K_, N_, ",+bias+GELU" if gelu else ""), "mfma",
+            2.0 * M * K_ * N_, 1e12, 2500.0, "TFLOP/s", t, ops.linear_backend())
+        del a, lin
     # PE, S=256, bf16 hi/lo-split matrix cores; 20864 flop per neighbour row
     t = hip_event_time(lambda: ops.pe_group_mlp_max(x, pe.r2, pe.ns2, pe.mlp2, bf16x3=True), 10, stream)
     dom = row("pe_group_mlp_max_bf16x3_kernel(S=%d)" % pe.ns2, "mfma", B * N * pe.ns2 * 20864.0, 1e12, 2500.0,
@@ -121,105 +174,167 @@ def roofline_leg(model, batch, img):
 
 
 def _pmc_traffic(kernel, B):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_summary.json: FETCH_SIZE and
+    """HBM bytes per launch from the committed PMC passes (profiles/r0N_pmc_summary.json: FETCH_SIZE and
     WRITE_SIZE collected in separate rocprofv3 runs at B=32, FETCH_SIZE doubled per the gfx950 note);
     null when the batch differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if B != 32 or not os.path.exists(path):
-        return None
-    k = json.load(open(path))["kernels"].get(kernel)
-    return None if k is None else dict(hbm_bytes_per_launch=k["hbm_bytes_per_launch"], source="profiles/r01_pmc_summary.json")
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd + "_pmc_summary.json")
+        if B == 32 and os.path.exists(path):
+            k = json.load(open(path))["kernels"].get(kernel)
+            if k is not None:
+                return dict(hbm_bytes_per_launch=k["hbm_bytes_per_launch"], source="profiles/%s_pmc_summary.json" % rnd)
+    return None
 
 
-def cpu_baseline_leg(img):
-    """The oracle (torch-CPU port of the reference forward + the C `_ext` port) timed on this host's
-    cores on a bounded sample: ONE pair at the workload's shapes, one forward."""
+def _cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_leg(img, batches=(1, 8), timed=3):
+    """The oracle (torch-CPU port of the reference forward + the C `_ext` port; kind "port": the reference's
+    Python cannot travel) timed on this host's cores on a bounded sample of the same workload
+    (SURVEY.md 8(d)): per batch size one warm-up forward, then `timed` timed forwards; value = the best
+    batch size's median rate."""
+    import torch
+
     from oracle import unopose_ref as R
     from oracle.pointnet2_oracle import ext as oext
-    from unopose_amd.synthetic import congruent_pair
+    from unopose_amd.synthetic import make_batch
 
-    torch.set_num_threads(min(32, os.cpu_count()))
-    g = torch.Generator().manual_seed(1)
-    ep, _, _ = congruent_pair(g, 2048, 5000, img, 5e-4)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
     cfg = R.default_cfg()
     sd = R.random_state_dict(cfg, seed=0, img_size=img, tame=0.1)
-    rand = torch.rand(1, 18000, generator=g)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        R.unopose_forward(ep, sd, cfg, rand, oext)
-    dt = time.perf_counter() - t0
-    return dict(value=1.0 / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 pair (2048 query / 5000 reference points, {img}x{img} crops), 1 forward, fp32, "
-                       f"torch {torch.get_num_threads()} threads + C `_ext` port")
+    by_batch = {}
+    for b in batches:
+        ep, _, _ = make_batch(b, 2048, 5000, img, seed=1)
+        rand = torch.rand(b, 18000, generator=torch.Generator().manual_seed(2))
+        times = []
+        with torch.no_grad():
+            for i in range(1 + timed):
+                t0 = time.perf_counter()
+                R.unopose_forward(ep, sd, cfg, rand, oext)
+                if i:
+                    times.append(time.perf_counter() - t0)
+        times.sort()
+        med = times[len(times) // 2]
+        by_batch[str(b)] = dict(pairs_per_s=b / med, median_s=med, min_s=times[0], max_s=times[-1], timed=timed, warmup=1)
+    best = max(by_batch.values(), key=lambda r: r["pairs_per_s"])
+    return dict(value=best["pairs_per_s"], unit="pairs/s", cores=threads, kind="port", cpu_model=_cpu_model_name(),
+                by_batch=by_batch,
+                sample=f"batches of {list(batches)} pairs (2048 query / 5000 reference points, {img}x{img} crops), 1 warm-up + "
+                       f"{timed} timed forwards each, fp32, torch {threads} threads + C `_ext` port; value = best median")
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))  # nothing above has touched the GPU
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
+
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # UNOPOSE_BENCH_BACKEND=gloo is a TEST hook: it lets the N>1 code path run with several ranks sharing one
     # GPU (collectives staged through host memory); the driver's runs use the default, RCCL over xGMI.
     # Keep such shared-GPU runs short and at --img 224: concurrent stream-K library GEMMs of two processes can
     # starve each other's workgroups (DESIGN.md section 7).
-    backend = os.environ.get("UNOPOSE_BENCH_BACKEND", "nccl")
-    local = local if backend == "nccl" else local % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    comm_dev = dev if backend == "nccl" else torch.device("cpu")
+    backend = "gloo" if args.dry_run else os.environ.get("UNOPOSE_BENCH_BACKEND", "nccl")
+    if args.dry_run:
+        dev = comm_dev = torch.device("cpu")
+    else:
+        local = local if backend == "nccl" else local % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        comm_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         else:
             dist.init_process_group(backend)
 
-    from unopose_amd.model import UNOPose, default_model_cfg
-    from unopose_amd.synthetic import make_batch, trained_like_
+    def sync():
+        if not args.dry_run:
+            torch.cuda.synchronize()
 
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
-    cfg = default_model_cfg(feature_extraction=dict(img_size=args.img))
-    model = trained_like_(UNOPose(cfg)).to(dev).eval()
+    B = args.batch
+    amp = args.dtype == "bf16"
+    if args.dry_run:
+        model = torch.nn.Linear(9, 9)
+        R_gt = torch.eye(3).expand(B, 3, 3).contiguous()
+        batch = {"pts": torch.zeros(B, 8, 3)}
+
+        def forward(ep, use_amp):
+            ep.update(pred_R=R_gt + 0 * model.weight.sum(), pred_t=torch.zeros(B, 3), pred_pose_score=torch.ones(B))
+            return ep
+    else:
+        from unopose_amd.model import UNOPose, default_model_cfg
+        from unopose_amd.synthetic import make_batch, trained_like_
+
+        cfg = default_model_cfg(feature_extraction=dict(img_size=args.img))
+        model = trained_like_(UNOPose(cfg)).to(dev).eval()
+        batch, R_gt, t_gt = make_batch(B, 2048, 5000, args.img, seed=100 + rank, device=dev)
+        batch["coarse_rand"] = torch.rand(B, 18000, device=dev)
+
+        def forward(ep, use_amp):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_amp):
+                return model(ep)
     if world > 1:  # one flat broadcast of the weights from rank 0 over RCCL / xGMI (SURVEY.md 8(e))
         from unopose_amd.runner import broadcast_module_
 
         broadcast_module_(model, 0)
-    B = args.batch
-    batch, R_gt, t_gt = make_batch(B, 2048, 5000, args.img, seed=100 + rank, device=dev)
-    batch["coarse_rand"] = torch.rand(B, 18000, device=dev)
-    amp = args.dtype == "bf16"
 
     graphed = None
-    if args.graph:
+    if args.graph and not args.dry_run:
         from unopose_amd.graph import GraphedForward
 
         graphed = GraphedForward(model, batch, torch.bfloat16 if amp else None)
 
-    def step():
+    def step(use_amp=amp):
         ep = dict(batch)
         if graphed is not None:  # inputs copied into the graph's static buffers, one hipGraphLaunch
             return graphed(ep)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            return model(ep)
+        return forward(ep, use_amp)
 
     for _ in range(args.warmup):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
+    # per-step HIP events on the launch stream (median / p10 / p90); `value` keeps the contract's wall clock
+    evs = None
+    if not args.dry_run:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if evs is not None:
+            evs[i].record()
         out = step()
+    if evs is not None:
+        evs[-1].record()
     poses = torch.cat([out["pred_R"].reshape(B, 9), out["pred_t"], out["pred_pose_score"].reshape(B, 1)], 1)
     if world > 1:  # gather of poses to rank 0 (the reference lacks it: every rank writes the same file)
         poses = poses.to(comm_dev)
         gathered = [torch.empty_like(poses) for _ in range(world)] if rank == 0 else None
         dist.gather(poses, gathered, 0)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
@@ -244,17 +359,37 @@ def main():
                                f"196 coarse pts, {args.img}x{args.img} crops, DINOv2 ViT-B/14 reg4, "
                                f"random-init (trained-like) weights",
                    "sharding": f"dp{world} (independent pairs, weights broadcast, poses gathered)"},
-        "launch": "hipGraph replay" if args.graph else "eager",
+        "launch": "hipGraph replay" if graphed is not None else "eager",
         "sanity": {"median_rot_err_vs_gt": rot_err.median().item(),
                    "frac_pairs_solved(<0.05)": (rot_err < 0.05).float().mean().item()},
     }
-    if rank == 0 and world == 1:
+    if args.dry_run:
+        res["dry_run"] = True
+    if evs is not None:
+        ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+        q = lambda f: ms[min(len(ms) - 1, int(round(f * (len(ms) - 1))))]  # noqa: E731
+        res["step_ms_hip_events"] = {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "min": ms[0], "max": ms[-1],
+                                     "pairs_per_s_at_median": world * B / q(0.5) * 1e3}
+    if rank == 0 and world == 1 and not args.dry_run:
+        if amp and not args.no_fp32 and graphed is None:
+            # the reference's default precision (configs/main_cfg.py:87-89: test.amp.enabled=False)
+            k = max(3, min(args.steps, 5))
+            step(False)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(k):
+                o32 = step(False)
+            sync()
+            d32 = time.perf_counter() - t1
+            e32 = (o32["pred_R"] - R_gt).abs().amax(dim=(1, 2))
+            res["fp32"] = {"value": B * k / d32, "unit": "pairs/s", "ms_per_step": d32 / k * 1e3, "steps": k,
+                           "median_rot_err_vs_gt": e32.median().item()}
         if not args.no_roofline:
             res.update(roofline_leg(model, batch, args.img))
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_leg(args.img)
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -31,7 +31,7 @@ class T:
 def run(model, ep, t):
     m = model
     t.mark("start")
-    dense_pm, dense_fm, dense_po, dense_fo, radius = m._features(ep)
+    dense_pm, dense_fm, dense_po, dense_fo, radius, _ = m._features(ep)
     t.mark("features(ViT+FPS5000)")
     pm_lrf = ops.lrf_global(ep["pts"])
     po_lrf = ops.lrf_global(ep["tem1_pts"])

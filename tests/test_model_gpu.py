@@ -493,7 +493,7 @@ def test_forward_variants(tamed):
         model.test_coarse_only = False
     assert err(co["pred_R"], full["init_R"]) < 1e-6 and err(co["pred_pose_score"], full["init_pose_score"]) < 1e-6
     # precomputed reference: un-normalised FPS-2048 subset + its features
-    _, _, dense_po, dense_fo, radius = model._features(dict(ep))
+    _, _, dense_po, dense_fo, radius, _ = model._features(dict(ep))
     ep2 = {k: ep[k] for k in ("pts", "rgb", "rgb_choose", "tem1_pts", "coarse_rand")}
     ep2["dense_po"] = dense_po * (radius.reshape(-1, 1, 1) + 1e-6)
     ep2["dense_fo"] = dense_fo

@@ -88,3 +88,71 @@ def test_two_rank_gloo_run_equals_single_process():
         mp.spawn(_worker, args=(2, 29517, multi), nprocs=2, join=True)
         assert _strip_time(open(multi).readlines()) == _strip_time(open(single).readlines())
         assert os.path.exists(multi.replace(".csv", ".json"))
+
+
+class _StubEncoder:
+    """encode_reference stand-in: features are a function of the view alone; counts encodes."""
+
+    def __init__(self):
+        self.calls = 0
+
+    def encode_reference(self, rgb, choose, pts):
+        self.calls += rgb.shape[0]
+        return dict(ref_dense_po=pts * 2, ref_dense_fo=pts + 1, ref_radius=pts.sum(dim=(1, 2)), ref_lrf=pts - 1)
+
+
+def test_reference_cache_is_lru_and_never_evicts_the_current_batch():
+    """max_items smaller than the number of distinct views (the FIFO of round 1 raised KeyError here)."""
+    enc = _StubEncoder()
+    cache = runner.ReferenceCache(enc, max_items=2)
+    views = {k: torch.full((4, 3), float(i)) for i, k in enumerate("ABCDE")}
+
+    def look(keys):
+        pts = torch.stack([views[k] for k in keys])
+        out = cache.lookup(list(keys), pts, pts, pts)
+        assert torch.equal(out["ref_dense_po"], pts * 2) and torch.equal(out["ref_radius"], pts.sum(dim=(1, 2)))
+        assert len(cache.store) <= 2
+
+    look("AB")
+    assert enc.calls == 2
+    look("AC")  # C is encoded while A (needed by this very call) is the oldest entry
+    assert enc.calls == 3 and set(cache.store) == {"A", "C"}  # B, least recently used, went
+    look("A")
+    look("D")  # evicts C (A was refreshed by the hit)
+    assert set(cache.store) == {"A", "D"} and enc.calls == 4
+    look("ABCDE")  # a batch with more distinct views than the cache holds still resolves
+    assert enc.calls == 7 and (cache.hits, cache.misses) == (1 + 1 + 2, 7)
+    # entries own their memory (an eviction frees it): not views into the encoder's batch tensor
+    e = next(iter(cache.store.values()))["ref_dense_po"]
+    assert e.untyped_storage().nbytes() == e.numel() * e.element_size()
+
+
+def test_detections_json_keeps_the_reference_layout():
+    """oneref_inference_utils_v1.py:31,112-113,134: deep copy of dataset.dets (lists of full detection dicts,
+    filtered detections included) + pred_R / pred_t on the entries `inst_ids` names."""
+    import json
+
+    imgs = _images(3)
+    dets = {}
+    for im in imgs:
+        n = im["pts"].shape[1]
+        key = f"{im['scene_id']:06d}_{im['img_id']:06d}"
+        dets[key] = [dict(scene_id=im["scene_id"], image_id=im["img_id"], category_id=5, score=0.5, bbox=[1, 2, 3, 4],
+                          time=0.1, segmentation={"size": [4, 4], "counts": [16]}) for _ in range(n + 2)]
+        im["inst_ids"] = torch.arange(1, n + 1)[None]  # detection 0 and the last one were filtered out
+
+    class _Set(list):
+        pass
+
+    data = _Set(imgs)
+    data.dets = dets
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "r.csv")
+        runner.inference_and_save(_StubModel(), data, path, 16)
+        out = json.load(open(path.replace(".csv", ".json")))
+    assert set(out) == set(dets) and "pred_R" not in dets[next(iter(dets))][1]  # the input is not mutated
+    for key, lst in out.items():
+        assert len(lst) == len(dets[key])
+        assert "pred_R" not in lst[0] and "pred_R" not in lst[-1] and lst[0]["bbox"] == [1, 2, 3, 4]
+        for det in lst[1:-1]:
+            assert len(det["pred_R"]) == 9 and len(det["pred_t"]) == 3 and det["segmentation"]["counts"] == [16]

@@ -43,7 +43,7 @@ class _Mlp(nn.Module):
         self.fc2 = nn.Linear(ratio * dim, dim)
 
     def forward(self, x):
-        return ops.linear(F.gelu(ops.linear(x, self.fc1)), self.fc2)
+        return ops.linear(ops.linear(x, self.fc1, gelu=True), self.fc2)
 
 
 class _Block(nn.Module):
@@ -474,7 +474,9 @@ class PositionalEncoding(nn.Module):
         self.mlp2 = _SharedMLP([6, 32, 64, 128])
         self.mlp3 = _Conv1d(256, out_dim)
 
-    def forward(self, pts):
+    def groups(self, pts):
+        """Both scales' grouped features, max-pooled: (B,N,3) -> (B,N,256) fp32 = [scale 1 | scale 2].  Only the two
+        fused HIP launches (no library GEMM, no inter-workgroup waits), so it may run on a side stream."""
         pts = pts.float()
         if pts.is_cuda and torch.is_autocast_enabled() and self.r2 >= self.r1 and self.ns1 % 32 == 0 and self.ns2 % 32 == 0:
             # the wide scale first: its neighbour lists are the candidates of the narrow scale (csrc/pe.hip)
@@ -483,7 +485,13 @@ class PositionalEncoding(nn.Module):
         else:
             f1 = ops.pe_group_mlp_max(pts, self.r1, self.ns1, self.mlp1)  # (B,N,128)
             f2 = ops.pe_group_mlp_max(pts, self.r2, self.ns2, self.mlp2)
-        feat = torch.cat([f1, f2], dim=2).float()
+        return torch.cat([f1, f2], dim=2).float()
+
+    def project(self, feat):
+        """mlp3 (Conv1d 256 -> out_dim, bias) on the concatenated scales; a library GEMM -> main stream only."""
         w = self.mlp3.conv.weight.reshape(self.mlp3.conv.weight.shape[0], -1)
         with torch.autocast("cuda", enabled=False):  # Fi:163-165 forces fp32 for the whole PE
             return F.linear(feat, w.float(), self.mlp3.conv.bias.float())
+
+    def forward(self, pts):
+        return self.project(self.groups(pts))

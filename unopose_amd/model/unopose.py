@@ -76,7 +76,7 @@ class FinePointMatchingOneRef(nn.Module):
         self.transformers = nn.ModuleList(
             [SparseToDenseTransformer(d, 4, cfg.focusing_factor) for _ in range(self.nblock)])
 
-    def forward(self, p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points, pe2=None):
+    def forward(self, p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points, pe2_groups=None):
         if self.training:
             raise NotImplementedError("training path is out of scope (SURVEY.md 8(f-4))")
         B, n1 = p1.shape[:2]
@@ -89,8 +89,10 @@ class FinePointMatchingOneRef(nn.Module):
                 and fps_idx1.shape == fps_idx2.shape):
             # both clouds as ONE batch of 2B through PE, in_proj and the three blocks; the background token
             # rides beside the dense features and is put in front only once, at the end
-            # pe2: the reference cloud's encoding when UNOPose.forward already computed it under the coarse stage
-            pe = self.PE(torch.cat([p1_, p2], 0)) if pe2 is None else torch.cat([self.PE(p1_), pe2], 0)
+            # pe2_groups: the reference cloud's grouped features (PE before mlp3) when UNOPose.forward already
+            # computed them under the coarse stage; mlp3 then runs HERE, on the main stream, as one 2B GEMM
+            pe = self.PE(torch.cat([p1_, p2], 0)) if pe2_groups is None else \
+                self.PE.project(torch.cat([self.PE.groups(p1_), pe2_groups], 0))
             d = ops.linear(f_all if f_all is not None else torch.cat([f1, f2], 0), self.in_proj)
             d = d + pe.to(d.dtype)
             bg = self.bg_token.expand(2 * B, -1, -1).to(d.dtype)
@@ -152,11 +154,11 @@ class UNOPose(nn.Module):
             radius = torch.norm(dense_po - dense_po.mean(1, keepdim=True), dim=2).max(1)[0]
             dense_pm = dense_pm / (radius.reshape(-1, 1, 1) + 1e-6)
             dense_po = dense_po / (radius.reshape(-1, 1, 1) + 1e-6)
-            return dense_pm, dense_fm, dense_po, dense_fo, radius
+            return dense_pm, dense_fm, dense_po, dense_fo, radius, None
         if "ref_dense_po" in end_points:  # encode_reference() output: same numbers as the full path below
             radius = end_points["ref_radius"]
             dense_pm = dense_pm / (radius.reshape(-1, 1, 1) + 1e-6)
-            return dense_pm, net.pixel_features(rgb, choose), end_points["ref_dense_po"], end_points["ref_dense_fo"], radius
+            return dense_pm, net.pixel_features(rgb, choose), end_points["ref_dense_po"], end_points["ref_dense_fo"], radius, None
         tem_rgb, tem_choose, tem_pts = end_points["tem1_rgb"], end_points["tem1_choose"], end_points["tem1_pts"]
         radius = torch.norm(tem_pts - tem_pts.mean(1, keepdim=True), dim=2).max(1)[0]
         dense_pm = dense_pm / (radius.reshape(-1, 1, 1) + 1e-6)
@@ -172,6 +174,7 @@ class UNOPose(nn.Module):
             sel_choose = torch.gather(tem_choose, 1, idx_o.long())
             for t in (idx_o, dense_po, sel_choose):
                 t.record_stream(main)
+            pre = None
             if GEOM_UNDER_VIT:
                 # the other latency-bound, feature-independent steps ride along: both global LRFs, the two
                 # 2048->196 FPS chains and the gathers of points / frame coordinates (M:28-47)
@@ -190,7 +193,6 @@ class UNOPose(nn.Module):
                                                                torch.cat([bg_point, pre["sparse_po_lrf"]], dim=1)], dim=0))
                 for t in pre.values():
                     t.record_stream(main)
-                self._pre = pre
         # both crops through the ViT as ONE batch of 2B images
         B = rgb.shape[0]
         z, (H, W), off = net.upprojected_tokens(torch.cat([rgb, tem_rgb], 0))
@@ -201,7 +203,7 @@ class UNOPose(nn.Module):
         main.wait_stream(side)
         # only the FPS-selected reference pixels are ever interpolated (gather commutes with sampling)
         dense_fo = ops.bilinear_sample_native(z[B:], sel_choose, H, W, out=None if both is None else both[B:], tok_offset=off)
-        return dense_pm, dense_fm, dense_po, dense_fo, radius
+        return dense_pm, dense_fm, dense_po, dense_fo, radius, pre
 
     @torch.no_grad()
     def encode_reference(self, tem1_rgb, tem1_choose, tem1_pts):
@@ -235,9 +237,7 @@ class UNOPose(nn.Module):
     def forward(self, end_points):
         if self.training:
             raise NotImplementedError("training path is out of scope (SURVEY.md 8(f-4))")
-        self._pre = None
-        dense_pm, dense_fm, dense_po, dense_fo, radius = self._features(end_points)
-        pre, self._pre = self._pre, None
+        dense_pm, dense_fm, dense_po, dense_fo, radius, pre = self._features(end_points)
         if pre is not None:
             return self._forward_from(pre, end_points, dense_pm, dense_fm, dense_po, dense_fo, radius)
         dense_pm_lrf = ops.lrf_global(end_points["pts"], self.use_ref_rad)
@@ -282,10 +282,11 @@ class UNOPose(nn.Module):
     def _matching(self, end_points, geo, B, sparse_pm, sparse_fm, sparse_po, sparse_fo, fps_idx_m, fps_idx_o, dense_pm,
                   dense_fm, dense_po, dense_fo, radius):
         geo_m, geo_o = geo[:B], geo[B:]
-        # The reference cloud's positional encoding (Fi:77-80) does not depend on the coarse pose: it runs on
-        # the side stream UNDER the coarse stage, whose 197-token kernels and hypothesis search are latency-
-        # bound and leave most CUs idle (the PE kernel has no inter-workgroup waits, so sharing the GPU with
-        # the coarse stage's small library GEMMs is safe -- DESIGN.md section 7).
+        # The reference cloud's positional encoding (Fi:77-80) does not depend on the coarse pose: its two fused
+        # group/MLP/max launches run on the side stream UNDER the coarse stage, whose 197-token kernels and
+        # hypothesis search are latency-bound and leave most CUs idle.  Only kernels without inter-workgroup
+        # waits go there; the mlp3 projection is a library GEMM and stays on the main stream (no two library
+        # GEMMs are ever co-scheduled -- DESIGN.md section 7).
         pe2 = None
         if (PE_UNDER_COARSE and not self.test_coarse_only and dense_pm.is_cuda and torch.is_autocast_enabled()
                 and dense_pm.shape == dense_po.shape):
@@ -293,7 +294,7 @@ class UNOPose(nn.Module):
             side = self._side_stream(dense_po.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                pe2 = self.fine_point_matching.PE(dense_po)
+                pe2 = self.fine_point_matching.PE.groups(dense_po)
                 pe2.record_stream(main)
         end_points = self.coarse_point_matching(sparse_pm, sparse_fm, geo_m, sparse_po, sparse_fo, geo_o, radius,
                                                 end_points)
@@ -305,4 +306,4 @@ class UNOPose(nn.Module):
             end_points["pred_pose_score"] = end_points["init_pose_score"]
             return end_points
         return self.fine_point_matching(dense_pm, dense_fm, geo_m, fps_idx_m, dense_po, dense_fo, geo_o, fps_idx_o,
-                                        radius, end_points, pe2=pe2)
+                                        radius, end_points, pe2_groups=pe2)

@@ -67,13 +67,20 @@ import torch.nn.functional as F
 from .pointnet2 import _ext
 
 
-def linear(x, lin, relu=False):
+def linear_backend():
+    """Which GEMM runs the bf16 linears (reported by bench.py next to the measured rate)."""
+    return "hipBLASLt (through torch)"
+
+
+def linear(x, lin, relu=False, gelu=False):
     """nn.Linear under autocast without the per-call weight cast: bf16 copies of (weight, bias) are cached
     on the module (keyed by the parameter version) and the GEMM is issued directly in bf16.  Outside
     autocast this is just `lin(x)`.  `relu=True` asks for relu(lin(x)); on the bf16 path the ReLU rides in
-    the GEMM epilogue (hipBLASLt RELU_BIAS through torch._addmm_activation) instead of a separate pass."""
+    the GEMM epilogue (hipBLASLt RELU_BIAS through torch._addmm_activation) instead of a separate pass.
+    `gelu=True` asks for the exact-erf GELU of the result (timm Mlp, act_layer=nn.GELU)."""
     if not (torch.is_autocast_enabled() and x.is_cuda):
-        return F.relu(lin(x)) if relu else lin(x)
+        y = lin(x)
+        return F.relu(y) if relu else (F.gelu(y) if gelu else y)
     key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.device)
     cache = getattr(lin, "_bf16_cache", None)
     if cache is None or cache[0] != key:
@@ -87,7 +94,7 @@ def linear(x, lin, relu=False):
             x2 = xb.reshape(-1, xb.shape[-1])
             return torch._addmm_activation(cache[2], x2, cache[1].t()).reshape(*xb.shape[:-1], cache[1].shape[0])
         y = F.linear(xb, cache[1], cache[2])
-        return F.relu(y) if relu else y
+        return F.relu(y) if relu else (F.gelu(y) if gelu else y)
 
 
 def gather_rows(feats, idx):

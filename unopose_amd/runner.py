@@ -54,27 +54,34 @@ class ReferenceCache:
     """Per-reference-view features kept across images: BOP test sets pair many
     query instances with few reference views, and everything `UNOPose.encode_reference` returns depends
     on the reference view alone.  Keys are whatever identifies a view to the caller (e.g.
-    ``(ref_scene_id, ref_im_id, obj_id)``); entries live on the model's device, oldest evicted first."""
+    ``(ref_scene_id, ref_im_id, obj_id)``); entries live on the model's device.  Eviction is LRU (a hit
+    refreshes the entry), happens only AFTER the batch's result has been assembled -- a key the current call
+    needs is never dropped under it -- and entries are own copies, so an eviction really frees memory."""
 
     def __init__(self, model, max_items=256):
-        self.model, self.max_items, self.store = model, max_items, {}
+        from collections import OrderedDict
+
+        self.model, self.max_items, self.store = model, max_items, OrderedDict()
         self.hits = self.misses = 0
 
     def lookup(self, keys, tem1_rgb, tem1_choose, tem1_pts):
-        miss = [i for i, k in enumerate(keys) if k not in self.store]
         first = {}
-        for i in miss:
-            first.setdefault(keys[i], i)  # one encode per distinct missing view
+        for i, k in enumerate(keys):
+            if k not in self.store:
+                first.setdefault(k, i)  # one encode per distinct missing view
         if first:
             sel = torch.as_tensor(list(first.values()), device=tem1_pts.device)
             enc = self.model.encode_reference(tem1_rgb[sel], tem1_choose[sel], tem1_pts[sel])
             for j, k in enumerate(first):
-                self.store[k] = {name: v[j] for name, v in enc.items()}
-            while len(self.store) > max(self.max_items, len(set(keys))):
-                self.store.pop(next(iter(self.store)))
+                self.store[k] = {name: v[j].clone() for name, v in enc.items()}
+        for k in keys:
+            self.store.move_to_end(k)  # most recently used last
         self.misses += len(first)
         self.hits += len(keys) - len(first)
-        return {name: torch.stack([self.store[k][name] for k in keys]) for name in _REF_KEYS}
+        out = {name: torch.stack([self.store[k][name] for k in keys]) for name in _REF_KEYS}
+        while len(self.store) > self.max_items:  # least recently used first; `out` no longer needs the store
+            self.store.popitem(last=False)
+        return out
 
 
 @torch.no_grad()
@@ -104,13 +111,25 @@ def run_image(model, data, instance_batch_size=16, device=None, ref_cache=None):
     return Rs, ts, scores
 
 
-def inference_and_save(model, images, save_path, instance_batch_size=16, device=None, sync=None, ref_cache=None):
+def inference_and_save(model, images, save_path, instance_batch_size=16, device=None, sync=None, ref_cache=None,
+                       dets=None):
     """`images`: an indexable of per-image dicts (the reference's test dataset items, batch dim 1).
     Every rank processes its InferenceSampler shard; rows are gathered to rank 0, which writes the CSV
-    (and the detections JSON) in global image order.  Returns the rows on rank 0, None elsewhere."""
+    and the detections JSON in global image order.  Returns the CSV lines on rank 0, None elsewhere.
+
+    Detections JSON (oneref_inference_utils_v1.py:31,112-113,134-135): a deep copy of the dataset's
+    detections -- ``{"<scene:06d>_<img:06d>": [detection dict, ...]}``, every field kept, detections the
+    provider filtered out included -- with ``pred_R`` (9 floats, row major) and ``pred_t`` (3 floats, mm) added
+    to the entries ``inst_ids`` names.  `dets` defaults to ``images.dets`` (the provider's attribute, like
+    ``data_loader.dataset.dets``)."""
+    from copy import deepcopy
+
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    rows, dets = [], {}
+    if dets is None:
+        dets = getattr(images, "dets", None)
+    dets = deepcopy(dets) if dets is not None else {}
+    rows, preds = [], []
     for idx in shard_range(len(images), world, rank):
         data = images[idx]
         if sync is not None:
@@ -119,26 +138,28 @@ def inference_and_save(model, images, save_path, instance_batch_size=16, device=
         Rs, ts, scores = run_image(model, data, instance_batch_size, device, ref_cache)
         if sync is not None:
             sync()
-        image_time = time.perf_counter() - t0 + float(data["seg_time"]) if "seg_time" in data else \
-            time.perf_counter() - t0
+        image_time = time.perf_counter() - t0
+        if "seg_time" in data:
+            image_time += float(data["seg_time"])
         scene_id, img_id = int(data["scene_id"]), int(data["img_id"])
         inst_ids = np.asarray(data["inst_ids"][0]) if "inst_ids" in data else np.arange(len(scores))
         for k in range(len(scores)):
             rows.append((idx, k, csv_line(scene_id, img_id, int(data["obj_id"][0][k]), scores[k], Rs[k], ts[k],
                                           image_time)))
-            dets.setdefault(f"{scene_id:06d}_{img_id:06d}", {})[int(inst_ids[k])] = {
-                "pred_R": Rs[k].tolist(), "pred_t": ts[k].tolist()}
+            preds.append((f"{scene_id:06d}_{img_id:06d}", int(inst_ids[k]), Rs[k].tolist(), ts[k].tolist()))
     if world > 1:
         gathered = [None] * world if rank == 0 else None
-        dist.gather_object((rows, dets), gathered, dst=0)
+        dist.gather_object((rows, preds), gathered, dst=0)
         if rank != 0:
             return None
         rows = [r for part in gathered for r in part[0]]
-        merged = {}
-        for part in gathered:
-            for key, v in part[1].items():
-                merged.setdefault(key, {}).update(v)
-        dets = merged
+        preds = [q for part in gathered for q in part[1]]
+    for key, inst_i, R9, t3 in preds:
+        if isinstance(dets.get(key), list):  # the reference's layout: a list of detection dicts per image
+            entry = dets[key][inst_i]
+        else:  # no detections handed in (synthetic runs): same nesting, keyed by instance
+            entry = dets.setdefault(key, {}).setdefault(inst_i, {})
+        entry["pred_R"], entry["pred_t"] = R9, t3
     rows.sort(key=lambda r: (r[0], r[1]))
     lines = [r[2] for r in rows]
     with open(save_path, "w+") as f:
@@ -152,10 +173,10 @@ def broadcast_module_(module, src=0):
     """One flat broadcast of all parameters and buffers from `src` (weights travel once over xGMI)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return module
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    tensors = list(module.parameters()) + list(module.buffers())
     if not tensors:
         return module
-    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
     if flat.is_cuda and dist.get_backend() != "nccl":  # host-memory backends (gloo in the tests)
         host = flat.cpu()
         dist.broadcast(host, src)
@@ -163,8 +184,9 @@ def broadcast_module_(module, src=0):
     else:
         dist.broadcast(flat, src)
     off = 0
-    for t in tensors:
-        n = t.numel()
-        t.copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
-        off += n
+    with torch.no_grad():  # in-place copy on the parameter itself: bumps `_version`, which keys every derived-weight
+        for t in tensors:  # cache in ops.py (a `.data` alias would leave them stale)
+            n = t.numel()
+            t.copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
+            off += n
     return module
