@@ -281,6 +281,11 @@ int unopose_scale_residual(float *x, const void *y_bf16, const float *gamma, lon
 int unopose_linear_attention(const void *x, const float *inv_softplus_scale, const void *kvt,
                              const float *ksum, int B, int N, int focus, int mode, void *out,
                              unopose_stream_t stream);
+/* Same function on float32 data (the reference's default precision, configs/main_cfg.py:87-89): x, kvt
+ * and out are float32; the per-head contraction runs as hi/lo-split bf16 MFMAs (fp32-class accuracy). */
+int unopose_linear_attention_f32(const float *x, const float *inv_softplus_scale, const float *kvt,
+                                 const float *ksum, int B, int N, int focus, int mode, float *out,
+                                 unopose_stream_t stream);
 
 /* Fused tail of a post-LN transformer layer (core/unopose/model/transformer.py:151-193, d_model 256):
  *   r = LN1(h Wl^T + bl + x);  out = LN2(r + relu(r We^T + be) Ws^T + bs)

@@ -405,6 +405,17 @@ def fine_point_matching(p1, f1, g1, i1, p2, f2, g2, i2, init_R, init_t, sd, p, c
 
 
 # --------------------------------------------------------------------- ViT ---
+def vit_attention_core(qkv, heads):
+    """timm 0.9.12 `Attention.forward` between the qkv and proj linears (non-fused branch): qkv (B,T,3D) ->
+    (B,T,D); q scaled by head_dim^-0.5, softmax over keys, heads concatenated."""
+    B, T, D3 = qkv.shape
+    D = D3 // 3
+    hd = D // heads
+    qkv = qkv.reshape(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    a = torch.softmax((qkv[0] * hd ** -0.5) @ qkv[1].transpose(-2, -1), dim=-1) @ qkv[2]
+    return a.transpose(1, 2).reshape(B, T, D)
+
+
 def vit_taps(x, sd, p, depth=12, heads=12, patch=14):
     """timm 0.9.12 VisionTransformer as subclassed at F:24-42 (PARITY UNPINNED, App-D).
     Returns [norm(x_b) for b in the 4 tap blocks], each (B, 5+P, D)."""
@@ -421,9 +432,7 @@ def vit_taps(x, sd, p, depth=12, heads=12, patch=14):
     for i in range(depth):
         q = f"{p}.blocks.{i}"
         y = _ln(x, sd, q + ".norm1", 1e-6)
-        qkv = _lin(y, sd, q + ".attn.qkv").reshape(B, -1, 3, heads, hd).permute(2, 0, 3, 1, 4)
-        a = torch.softmax((qkv[0] * hd ** -0.5) @ qkv[1].transpose(-2, -1), dim=-1) @ qkv[2]
-        a = _lin(a.transpose(1, 2).reshape(B, -1, D), sd, q + ".attn.proj")
+        a = _lin(vit_attention_core(_lin(y, sd, q + ".attn.qkv"), heads), sd, q + ".attn.proj")
         x = x + a * sd[q + ".ls1.gamma"]
         y = _ln(x, sd, q + ".norm2", 1e-6)
         y = _lin(F.gelu(_lin(y, sd, q + ".mlp.fc1")), sd, q + ".mlp.fc2")

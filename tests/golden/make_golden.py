@@ -397,7 +397,130 @@ def main():
          init_t=ep["init_t"], radius=mine["radius"], R=ep2["pred_R"], t=ep2["pred_t"],
          pose_score=ep2["pred_pose_score"], f1_out=det["f1"][:, :64], f2_out=det["f2"][:, :64], score=det["score"],
          atten_rowmax=det["atten"].max(2)[0], atten_colmax=det["atten"].max(1)[0])
+    production_size_layers(pu, sd, cfg)
     print("done")
+
+
+def seeded(shape, seed, scale=1.0):
+    """Fixture inputs too large to commit are regenerated from a seed (torch's CPU generator is
+    deterministic for a given torch build; `tests/helpers.py::seeded_checked` re-derives them and checks the
+    stored checksum before use)."""
+    return scale * torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def checksum(t):
+    t = t.double().flatten()
+    return np.array([t.sum().item(), (t * torch.arange(1, t.numel() + 1, dtype=torch.float64)).sum().item() / t.numel()])
+
+
+def production_size_layers(pu, sd, cfg):
+    """Layer-level fixtures at the PRODUCTION sizes (197 tokens, 2048 dense points, PE radii 0.1 / 0.2 with
+    64 / 256 neighbours) with UNTAMED random weights, from the reference modules themselves.  Large
+    tensors are stored as row subsets (the index lists are in the fixture); large random inputs as seeds."""
+    from oracle import unopose_ref as R
+    from oracle.pointnet2_oracle import ext
+    from helpers import object_cloud, constructed_similarity
+
+    import core.unopose.model.transformer as T
+    import core.unopose.utils.model_utils as U
+    from core.unopose.model.oneref_predator_fine_point_matching import PositionalEncoding
+
+    g = torch.Generator().manual_seed(4321)
+
+    def norm_cloud(n, repl=False):
+        p = object_cloud(g, n, with_replacement=repl)
+        c = p.mean(0, keepdim=True)
+        return (p / (p - c).norm(dim=1).max()).contiguous()
+
+    # ---- a11 at n = 197 ----------------------------------------------------------------------------
+    print("geo_embedding n=197")
+    geo = T.GeometricStructureEmbedding(cfg.geo_embedding).eval()
+    geo.load_state_dict(sub_sd(sd, "geo_embedding"), strict=True)
+    gp = torch.cat([torch.ones(2, 1, 3), torch.stack([norm_cloud(196), norm_cloud(196)])], 1)
+    E = geo(gp)  # (2,197,197,256)
+    close(R.geo_embedding(gp, sd, "geo_embedding", cfg.geo_embedding), E, 1e-4, "geo_embedding n=197")
+    sel_i = torch.arange(0, 197, 16)
+    sel_j = torch.arange(0, 197, 4)
+    save("geo_embedding_n197", points=gp, sel_i=sel_i.to(torch.int32), sel_j=sel_j.to(torch.int32),
+         out=E[:, sel_i][:, :, sel_j])
+
+    # ---- a12 / a13: GeometricTransformer at n = 197 --------------------------------------------------
+    print("GeometricTransformer n=197 (untamed)")
+    gt = T.GeometricTransformer(["self", "cross"], 256, 4, dropout=None, activation_fn="ReLU").eval()
+    tp = "coarse_point_matching.transformers.1"
+    gt.load_state_dict(sub_sd(sd, tp), strict=True)
+    f0, f1 = seeded((1, 197, 256), 501), seeded((1, 197, 256), 502)
+    r_self = gt.layers[0](f0, f0, E[0:1])[0]
+    r_cross = gt.layers[1](f0, f1)[0]
+    r0, r1 = gt(f0, E[0:1], f1, E[1:2])
+    close(R.transformer_layer(f0, f0, sd, tp + ".layers.0", embed=E[0:1]), r_self, 5e-5, "RPE self layer n=197")
+    m0, m1 = R.geometric_transformer(f0, E[0:1], f1, E[1:2], sd, tp)
+    close(m0, r0, 1e-4, "geometric_transformer n=197 f0")
+    close(m1, r1, 1e-4, "geometric_transformer n=197 f1")
+    save("geometric_transformer_n197", points=gp, f0=f0, f1=f1, rpe_self=r_self, cross=r_cross, gt0=r0, gt1=r1)
+
+    # ---- a14 / a15: SparseToDenseTransformer at 2049 / 197 -------------------------------------------
+    print("SparseToDenseTransformer 2049/197 (untamed)")
+    s2d = T.SparseToDenseTransformer(256, ["self", "cross"], num_heads=4, focusing_factor=3).eval()
+    sp = "fine_point_matching.transformers.1"
+    s2d.load_state_dict(sub_sd(sd, sp), strict=True)
+    d0, d1 = seeded((1, 2049, 256), 601), seeded((1, 2049, 256), 602)
+    i0 = ext.furthest_point_sampling(norm_cloud(2048)[None], 196)
+    i1 = ext.furthest_point_sampling(norm_cloud(2048, True)[None], 196)
+    ref_lin = s2d.dense_layer(d0[:, 1:].contiguous(), f0[:, 1:].contiguous())
+    close(R.linear_transformer_layer(d0[:, 1:].contiguous(), f0[:, 1:].contiguous(), sd, sp + ".dense_layer"), ref_lin,
+          1e-4, "linear transformer layer 2048x196")
+    att = s2d.dense_layer.attention.attention
+    ref_core = att(d0[:, 1:].contiguous(), f0[:, 1:].contiguous(), f0[:, 1:].contiguous())  # LinearAttention.forward alone (T:531-568)
+    close(R.linear_attention(d0[:, 1:].contiguous(), f0[:, 1:].contiguous(), sd, sp + ".dense_layer.attention.attention"),
+          ref_core, 1e-4, "linear attention core 2048x196")
+    rd0, rd1 = s2d(d0, E[0:1], i0, d1, E[1:2], i1)
+    md0, md1 = R.sparse_to_dense_transformer(d0, E[0:1], i0, d1, E[1:2], i1, sd, sp, ext)
+    close(md0, rd0, 2e-4, "sparse_to_dense 2049 f0")
+    close(md1, rd1, 2e-4, "sparse_to_dense 2049 f1")
+    rows = torch.arange(0, 2048, 8)
+    rows1 = torch.cat([torch.zeros(1, dtype=torch.long), 1 + rows])  # bg row + every 8th dense row
+    save("sparse_to_dense_2049", points=gp, d_seeds=np.array([601, 602]), d_checksum=np.stack([checksum(d0), checksum(d1)]),
+         sparse0=f0, i0=i0, i1=i1, rows=rows.to(torch.int32), rows1=rows1.to(torch.int32), linear=ref_lin[:, rows],
+         linear_core=ref_core[:, rows], out0=rd0[:, rows1], out1=rd1[:, rows1])
+
+    # ---- a7: PositionalEncoding at the configured radii / neighbour counts, N = 2048 -----------------
+    print("PositionalEncoding r=0.1/0.2 ns=64/256 N=2048")
+    fcfg = cfg.fine_point_matching
+    pe = PositionalEncoding(256, r1=fcfg.pe_radius1, r2=fcfg.pe_radius2, nsample1=fcfg.nsample1, nsample2=fcfg.nsample2,
+                            use_lrf=True, use_xyz=True).eval()
+    pe.load_state_dict(sub_sd(sd, "fine_point_matching.PE"), strict=True)
+    xyz = torch.stack([norm_cloud(2048), norm_cloud(2048, True)])
+    ref = pe(xyz)
+    close(R.positional_encoding(xyz, sd, "fine_point_matching.PE", fcfg, ext), ref, 5e-3, "positional_encoding prod")
+    for rad, ns in ((fcfg.pe_radius1, fcfg.nsample1), (fcfg.pe_radius2, fcfg.nsample2)):
+        grp = pu.QueryAndLRFGroup(rad, ns, use_xyz=True, use_feature=False)
+        o = grp(xyz.contiguous(), xyz.contiguous(), xyz.transpose(1, 2).contiguous())
+        close(R.query_and_lrf_group(xyz, rad, ns, ext), o, 2e-3, f"query_and_lrf_group prod r={rad}")
+    pts_sel = torch.arange(0, 2048, 4)
+    save("positional_encoding_prod", xyz=xyz, r1=np.float32(fcfg.pe_radius1), r2=np.float32(fcfg.pe_radius2),
+         ns1=fcfg.nsample1, ns2=fcfg.nsample2, sel=pts_sel.to(torch.int32), out=ref[:, pts_sel])
+
+    # ---- a20 at 2049 x 2049 ---------------------------------------------------------------------------
+    print("fine Rt 2049x2049 (constructed similarity, regenerated from its seed)")
+    gg = torch.Generator().manual_seed(9001)
+    N = 2048
+    p2 = torch.stack([norm_cloud(N)])
+    perm = torch.stack([torch.randperm(N, generator=gg)])
+    Q = torch.linalg.qr(torch.randn(1, 3, 3, generator=gg))[0]
+    Q = Q * torch.sign(torch.det(Q)).reshape(-1, 1, 1)
+    tg = 0.1 * torch.randn(1, 3, generator=gg)
+    p1 = torch.gather(p2, 1, perm.unsqueeze(2).expand(-1, -1, 3)) @ Q.transpose(1, 2) + tg.unsqueeze(1)
+    p1 = p1 + 0.003 * torch.randn(1, N, 3, generator=gg)
+    atten, score = constructed_similarity(perm, N, torch.Generator().manual_seed(9002), n_bg=300)
+    Rr, tr, sr = U.compute_fine_Rt_overlap(atten, score, p1, p2, None)
+    Rm, tm, sm = R.compute_fine_rt_overlap(atten, score, p1, p2)
+    close(Rm, Rr, 1e-5, "fine R 2049")
+    close(tm, tr, 1e-5, "fine t 2049")
+    close(sm, sr, 1e-5, "fine score 2049")
+    print(f"  fine R vs ground truth: {(Rr - Q).abs().max().item():.3e}")
+    save("fine_rt_2049", p1=p1, p2=p2, perm=perm.to(torch.int32), sim_seed=9002, n_bg=300, sim_checksum=checksum(atten),
+         score=score, R=Rr, t=tr, pose_score=sr, R_gt=Q, t_gt=tg)
 
 
 if __name__ == "__main__":

@@ -73,4 +73,19 @@ def constructed_similarity(perm, N, gen, n_bg=40, hi=8.0, noise=1.5):
     return atten, score
 
 
+def seeded_checked(shape, seed, checksum, scale=1.0):
+    """Regenerate a fixture input that was stored as a seed (tests/golden/make_golden.py::seeded) and verify
+    it against the checksum recorded when the reference ran on it."""
+    t = scale * torch.randn(*shape, generator=torch.Generator().manual_seed(int(seed)))
+    d = t.double().flatten()
+    got = np.array([d.sum().item(), (d * torch.arange(1, d.numel() + 1, dtype=torch.float64)).sum().item() / d.numel()])
+    assert np.allclose(got, np.asarray(checksum), rtol=1e-9, atol=1e-9), "seeded fixture input differs from the one the reference saw"
+    return t
+
+
+def tensor_checksum(t):
+    d = t.double().flatten()
+    return np.array([d.sum().item(), (d * torch.arange(1, d.numel() + 1, dtype=torch.float64)).sum().item() / d.numel()])
+
+
 from unopose_amd.synthetic import congruent_pair, random_rotation  # noqa: E402,F401

@@ -60,7 +60,10 @@ def _well_conditioned(ref, radius):
     return (gap > 2e-2) & ((vote.abs() - near) >= 1) & (acc / scale > 1e-2)
 
 
-def _check_group(out, ref, radius, tol=2e-3, min_well=0.30):
+def _check_group(out, ref, radius, expect_well, tol=2e-3):
+    """`expect_well`: the well-conditioned fraction per cloud, a property of the REFERENCE output measured once
+    (clouds sampled with replacement are full of duplicated neighbourhoods and score low); asserted as measured
+    minus 0.01, so the set on which every point is compared cannot silently shrink."""
     # channels 0-2 are plain differences of the same fp32 numbers: bit-exact
     assert torch.equal(out[:, :3], ref[:, :3])
     # channels 3-5 depend on a 3x3 eigenvector (torch.svd vs register Jacobi).  Where the frame is
@@ -68,30 +71,34 @@ def _check_group(out, ref, radius, tol=2e-3, min_well=0.30):
     # duplicated neighbourhoods, tied sign votes) are implementation-defined in the reference itself.
     err = (out[:, 3:] - ref[:, 3:]).abs().amax(dim=(1, 3))  # (B,N)
     well = _well_conditioned(ref, radius)
-    assert well.float().mean().item() >= min_well, well.float().mean().item()
+    frac = well.float().mean(1)
+    print("well-conditioned fraction per cloud:", [round(f, 4) for f in frac.tolist()],
+          "worst error on them: %.2e" % err[well].max().item(), "; all points within tol: %.4f" % (err < tol).float().mean().item())
+    assert all(f >= e - 0.01 for f, e in zip(frac.tolist(), expect_well)), (frac.tolist(), expect_well)
     bad = (err >= tol) & well
     assert not bad.any(), f"{int(bad.sum())} well-conditioned points differ, worst {err[well].max().item():.3e}"
-    return well.float().mean().item()
+    return frac
 
 
-@pytest.mark.parametrize("name", ["query_lrf_group_r0.2_ns32", "query_lrf_group_r0.4_ns64"])
-def test_query_lrf_group_golden(name):
+@pytest.mark.parametrize("name,expect", [("query_lrf_group_r0.2_ns32", (0.9258, 0.0977)),
+                                         ("query_lrf_group_r0.4_ns64", (0.9922, 0.7852))])
+def test_query_lrf_group_golden(name, expect):
     from unopose_amd import ops
 
     z = load(name)
     out = ops.query_lrf_group(z["xyz"].cuda(), z["radius"], z["nsample"]).cpu()
-    _check_group(out, z["out"], z["radius"])
+    _check_group(out, z["out"], z["radius"], expect)
 
 
-@pytest.mark.parametrize("r,ns", [(0.1, 64), (0.2, 256)])
-def test_query_lrf_group_full_size_vs_oracle(oracle_ext, r, ns):
+@pytest.mark.parametrize("r,ns,expect", [(0.1, 64, (0.9321, 0.9712, 0.4658)), (0.2, 256, (0.9858, 0.9951, 0.9697))])
+def test_query_lrf_group_full_size_vs_oracle(oracle_ext, r, ns, expect):
     from unopose_amd import ops
     from oracle import unopose_ref as R
 
     x = norm_clouds(2048, 3, seed=11)
     out = ops.query_lrf_group(x.cuda(), r, ns).cpu()
     ref = R.query_and_lrf_group(x, r, ns, oracle_ext)
-    _check_group(out, ref, r)
+    _check_group(out, ref, r, expect)
 
 
 def test_weighted_procrustes_golden():

@@ -139,3 +139,69 @@ def test_state_dict_layout_counts(sd):
     n_fine = sum(v.numel() for k, v in sd.items()
                  if k.startswith("fine_point_matching") and "running" not in k and "tracked" not in k)
     assert n_coarse == 3492611 and n_fine == 5163782
+
+
+# ---- production-size layer fixtures (untamed weights, from the reference modules; make_golden.py::production_size_layers)
+def test_geo_embedding_n197(sd, cfg):
+    z = load("geo_embedding_n197")
+    E = R.geo_embedding(z["points"], sd, "geo_embedding", cfg.geo_embedding)
+    close(E[:, z["sel_i"].long()][:, :, z["sel_j"].long()], z["out"], 1e-4)
+
+
+def test_geometric_transformer_n197(sd, cfg):
+    z = load("geometric_transformer_n197")
+    E = R.geo_embedding(z["points"], sd, "geo_embedding", cfg.geo_embedding)
+    tp = "coarse_point_matching.transformers.1"
+    close(R.transformer_layer(z["f0"], z["f0"], sd, tp + ".layers.0", embed=E[0:1]), z["rpe_self"], 5e-5)
+    close(R.transformer_layer(z["f0"], z["f1"], sd, tp + ".layers.1"), z["cross"], 5e-5)
+    m0, m1 = R.geometric_transformer(z["f0"], E[0:1], z["f1"], E[1:2], sd, tp)
+    close(m0, z["gt0"], 1e-4)
+    close(m1, z["gt1"], 1e-4)
+
+
+def test_sparse_to_dense_2049(oracle_ext, sd, cfg):
+    from helpers import seeded_checked
+
+    z = load("sparse_to_dense_2049")
+    d0 = seeded_checked((1, 2049, 256), z["d_seeds"][0], z["d_checksum"][0])
+    d1 = seeded_checked((1, 2049, 256), z["d_seeds"][1], z["d_checksum"][1])
+    E = R.geo_embedding(z["points"], sd, "geo_embedding", cfg.geo_embedding)
+    sp = "fine_point_matching.transformers.1"
+    rows, rows1 = z["rows"].long(), z["rows1"].long()
+    dq, kv = d0[:, 1:].contiguous(), z["sparse0"][:, 1:].contiguous()
+    close(R.linear_attention(dq, kv, sd, sp + ".dense_layer.attention.attention")[:, rows], z["linear_core"], 1e-4)
+    close(R.linear_transformer_layer(dq, kv, sd, sp + ".dense_layer")[:, rows], z["linear"], 1e-4)
+    m0, m1 = R.sparse_to_dense_transformer(d0, E[0:1], z["i0"], d1, E[1:2], z["i1"], sd, sp, oracle_ext)
+    close(m0[:, rows1], z["out0"], 2e-4)
+    close(m1[:, rows1], z["out1"], 2e-4)
+
+
+def test_positional_encoding_production_radii(oracle_ext, sd, cfg):
+    z = load("positional_encoding_prod")
+    f = cfg.fine_point_matching
+    assert (z["r1"], z["r2"], z["ns1"], z["ns2"]) == (np.float32(f.pe_radius1), np.float32(f.pe_radius2), 64, 256)
+    out = R.positional_encoding(z["xyz"], sd, "fine_point_matching.PE", f, oracle_ext)
+    close(out[:, z["sel"].long()], z["out"], 5e-3)
+
+
+def test_fine_rt_2049():
+    from helpers import constructed_similarity, tensor_checksum
+
+    z = load("fine_rt_2049")
+    atten, score = constructed_similarity(z["perm"].long(), 2048, torch.Generator().manual_seed(z["sim_seed"]), n_bg=z["n_bg"])
+    assert np.allclose(tensor_checksum(atten), z["sim_checksum"].numpy(), rtol=1e-9) and torch.equal(score, z["score"])
+    Rm, tm, sm = R.compute_fine_rt_overlap(atten, score, z["p1"], z["p2"])
+    close(Rm, z["R"], 1e-5)
+    close(tm, z["t"], 1e-5)
+    close(sm, z["pose_score"], 1e-5)
+    close(Rm, z["R_gt"], 5e-3)
+
+
+def test_vit_attention_core_is_the_softmax_definition():
+    """The factored-out attention core equals the textbook per-head softmax(q k^T / sqrt(d)) v in float64."""
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(2, 37, 3 * 128, generator=g)
+    out = R.vit_attention_core(qkv, 2)
+    q, k, v = qkv.double().reshape(2, 37, 3, 2, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).transpose(1, 2).reshape(2, 37, 128)
+    close(out, ref, 1e-5)

@@ -145,6 +145,125 @@ __global__ __launch_bounds__(256) void linear_attn_kernel(const u16 *__restrict_
   store_tile();
 }
 
+// ---- fp32-class variant (the reference's default precision: no autocast) ------------------------------------
+// Same scheme on fp32 data: focusing in fp32 registers, the per-head 64x64 contraction as hi/lo-split bf16
+// MFMAs (x = xh + xl, 3 MFMAs per product, fp32 accumulation: ~2^-16 relative error, as csrc/attn_f32.hip),
+// fp32 in / out.  I/O goes straight between global memory and fragment registers (32-byte pieces per
+// lane): this is the parity configuration, not the benched one.
+__device__ __forceinline__ void la_split(const float (&v)[8], bf16x8 &hi, bf16x8 &lo) {
+  union { bf16x8 v; uint32_t u[4]; } h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h.u[e] = cvt_pk_bf16_f32(v[2 * e], v[2 * e + 1]);
+    const float r0 = v[2 * e] - __uint_as_float(h.u[e] << 16);
+    const float r1 = v[2 * e + 1] - __uint_as_float(h.u[e] & 0xFFFF0000u);
+    l.u[e] = cvt_pk_bf16_f32(r0, r1);
+  }
+  hi = h.v;
+  lo = l.v;
+}
+
+// x: (B,N,256) fp32 projected q (or k); kvt: (B,4,64 d,64 c) fp32; ksum: (B,256) fp32; out (B,N,256) fp32.
+template <int MODE>
+__global__ __launch_bounds__(256) void linear_attn_f32_kernel(const float *__restrict__ x, const float *__restrict__ inv_sp,
+                                                              const float *__restrict__ kvt, const float *__restrict__ ksum,
+                                                              int N, float *__restrict__ out) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = (blockIdx.x * 4 + wave) * 32;
+  if (t0 >= N) return;
+  const int col = lane & 31, hb = lane >> 5;
+  const int trow = min(t0 + col, N - 1);  // ragged tail: clamp the load, mask the store
+  const float *xr = x + ((size_t)b * N + trow) * 256 + hb * 8;
+  float q[16][8];
+  float n1 = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const float4 a0 = *reinterpret_cast<const float4 *>(xr + ks * 16);
+    const float4 a1 = *reinterpret_cast<const float4 *>(xr + ks * 16 + 4);
+    const float4 s0 = *reinterpret_cast<const float4 *>(inv_sp + ks * 16 + hb * 8);
+    const float4 s1 = *reinterpret_cast<const float4 *>(inv_sp + ks * 16 + hb * 8 + 4);
+    const float xv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = (fmaxf(xv[e], 0.f) + 1e-6f) * sc[e];
+      q[ks][e] = v;
+      n1 += v * v;
+    }
+  }
+  n1 += __shfl_xor(n1, 32);
+  float n3 = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float p = q[ks][e];
+      p = p * p * p;
+      q[ks][e] = p;
+      n3 += p * p;
+    }
+  n3 += __shfl_xor(n3, 32);
+  const float fac = sqrtf(n1) / sqrtf(n3);
+  float zp[4] = {0.f, 0.f, 0.f, 0.f};
+  const float *ks_b = MODE == 0 ? ksum + (size_t)b * 256 + hb * 8 : nullptr;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      q[ks][e] *= fac;
+      if (MODE == 0) zp[ks >> 2] += q[ks][e] * ks_b[ks * 16 + e];
+    }
+  if (MODE == 1) {  // focused features only
+    if (t0 + col < N) {
+      float *dst = out + ((size_t)b * N + t0 + col) * 256 + hb * 8;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        *reinterpret_cast<float4 *>(dst + ks * 16) = make_float4(q[ks][0], q[ks][1], q[ks][2], q[ks][3]);
+        *reinterpret_cast<float4 *>(dst + ks * 16 + 4) = make_float4(q[ks][4], q[ks][5], q[ks][6], q[ks][7]);
+      }
+    }
+    return;
+  }
+  __shared__ float zl[4][32][4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    zp[h] += __shfl_xor(zp[h], 32);
+    if (hb == 0) zl[wave][col][h] = 1.f / (zp[h] + 1e-6f);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    bf16x8 qh[4], ql[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) la_split(q[h * 4 + ks], qh[ks], ql[ks]);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float *kp = kvt + (((size_t)b * 4 + h) * 64 + nt * 32 + col) * 64 + hb * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const float4 b0 = *reinterpret_cast<const float4 *>(kp + ks * 16);
+        const float4 b1 = *reinterpret_cast<const float4 *>(kp + ks * 16 + 4);
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        bf16x8 bh, bl;
+        la_split(bv, bh, bl);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql[ks], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[ks], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[ks], bh, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hb;
+        if (t0 + row < N) out[((size_t)b * N + t0 + row) * 256 + h * 64 + nt * 32 + col] = acc[r] * zl[wave][row][h];
+      }
+    }
+  }
+}
+
 }  // namespace unopose
 
 using namespace unopose;
@@ -166,6 +285,22 @@ int unopose_linear_attention(const void *x, const float *inv_softplus_scale, con
     hipLaunchKernelGGL(linear_attn_kernel<0>, grid, dim3(256), 0, s, (const u16 *)x, inv_softplus_scale,
                        (const u16 *)kvt, ksum, N, focus, (u16 *)out);
   return check_launch("linear_attention");
+}
+
+int unopose_linear_attention_f32(const float *x, const float *inv_softplus_scale, const float *kvt, const float *ksum, int B,
+                                 int N, int focus, int mode, float *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(x && inv_softplus_scale && out && (mode == 1 || (kvt && ksum)), "linear_attention_f32: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && N >= 1 && B <= 65535, "linear_attention_f32: bad sizes");
+  UNOPOSE_REQUIRE(focus == 3, "linear_attention_f32: built for focusing_factor = 3 (got %d)", focus);
+  if (B == 0) return UNOPOSE_OK;
+  dim3 grid(cdiv(N, 128), B);
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 1)
+    hipLaunchKernelGGL(linear_attn_f32_kernel<1>, grid, dim3(256), 0, s, x, inv_softplus_scale, (const float *)nullptr,
+                       (const float *)nullptr, N, out);
+  else
+    hipLaunchKernelGGL(linear_attn_f32_kernel<0>, grid, dim3(256), 0, s, x, inv_softplus_scale, kvt, ksum, N, out);
+  return check_launch("linear_attention_f32");
 }
 
 }  // extern "C"

@@ -34,6 +34,7 @@ class CoarsePointMatchingOneRef(nn.Module):
         self.bg_token = nn.Parameter(torch.randn(1, 1, cfg.hidden_dim) * 0.02)
         self.score_heads = nn.ModuleList([nn.Linear(cfg.hidden_dim, 1) for _ in range(self.nblock)])
         self.transformers = nn.ModuleList([GeometricTransformer(cfg.hidden_dim, 4) for _ in range(self.nblock)])
+        self.taps = None  # assign a dict to receive (f1, f2, atten, score) of the next forward (tests)
 
     def forward(self, p1, f1, geo1, p2, f2, geo2, radius, end_points):
         if self.training:
@@ -49,6 +50,8 @@ class CoarsePointMatchingOneRef(nn.Module):
         scores = self.score_heads[self.nblock - 1](torch.cat((f1, f2), dim=1))
         atten = ops.feature_similarity(ops.linear(f1, self.out_proj), ops.linear(f2, self.out_proj), self.cfg.temp)
         score = _scores(scores, n1)
+        if self.taps is not None:  # test probe: the tensors the reference's eval branch hands to the pose head
+            self.taps.update(f1=f1, f2=f2, atten=atten, score=score)
         n1p, n2p = self.cfg.nproposal1, self.cfg.nproposal2
         rand = end_points.get("coarse_rand")
         if rand is None:  # the reference draws inside forward (U:462)
@@ -75,6 +78,7 @@ class FinePointMatchingOneRef(nn.Module):
         self.score_heads = nn.ModuleList([nn.Linear(d, 1) for _ in range(self.nblock)])
         self.transformers = nn.ModuleList(
             [SparseToDenseTransformer(d, 4, cfg.focusing_factor) for _ in range(self.nblock)])
+        self.taps = None  # assign a dict to receive (f1, f2, atten, score) of the next forward (tests)
 
     def forward(self, p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points, pe2_groups=None):
         if self.training:
@@ -121,6 +125,8 @@ class FinePointMatchingOneRef(nn.Module):
             scores = self.score_heads[self.nblock - 1](torch.cat((f1, f2), dim=1))
             atten = ops.feature_similarity(ops.linear(f1, self.out_proj), ops.linear(f2, self.out_proj), self.cfg.temp)
         score = _scores(scores, n1)
+        if self.taps is not None:
+            self.taps.update(f1=f1, f2=f2, atten=atten, score=score)
         R, t, s = ops.fine_pose(atten, score, p1, p2)
         end_points["pred_R"] = R
         end_points["pred_t"] = t * (radius.reshape(-1, 1) + 1e-6)
@@ -141,6 +147,7 @@ class UNOPose(nn.Module):
         self.geo_embedding = GeometricStructureEmbedding(cfg.geo_embedding)
         self.coarse_point_matching = CoarsePointMatchingOneRef(cfg.coarse_point_matching)
         self.fine_point_matching = FinePointMatchingOneRef(cfg.fine_point_matching)
+        self.taps = None  # assign a dict to receive the sampling intermediates of the next forward (tests)
 
     # ---- F:245-298 -------------------------------------------------------------------------------
     def _features(self, end_points):
@@ -263,6 +270,9 @@ class UNOPose(nn.Module):
         B = dense_pm.size(0)
         bg_point = torch.ones(B, 1, 3, device=dense_pm.device)
         fps_idx_m, fps_idx_o = pre["idx_m"], pre["idx_o"]
+        if self.taps is not None:  # test probe (the model never reads fps_idx_* from end_points)
+            self.taps.update(fps_idx_m=fps_idx_m, fps_idx_o=fps_idx_o, dense_pm=dense_pm, dense_fm=dense_fm,
+                             dense_po=dense_po, dense_fo=dense_fo, radius=radius)
         sparse_pm, sparse_po, sparse_pm_lrf, sparse_po_lrf = (pre[k] for k in ("sparse_pm", "sparse_po", "sparse_pm_lrf",
                                                                                   "sparse_po_lrf"))
         sparse_fm = pre["sparse_fm"] if "sparse_fm" in pre else ops.gather_rows(dense_fm, fps_idx_m)

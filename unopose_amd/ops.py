@@ -408,13 +408,41 @@ def token_attention_torch(x, mem, att, heads, embed=None):
 
 
 def focused_linear_attention(xq, xkv, att, heads, focusing):
-    """LinearAttention.forward (transformer.py:533-568).  Under autocast(bf16) with 4 heads x 64 the
-    focusing + per-head contraction + z scaling run in ONE HIP kernel per side (csrc/linattn.hip);
-    otherwise the op-by-op composite."""
-    if torch.is_autocast_enabled() and heads == 4 and xq.shape[-1] == 256 and xq.is_cuda \
-            and float(focusing) == 3.0:
-        return _focused_linear_attention_hip(xq, xkv, att, int(focusing))
+    """LinearAttention.forward (transformer.py:533-568).  With 4 heads x 64 the focusing + per-head
+    contraction + z scaling run in ONE HIP kernel per side (csrc/linattn.hip): bf16 MFMAs under autocast,
+    hi/lo-split (fp32-class) MFMAs on fp32 data; other shapes take the op-by-op composite."""
+    if heads == 4 and xq.shape[-1] == 256 and xq.is_cuda and float(focusing) == 3.0:
+        if torch.is_autocast_enabled():
+            return _focused_linear_attention_hip(xq, xkv, att, int(focusing))
+        if xq.dtype == torch.float32 and xkv.dtype == torch.float32:
+            return _focused_linear_attention_hip_f32(xq, xkv, att, int(focusing))
     return focused_linear_attention_torch(xq, xkv, att, heads, focusing)
+
+
+def _focused_linear_attention_hip_f32(xq, xkv, att, focusing):
+    """fp32 configuration: same two launches on fp32 data (csrc/linattn.hip linear_attn_f32_kernel: hi/lo-split
+    MFMAs); projections are plain fp32 GEMMs, kv / k-sum tiny fp32 contractions."""
+    B, N, C = xq.shape
+    j = xkv.shape[1]
+    key = (att.scale._version, att.scale.data_ptr(), "f32")
+    cache = getattr(att, "_hip_cache_f32", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            cache = (key, (1.0 / F.softplus(att.scale.float())).reshape(-1).contiguous())
+        att._hip_cache_f32 = cache
+    inv_sp = cache[1]
+    q = _c(att.proj_q(xq))
+    kproj = _c(att.proj_k(xkv))
+    v = att.proj_v(xkv)
+    kf = torch.empty(B, j, C, dtype=torch.float32, device=xq.device)
+    out = torch.empty(B, N, C, dtype=torch.float32, device=xq.device)
+    with torch.cuda.device(xq.device):
+        call("unopose_linear_attention_f32", ptr(kproj), ptr(inv_sp), None, None, B, j, focusing, 1, ptr(kf), stream_ptr())
+        ksum = _c(kf.sum(dim=1))
+        kvt = _c(torch.einsum("bjhd,bjhc->bhdc", v.reshape(B, j, 4, 64), kf.reshape(B, j, 4, 64)))
+        call("unopose_linear_attention_f32", ptr(q), ptr(inv_sp), ptr(kvt), ptr(ksum), B, N, focusing, 0, ptr(out),
+             stream_ptr())
+    return out
 
 
 def _focused_linear_attention_hip(xq, xkv, att, focusing):
