@@ -72,6 +72,14 @@ def launch_ranks(n):
     return rc
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (stdout carries only the JSON line)."""
+    print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
 def hip_event_time(fn, iters, stream):
     """Average duration (s) of `fn` measured with events recorded on `stream` (the stream the kernels
     are launched on)."""
@@ -207,7 +215,9 @@ def cpu_baseline_leg(img, batches=(1, 8), timed=3):
     from oracle.pointnet2_oracle import ext as oext
     from unopose_amd.synthetic import make_batch
 
-    threads = os.cpu_count() or 1
+    # torch's intra-op pool: every core up to 32 (more threads than that only add contention on these op sizes;
+    # the C `_ext` port is single-threaded) -- `cores` reports the threads actually used
+    threads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     cfg = R.default_cfg()
     sd = R.random_state_dict(cfg, seed=0, img_size=img, tame=0.1)
@@ -220,14 +230,15 @@ def cpu_baseline_leg(img, batches=(1, 8), timed=3):
             for i in range(1 + timed):
                 t0 = time.perf_counter()
                 R.unopose_forward(ep, sd, cfg, rand, oext)
+                log("cpu_baseline B=%d forward %d: %.2f s" % (b, i, time.perf_counter() - t0))
                 if i:
                     times.append(time.perf_counter() - t0)
         times.sort()
         med = times[len(times) // 2]
         by_batch[str(b)] = dict(pairs_per_s=b / med, median_s=med, min_s=times[0], max_s=times[-1], timed=timed, warmup=1)
     best = max(by_batch.values(), key=lambda r: r["pairs_per_s"])
-    return dict(value=best["pairs_per_s"], unit="pairs/s", cores=threads, kind="port", cpu_model=_cpu_model_name(),
-                by_batch=by_batch,
+    return dict(value=best["pairs_per_s"], unit="pairs/s", cores=threads, host_cores=os.cpu_count(), kind="port",
+                cpu_model=_cpu_model_name(), by_batch=by_batch,
                 sample=f"batches of {list(batches)} pairs (2048 query / 5000 reference points, {img}x{img} crops), 1 warm-up + "
                        f"{timed} timed forwards each, fp32, torch {threads} threads + C `_ext` port; value = best median")
 
@@ -309,9 +320,11 @@ def main():
             return graphed(ep)
         return forward(ep, use_amp)
 
+    log("model + batch ready (rank %d of %d)" % (rank, world))
     for _ in range(args.warmup):
         out = step()
     sync()
+    log("warm-up done")
     if world > 1:
         dist.barrier()
     sync()
@@ -341,6 +354,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
 
+    log("timed region done: %.2f ms/step" % (dt / args.steps * 1e3))
     rot_err = (out["pred_R"] - R_gt).abs().amax(dim=(1, 2))
     res = {
         "metric": "(query,ref) pairs/sec forward",
@@ -382,10 +396,12 @@ def main():
             sync()
             d32 = time.perf_counter() - t1
             e32 = (o32["pred_R"] - R_gt).abs().amax(dim=(1, 2))
+            log("fp32 leg done")
             res["fp32"] = {"value": B * k / d32, "unit": "pairs/s", "ms_per_step": d32 / k * 1e3, "steps": k,
                            "median_rot_err_vs_gt": e32.median().item()}
         if not args.no_roofline:
             res.update(roofline_leg(model, batch, args.img))
+            log("roofline leg done")
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_leg(args.img)
     if rank == 0:

@@ -436,7 +436,17 @@ def production_size_layers(pu, sd, cfg):
     print("geo_embedding n=197")
     geo = T.GeometricStructureEmbedding(cfg.geo_embedding).eval()
     geo.load_state_dict(sub_sd(sd, "geo_embedding"), strict=True)
-    gp = torch.cat([torch.ones(2, 1, 3), torch.stack([norm_cloud(196), norm_cloud(196)])], 1)
+    # the points the model feeds here (M:28-47): global-LRF coordinates (centred, |p| <= 1) of the 196 FPS-selected
+    # coarse points, background point (1,1,1) in front.  (Un-centred coordinates would make the reference's own
+    # |x|^2 - 2xy + |y|^2 distances pure rounding noise at the close pairs.)
+    def coarse_lrf_points(repl):
+        cloud = object_cloud(g, 2048, with_replacement=repl)[None]
+        lrf = R.get_batch_lrf(cloud)
+        rad = torch.norm(cloud - cloud.mean(1, keepdim=True), dim=2).max(1)[0]
+        idx = ext.furthest_point_sampling((cloud / rad.reshape(-1, 1, 1)).contiguous(), 196)
+        return torch.gather(lrf, 1, idx.long().unsqueeze(2).expand(-1, -1, 3))[0]
+
+    gp = torch.cat([torch.ones(2, 1, 3), torch.stack([coarse_lrf_points(False), coarse_lrf_points(True)])], 1)
     E = geo(gp)  # (2,197,197,256)
     close(R.geo_embedding(gp, sd, "geo_embedding", cfg.geo_embedding), E, 1e-4, "geo_embedding n=197")
     sel_i = torch.arange(0, 197, 16)
