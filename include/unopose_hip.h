@@ -287,6 +287,15 @@ int unopose_linear_attention_f32(const float *x, const float *inv_softplus_scale
                                  const float *ksum, int B, int N, int focus, int mode, float *out,
                                  unopose_stream_t stream);
 
+/* nn.Linear on bf16 data with a fused epilogue (timm ViT blocks: qkv / proj / fc1 + GELU / fc2, and the
+ * up-projection of oneref_feature_extraction.py:221):
+ *     C (M,N) bf16 = act( A (M,K) bf16 . W (N,K)^T bf16 + bias (N) fp32 ),  fp32 accumulation,
+ * epilogue 0 = bias only, 1 = bias + exact (erf) GELU evaluated on the fp32 accumulators.
+ * Requires N % 256 == 0 and K % 64 == 0 (unopose_gemm_bf16_tile() reports the 256); any M >= 1. */
+int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C, long M, int N, int K,
+                        int epilogue, unopose_stream_t stream);
+int unopose_gemm_bf16_tile(void);
+
 /* Fused tail of a post-LN transformer layer (core/unopose/model/transformer.py:151-193, d_model 256):
  *   r = LN1(h Wl^T + bl + x);  out = LN2(r + relu(r We^T + be) Ws^T + bs)
  * h (attention core output), x (layer input), out: (rows,256) bfloat16; Wl (256,256), We (512,256),

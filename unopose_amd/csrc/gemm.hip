@@ -1,0 +1,235 @@
+// bf16 "linear" GEMM with fused epilogues for gfx950 (C ABI part 2):
+//     C[M][N] = act( A[M][K] . W[N][K]^T + bias[N] ),   A / W / C bf16 row-major, bias fp32, fp32 accumulation.
+// This is nn.Linear as timm's ViT blocks call it (qkv, proj, fc1 + exact-erf GELU, fc2; the up-projection of
+// oneref_feature_extraction.py:221) -- 41 % of the forward at 518x518 crops when it runs on the library.
+//
+// Structure (one 512-thread workgroup per 256 x 256 output tile, K step 64, one workgroup per CU):
+//   * both operands are K-contiguous, so A and W tiles are the same kind of image: [256 rows][64 k] bf16.
+//     Each 1-KiB piece (8 rows x 128 B, whole cache lines) is moved HBM/L2 -> LDS by ONE LDS-DMA wave instruction
+//     (global_load_lds_dwordx4: destination = wave-uniform base + lane * 16).  The bank swizzle therefore lives on
+//     the per-lane SOURCE address: LDS slot (row, p) holds the row's 16-byte chunk  c = p ^ ((row >> 1) & 7)  and the
+//     fragment reads apply the same XOR -- every ds_read_b128 lane group then covers all 16 slots of the 256-byte
+//     bank row (conflict-free), and every DMA instruction still fetches full 128-byte lines;
+//   * two LDS buffers (2 x 64 KiB): the 8 DMA pieces of K-tile t+1 are spread over the four MFMA groups of tile t,
+//     fragment reads run one k-substep ahead of the MFMAs (two register sets), one vmcnt(0) + barrier per K-tile;
+//   * every tile starts its K walk at a tile-dependent K-tile (the sum is order-independent): concurrently running
+//     tiles then touch different 128-byte columns of their panels at any instant;
+//   * 8 waves as 2 (M) x 4 (N), 128 x 64 outputs per wave, v_mfma_f32_32x32x16_bf16 with the operands SWAPPED
+//     (rows of the MFMA result = output columns n): a lane then owns 4 consecutive n of one output row, which
+//     packs to 8-byte LDS writes in the epilogue;
+//   * epilogue: + bias, optional exact GELU (erf by Abramowitz-Stegun 7.1.26, |err| < 1.5e-7, on the fp32
+//     accumulators -- no bf16 round trip between the Linear and the activation), bf16, staged through LDS
+//     (XOR-swizzled, the K-loop buffers are free by then) and written as whole 128-byte row segments.
+#include "common.h"
+
+namespace unopose {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+#ifndef GEMM_ABL
+#define GEMM_ABL 0  // scripts/ubench/gemm_abl.py builds variants: 1 = no LDS-DMA in the K loop, 2 = no MFMAs, 3 = no fragment reads
+#endif
+#ifndef GEMM_ROT
+#define GEMM_ROT 1  // K-tile rotation (measured +7 % at K = 768, neutral at K = 3072; scripts/ubench/gemm_abl.py)
+#endif
+#define GEMM_BM 256
+#define GEMM_BN 256
+#define GEMM_BK 64
+#define GEMM_OPBYTES (256 * 64 * 2)       // one operand tile: 32 KiB
+#define GEMM_BUFBYTES (2 * GEMM_OPBYTES)  // A + W: 64 KiB
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  // 0.5 x (1 + erf(x / sqrt 2)); erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), z >= 0
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  const float erfz = fmaf(-p, e, 1.0f);  // erf(|x| / sqrt 2)
+  const float hx = 0.5f * x;
+  return fmaf(fabsf(hx), erfz, hx);  // 0.5 x + 0.5 |x| erf(|x|/sqrt2) = 0.5 x (1 + sign(x) erf(.))
+}
+
+// XCD-aware, bijective tile order: workgroup b runs on XCD b % 8 (observed dispatch rule; a speed assumption only),
+// each XCD walks one contiguous range of tiles so neighbouring tiles (same A row panel) share an L2.
+__device__ __forceinline__ int xcd_swizzle(int bid, int n) {
+  const int q = n >> 3, r = n & 7, xcd = bid & 7, k = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <int EPI>  // 0: bias; 1: bias + exact GELU
+__global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict__ A, const u16 *__restrict__ W,
+                                                           const float *__restrict__ bias, u16 *__restrict__ C, int M,
+                                                           int N, int K, int tiles_n, int tiles) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * GEMM_BUFBYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = xcd_swizzle(blockIdx.x, tiles);
+  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // ---- LDS-DMA (buffer_load_dwordx4 ... lds): piece j = wave * 4 + i covers tile rows 8j .. 8j+7; per-lane byte offset
+  //      in the VGPR, K-tile offset in an SGPR; rows past M (ragged last tile) fall outside the descriptor -> zeros
+  uint32_t a_off[4], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    a_off[i] = (uint32_t)(((size_t)(m0 + row) * K + c * 8) * 2);
+    w_off[i] = (uint32_t)(((size_t)(n0 + row) * K + c * 8) * 2);
+  }
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, (int)((size_t)M * K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, (int)((size_t)N * K * 2), 0x00020000);
+  // K-tile rotation: tile t walks K starting at a tile-dependent K-tile, so concurrently running tiles touch
+  // different 128-byte columns of their row panels at any instant (spreads the L2 / fabric channels)
+  const int nk_ = K / GEMM_BK;
+  const int rot = GEMM_ROT ? (tm * 5 + tn * 3) % nk_ : 0;
+  auto stage1 = [&](int buf, int kt, int i) {  // pieces i of A and W of K-tile kt (i = 0..3)
+    kt += rot;
+    if (kt >= nk_) kt -= nk_;
+    char *la = smem + buf * GEMM_BUFBYTES + wave * 4096 + i * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void *)la, 16, a_off[i], kt * (GEMM_BK * 2), 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (__attribute__((address_space(3))) void *)(la + GEMM_OPBYTES), 16, w_off[i],
+                                             kt * (GEMM_BK * 2), 0, 0);
+  };
+
+  // ---- fragment read addresses: tile row r = base + l31 (base a multiple of 32), chunk c = 2 ks + hi:
+  //      byte = (r >> 3) * 1024 + (r & 7) * 128 + ((c ^ ((r >> 1) & 7)) << 4)
+  const int fx = (l31 >> 1) & 7;
+  uint32_t fr_off[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) fr_off[ks] = (uint32_t)((l31 >> 3) * 1024 + (l31 & 7) * 128 + ((((ks << 1) | hi) ^ fx) << 4));
+  const uint32_t a_base = (uint32_t)(wm * 128 * 128);                // A rows wm*128 .. (+ mb * 32 rows = mb * 4096 B)
+  const uint32_t w_base = (uint32_t)(GEMM_OPBYTES + wn * 64 * 128);  // W rows wn*64 ..  (+ nb * 4096 B)
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][mb][r] = 0.f;
+
+  const int nk = K / GEMM_BK;
+  auto read_frags = [&](const char *lb, int ks, bf16x8 (&wf)[2], bf16x8 (&af)[4]) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) wf[nb] = *reinterpret_cast<const bf16x8 *>(lb + w_base + nb * 4096 + fr_off[ks]);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) af[mb] = *reinterpret_cast<const bf16x8 *>(lb + a_base + mb * 4096 + fr_off[ks]);
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) stage1(0, 0, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // Software pipeline inside a K-tile: the fragment reads of k-substep ks+1 are issued BEFORE the 8 MFMAs of substep ks
+  // (two register sets), and the 8 LDS-DMA pieces of the next K-tile are spread over the four MFMA groups (2 per
+  // group) instead of being issued in one ~500-cycle burst right after the barrier.
+  bf16x8 wf0[2], af0[4], wf1[2], af1[4];
+  read_frags(smem, 0, wf0, af0);
+#define GEMM_STEP(MORE, KS, WC, AC, WN, AN)                                                             \
+    if ((KS) < 3 && GEMM_ABL != 3) read_frags(lb, (KS) + 1, WN, AN);                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if (GEMM_ABL == 2) { asm volatile("" ::"v"(WC[0]), "v"(WC[1]), "v"(AC[0]), "v"(AC[1]), "v"(AC[2]), "v"(AC[3])); } \
+    if (GEMM_ABL != 2) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[0], acc[0][0], 0, 0, 0);            \
+    if (GEMM_ABL != 2) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[1], acc[0][1], 0, 0, 0);            \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if (MORE && GEMM_ABL != 1) stage1(buf ^ 1, kt + 1, (KS));                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if (GEMM_ABL != 2) acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[2], acc[0][2], 0, 0, 0);            \
+    if (GEMM_ABL != 2) acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[3], acc[0][3], 0, 0, 0);            \
+    if (GEMM_ABL != 2) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[0], acc[1][0], 0, 0, 0);            \
+    if (GEMM_ABL != 2) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[1], acc[1][1], 0, 0, 0);            \
+    if (GEMM_ABL != 2) acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[2], acc[1][2], 0, 0, 0);            \
+    if (GEMM_ABL != 2) acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[3], acc[1][3], 0, 0, 0);            \
+    __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 0; kt < nk - 1; ++kt) {
+    const int buf = kt & 1;
+    const char *lb = smem + buf * GEMM_BUFBYTES;
+    GEMM_STEP(true, 0, wf0, af0, wf1, af1)
+    GEMM_STEP(true, 1, wf1, af1, wf0, af0)
+    GEMM_STEP(true, 2, wf0, af0, wf1, af1)
+    GEMM_STEP(true, 3, wf1, af1, wf0, af0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (GEMM_ABL != 3) read_frags(smem + (buf ^ 1) * GEMM_BUFBYTES, 0, wf0, af0);
+  }
+  {
+    const int kt = nk - 1, buf = kt & 1;
+    const char *lb = smem + buf * GEMM_BUFBYTES;
+    GEMM_STEP(false, 0, wf0, af0, wf1, af1)
+    GEMM_STEP(false, 1, wf1, af1, wf0, af0)
+    GEMM_STEP(false, 2, wf0, af0, wf1, af1)
+    GEMM_STEP(false, 3, wf1, af1, wf0, af0)
+    __syncthreads();  // every wave is done reading the K-loop buffers: the epilogue reuses them
+  }
+#undef GEMM_STEP
+
+  // ---- epilogue: acc[nb][mb][4g + e] = C[m = wm*128 + mb*32 + l31][n = wn*64 + nb*32 + 8g + 4hi + e]
+  char *cw = smem + wave * (128 * 128);  // this wave's [128 rows][64 n] bf16 image, 16-byte slots XOR-swizzled by row
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nl = nb * 32 + 8 * g + 4 * hi;  // local column of the 4 values
+      const float4 bv = *reinterpret_cast<const float4 *>(bias + n0 + wn * 64 + nl);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        float v0 = acc[nb][mb][4 * g + 0] + bv.x, v1 = acc[nb][mb][4 * g + 1] + bv.y;
+        float v2 = acc[nb][mb][4 * g + 2] + bv.z, v3 = acc[nb][mb][4 * g + 3] + bv.w;
+        if (EPI == 1) {
+          v0 = gelu_erf(v0);
+          v1 = gelu_erf(v1);
+          v2 = gelu_erf(v2);
+          v3 = gelu_erf(v3);
+        }
+        const int row = mb * 32 + l31;
+        const int slot = (nl >> 3) ^ (row & 7);
+        *reinterpret_cast<uint2 *>(cw + row * 128 + slot * 16 + (nl & 4) * 2) = make_uint2(cvt_pk_bf16_f32(v0, v1), cvt_pk_bf16_f32(v2, v3));
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  char *Cb = reinterpret_cast<char *>(C);
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 8 + (lane >> 3), q = lane & 7;
+    const uint4 v = *reinterpret_cast<const uint4 *>(cw + row * 128 + ((q ^ (row & 7)) << 4));
+    const int m = m0 + wm * 128 + row;
+    if (m < M) *reinterpret_cast<uint4 *>(Cb + ((size_t)m * N + n0 + wn * 64 + q * 8) * 2) = v;
+  }
+}
+
+}  // namespace unopose
+
+using namespace unopose;
+
+extern "C" {
+
+int unopose_gemm_bf16_tile(void) { return GEMM_BM; }
+
+int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C, long M, int N, int K, int epilogue,
+                        unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(A && W && bias && C, "linear_bf16: null pointer");
+  UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && K >= GEMM_BK && K % GEMM_BK == 0,
+                  "linear_bf16: needs N %% 256 == 0 and K %% 64 == 0 (got M=%ld N=%d K=%d)", M, N, K);
+  UNOPOSE_REQUIRE((size_t)M * K * 2 < (1UL << 32) && (size_t)N * K * 2 < (1UL << 32), "linear_bf16: operand larger than 4 GiB");
+  UNOPOSE_REQUIRE(epilogue == 0 || epilogue == 1, "linear_bf16: epilogue must be 0 (bias) or 1 (bias + GELU)");
+  const int tiles_m = cdiv(M, GEMM_BM), tiles_n = N / GEMM_BN, tiles = tiles_m * tiles_n;
+  hipStream_t s = (hipStream_t)stream;
+  if (epilogue == 1)
+    hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(tiles), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
+                       K, tiles_n, tiles);
+  else
+    hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(tiles), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
+                       K, tiles_n, tiles);
+  return check_launch("linear_bf16");
+}
+
+}  // extern "C"
