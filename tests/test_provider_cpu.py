@@ -18,24 +18,25 @@ def test_helpers_match_reference_golden():
     z = np.load(os.path.join(GOLD, "provider_helpers.npz"))
     for i in range(12):
         m = z[f"bbox_mask_{i}"]
-        assert list(P.get_bbox(m)) == z[f"bbox_out_{i}"].tolist()
+        assert P.Window.around(m).as_list() == z[f"bbox_out_{i}"].tolist()
         rle = {"size": list(m.shape), "counts": z[f"rle_counts_{i}"].tolist()}
         assert np.array_equal(P.rle_decode(rle).astype(bool), z[f"rle_mask_{i}"])  # data_utils.rle_to_binary_mask
         assert np.array_equal(P.rle_decode(rle).astype(bool), m)
-    assert np.array_equal(P.backproject(z["bp_depth"], z["bp_K"]), z["bp_full"])
-    assert np.array_equal(P.backproject(z["bp_depth"], z["bp_K"], [3, 33, 10, 40]), z["bp_crop"])
+    win = P.Window(3, 33, 10, 40)
+    assert np.array_equal(P.lift_depth(z["bp_depth"], z["bp_K"]), z["bp_full"])
+    assert np.array_equal(P.lift_depth(z["bp_depth"], z["bp_K"], win), z["bp_crop"])
     for size in (224, 56, 518):
-        assert np.array_equal(P.get_resize_rgb_choose(z["rc_choose"], [3, 33, 10, 40], size), z[f"rc_out_{size}"])
+        assert np.array_equal(win.to_resized(z["rc_choose"], size), z[f"rc_out_{size}"])
 
 
 def test_bbox_edge_cases():
     m = np.zeros((40, 60), bool)
     m[0:3, 55:60] = True  # corner: the square (side 2*int(5/2) = 4, the reference's rounding) is pushed back inside
-    y1, y2, x1, x2 = P.get_bbox(m)
+    y1, y2, x1, x2 = P.Window.around(m).as_list()
     assert (y1, y2, x1, x2) == (0, 4, 55, 59)
     m[:] = True  # whole image: side clipped to min(H, W)
-    y1, y2, x1, x2 = P.get_bbox(m)
-    assert y2 - y1 == 40 and x2 - x1 == 40
+    y1, y2, x1, x2 = P.Window.around(m).as_list()
+    assert y2 - y1 == 40 and x2 - x1 == 40 and P.Window.around(m).side == 40
 
 
 def test_rle_string_known_answers_and_round_trip():

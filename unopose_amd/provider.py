@@ -1,11 +1,20 @@
 """BOP test-set data provider for the one-reference setting: the producer side of UNOPose.forward's
 input dict.
 
-Host-side mirror of ``BOPTestsetPoseFreeOneRefv2`` (core/unopose/provider/pfoneref_bop_test_dataset_v2.py:33-354)
-and of the helpers it takes from core/unopose/utils/data_utils.py (``get_bbox`` :249-283, ``backproject``
-:216-229, ``get_resize_rgb_choose`` :232-246, ``get_bop_depth_map`` :339-351, ``get_bop_image`` :404-430,
-``rle_to_binary_mask`` :168-185).  Same constructor fields, same per-instance dict (keys, dtypes, shapes),
-same order of ``np.random`` draws, so a seeded run reproduces the reference's samples.
+Contract = the items of ``BOPTestsetPoseFreeOneRefv2`` (core/unopose/provider/pfoneref_bop_test_dataset_v2.py:33-354;
+geometry conventions of core/unopose/utils/data_utils.py:216-283): same constructor fields, same per-image dict
+(keys, dtypes, shapes), same ``np.random`` stream consumption, so a seeded run reproduces the reference's samples
+bit for bit (tests/golden/make_provider_golden.py runs the reference class on the same files).
+
+Structure is this repo's own, built around what is invariant per IMAGE and per REFERENCE VIEW instead of per
+detection:
+  * :class:`SceneFiles` reads every json / depth / colour file at most once (small LRU): the reference re-opens
+    scene_camera.json, the depth map and the colour image for every detection of an image;
+  * :class:`ReferenceViews` keeps the deterministic part of a reference view (window, masked cloud, normalised crop,
+    pose) across the many query instances that share it -- only the 5000-point draw is per instance (it must be:
+    it consumes the random stream);
+  * :class:`Window` carries the square crop geometry (construction from a mask, cropping, window-pixel ->
+    resized-crop index map) as one value object.
 
 Third-party pieces the reference calls that this image lacks are restated here:
   * pycocotools ``frPyObjects`` / ``decode``  -> :func:`rle_decode` (COCO RLE, compressed or not);
@@ -119,59 +128,62 @@ def rle_encode(mask):
 
 
 # ------------------------------------------------------------------------------------------------
-# geometry helpers (data_utils.py)
+# crop geometry
 # ------------------------------------------------------------------------------------------------
-def get_bbox(label):
-    """Square box around the mask, side = min(max(h_box, w_box), min(H, W)), centred on the mask's box and
-    shifted back inside the image (data_utils.py:249-283).  Returns [y1, y2, x1, x2]."""
-    img_width, img_length = label.shape
-    rows = np.any(label, axis=1)
-    cols = np.any(label, axis=0)
-    rmin, rmax = np.where(rows)[0][[0, -1]]
-    cmin, cmax = np.where(cols)[0][[0, -1]]
-    rmax += 1
-    cmax += 1
-    b = min(max(rmax - rmin, cmax - cmin), min(img_width, img_length))
-    center = [int((rmin + rmax) / 2), int((cmin + cmax) / 2)]
-    rmin, rmax = center[0] - int(b / 2), center[0] + int(b / 2)
-    cmin, cmax = center[1] - int(b / 2), center[1] + int(b / 2)
-    if rmin < 0:
-        rmax += -rmin
-        rmin = 0
-    if cmin < 0:
-        cmax += -cmin
-        cmin = 0
-    if rmax > img_width:
-        rmin -= rmax - img_width
-        rmax = img_width
-    if cmax > img_length:
-        cmin -= cmax - img_length
-        cmax = img_length
-    return [rmin, rmax, cmin, cmax]
+class Window:
+    """Square pixel window [y0, y1) x [x0, x1) around a mask (the reference's crop convention,
+    data_utils.py:249-283): side = min(longer extent of the mask's bounding box, shorter image side), rounded
+    down to even by the half-side arithmetic, centred on the box and pushed back inside the image."""
+
+    __slots__ = ("y0", "y1", "x0", "x1")
+
+    def __init__(self, y0, y1, x0, x1):
+        self.y0, self.y1, self.x0, self.x1 = int(y0), int(y1), int(x0), int(x1)
+
+    @classmethod
+    def around(cls, mask):
+        H, W = mask.shape
+        ys = np.flatnonzero(mask.any(axis=1))
+        xs = np.flatnonzero(mask.any(axis=0))
+        top, bottom, left, right = ys[0], ys[-1] + 1, xs[0], xs[-1] + 1  # half-open extents
+        half = int(min(max(bottom - top, right - left), min(H, W)) / 2)
+        cy, cx = int((top + bottom) / 2), int((left + right) / 2)
+        y0, x0 = cy - half, cx - half
+        y0 -= min(y0, 0)  # left / top overflow: shift right / down
+        x0 -= min(x0, 0)
+        y0 -= max(y0 + 2 * half - H, 0)  # bottom / right overflow: shift back
+        x0 -= max(x0 + 2 * half - W, 0)
+        return cls(y0, y0 + 2 * half, x0, x0 + 2 * half)
+
+    def as_list(self):
+        return [self.y0, self.y1, self.x0, self.x1]
+
+    @property
+    def side(self):
+        return self.y1 - self.y0
+
+    def crop(self, arr):
+        return arr[self.y0:self.y1, self.x0:self.x1]
+
+    def to_resized(self, flat_idx, img_size):
+        """Flat index into the window (row-major) -> flat index into the img_size x img_size resized crop.
+        The reference decomposes with the window HEIGHT for rows and columns alike (data_utils.py:243-244;
+        windows are square) and scales by img_size / side in float64 before flooring."""
+        h, w = self.y1 - self.y0, self.x1 - self.x0
+        r, c = np.divmod(flat_idx, h)
+        return (np.floor(r * (img_size / w)) * img_size + np.floor(c * (img_size / h))).astype(np.int64)
 
 
-def backproject(depth, K, bbox=None):
-    """Organised cloud (H, W, 3) of a depth map, optionally cropped (data_utils.py:216-229)."""
+def lift_depth(depth, K, window=None):
+    """Pinhole back-projection of a depth map to an organised (h, w, 3) float64 cloud, optionally only the
+    window: X = (u - cx) d / fx, Y = (v - cy) d / fy, Z = d  (evaluation order of data_utils.py:216-229, so the
+    float64 results are identical)."""
     H, W = depth.shape
-    X, Y = np.meshgrid(np.asarray(range(W)) - K[0, 2], np.asarray(range(H)) - K[1, 2])
-    cloud = np.stack((X * depth / K[0, 0], Y * depth / K[1, 1], depth), axis=2)
-    if bbox is not None:
-        rmin, rmax, cmin, cmax = bbox
-        return cloud[rmin:rmax, cmin:cmax]
-    return cloud
-
-
-def get_resize_rgb_choose(choose, bbox, img_size):
-    """Flat index into the crop -> flat index into the img_size x img_size resized crop
-    (data_utils.py:232-246; the crop is square, and the reference splits rows AND columns by crop_h)."""
-    rmin, rmax, cmin, cmax = bbox
-    crop_h = rmax - rmin
-    ratio_h = img_size / crop_h
-    crop_w = cmax - cmin
-    ratio_w = img_size / crop_w
-    row_idx = choose // crop_h
-    col_idx = choose % crop_h
-    return (np.floor(row_idx * ratio_w) * img_size + np.floor(col_idx * ratio_h)).astype(np.int64)
+    y0, y1, x0, x1 = (0, H, 0, W) if window is None else window.as_list()
+    d = depth[y0:y1, x0:x1]
+    u = (np.arange(x0, x1, dtype=np.int64) - K[0, 2])[None, :]
+    v = (np.arange(y0, y1, dtype=np.int64) - K[1, 2])[:, None]
+    return np.stack((u * d / K[0, 0], v * d / K[1, 1], d), axis=2)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -236,30 +248,102 @@ def to_tensor_normalize(rgb_u8, mean=IMAGENET_MEAN, std=IMAGENET_STD):
     return t.sub_(m).div_(s)
 
 
-def get_bop_depth_map(inst):
-    """Depth in metres before `depth_scale` (data_utils.py:339-351): png first, tif as the fallback."""
-    folder = osp.join(inst["data_folder"], f"{inst['scene_id']:06d}", "depth")
-    png = osp.join(folder, f"{inst['img_id']:06d}.png")
-    path = png if osp.exists(png) else osp.join(folder, f"{inst['img_id']:06d}.tif")
-    return read_image(path) / 1000.0
-
-
-def get_bop_image(inst, bbox, img_size, mask=None, rgb_to_bgr=False):
-    """Crop -> mask -> bilinear resize of the colour (or gray) image (data_utils.py:404-430)."""
-    rmin, rmax, cmin, cmax = bbox
-    folder = osp.join(inst["data_folder"], f"{inst['scene_id']:06d}")
-    img_path = folder + "/"
-    for s in (f"rgb/{inst['img_id']:06d}.jpg", f"rgb/{inst['img_id']:06d}.png", f"gray/{inst['img_id']:06d}.tif"):
-        if osp.exists(osp.join(folder, s)):
-            img_path = osp.join(folder, s)
-            break
-    rgb = read_image(img_path).astype(np.uint8)
-    if rgb.ndim == 2:
-        rgb = np.concatenate([rgb[:, :, None]] * 3, axis=2)
-    rgb = rgb[..., ::-1][rmin:rmax, cmin:cmax, :3] if rgb_to_bgr else rgb[rmin:rmax, cmin:cmax, :3]
+def _normalised_crop(rgb_u8, window, img_size, mask=None, bgr=False):
+    """Window of the colour image -> (masked) -> OpenCV-style bilinear resize -> ImageNet-normalised CHW tensor."""
+    if rgb_u8.ndim == 2:
+        rgb_u8 = np.repeat(rgb_u8[:, :, None], 3, axis=2)
+    patch = window.crop(rgb_u8[..., ::-1] if bgr else rgb_u8)[:, :, :3]
     if mask is not None:
-        rgb = rgb * (mask[:, :, None] > 0).astype(np.uint8)
-    return resize_bilinear_u8(rgb, img_size)
+        patch = patch * (mask[:, :, None] > 0).astype(np.uint8)
+    return to_tensor_normalize(resize_bilinear_u8(patch, img_size))
+
+
+class SceneFiles:
+    """Read-once access to a BOP split folder: per-scene json (camera, ground truth) and per-image depth (metres,
+    depth_scale applied) / colour arrays, each behind a small LRU."""
+
+    def __init__(self, max_scenes=64, max_images=8):
+        from collections import OrderedDict
+
+        self._json, self._img = OrderedDict(), OrderedDict()
+        self._max_json, self._max_img = 2 * max_scenes, 2 * max_images
+
+    @staticmethod
+    def _lru(store, key, limit, make):
+        if key in store:
+            store.move_to_end(key)
+            return store[key]
+        val = store[key] = make()
+        while len(store) > limit:
+            store.popitem(last=False)
+        return val
+
+    def scene_json(self, folder, scene_id, name):
+        path = osp.join(folder, f"{scene_id:06d}", name)
+        return self._lru(self._json, path, self._max_json, lambda: load_json(path))
+
+    def camera(self, folder, scene_id, im_id):
+        cam = self.scene_json(folder, scene_id, "scene_camera.json")[str(im_id)]
+        return np.array(cam["cam_K"]).reshape((3, 3)).copy(), cam["depth_scale"]
+
+    def depth_m(self, folder, scene_id, im_id, depth_scale):
+        """Depth in metres: file value / 1000 * depth_scale (png first, tif as the fallback, data_utils.py:339-351)."""
+        def make():
+            base = osp.join(folder, f"{scene_id:06d}", "depth", f"{im_id:06d}")
+            return read_image(base + ".png" if osp.exists(base + ".png") else base + ".tif") / 1000.0 * depth_scale
+
+        return self._lru(self._img, ("d", folder, scene_id, im_id), self._max_img, make)
+
+    def colour(self, folder, scene_id, im_id):
+        def make():
+            scene = osp.join(folder, f"{scene_id:06d}")
+            for rel in (f"rgb/{im_id:06d}.jpg", f"rgb/{im_id:06d}.png", f"gray/{im_id:06d}.tif"):
+                if osp.exists(osp.join(scene, rel)):
+                    return read_image(osp.join(scene, rel)).astype(np.uint8)
+            raise FileNotFoundError(f"no colour image for scene {scene_id} image {im_id} under {folder}")
+
+        return self._lru(self._img, ("c", folder, scene_id, im_id), self._max_img, make)
+
+
+class ReferenceViews:
+    """The per-view, draw-independent half of a reference instance: visible-mask window, masked organised cloud
+    (float32, reference camera frame, metres), flat indices of the mask pixels inside the window, normalised crop,
+    object pose in that camera.  Built once per (scene, image, object) and reused by every query paired with it."""
+
+    def __init__(self, files, img_size, rgb_mask_flag, bgr, max_views=64):
+        from collections import OrderedDict
+
+        self.files, self.img_size, self.rgb_mask_flag, self.bgr = files, img_size, rgb_mask_flag, bgr
+        self._views, self._max = OrderedDict(), max_views
+
+    def get(self, folder, scene_id, im_id, obj_id):
+        key = (folder, scene_id, im_id, obj_id)
+        if key in self._views:
+            self._views.move_to_end(key)
+            return self._views[key]
+        view = self._views[key] = self._build(folder, scene_id, im_id, obj_id)
+        while len(self._views) > self._max:
+            self._views.popitem(last=False)
+        return view
+
+    def _build(self, folder, scene_id, im_id, obj_id):
+        gts = self.files.scene_json(folder, scene_id, "scene_gt.json")[str(im_id)]
+        slot = next((i for i, gt in enumerate(gts) if gt["obj_id"] == obj_id), None)
+        if slot is None:
+            return None
+        pose = np.eye(4, dtype=np.float32)
+        pose[:3, :3] = np.array(gts[slot]["cam_R_m2c"], dtype=np.float32).reshape(3, 3)
+        pose[:3, 3] = np.array(gts[slot]["cam_t_m2c"], dtype=np.float32).reshape(3) * 0.001
+        K, depth_scale = self.files.camera(folder, scene_id, im_id)
+        depth = self.files.depth_m(folder, scene_id, im_id, depth_scale).astype("float32")
+        visible = np.array(read_image(osp.join(folder, f"{scene_id:06d}", "mask_visib", f"{im_id:06d}_{slot:06d}.png"))).astype(bool)
+        win = Window.around(visible)
+        inside = win.crop(visible)
+        cloud = lift_depth(depth, K, win)
+        cloud *= inside.astype("float32")[:, :, None]
+        crop = _normalised_crop(self.files.colour(folder, scene_id, im_id), win, self.img_size,
+                                inside if self.rgb_mask_flag else None, self.bgr)
+        return dict(window=win, cloud=cloud.reshape(-1, 3), pixels=np.flatnonzero(inside), crop=crop, pose=pose)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -269,172 +353,130 @@ class BOPTestsetOneRef:
 
     cfg fields (attribute or key access): data_dir, ref_targets_name, rgb_mask_flag, img_size,
     n_sample_observed_point, n_sample_template_point, minimum_n_point, seg_filter_score; optional
-    rgb_to_bgr, obj_idxs, oneref_percat (+ targets_name, ref_scene_ims)."""
+    rgb_to_bgr, obj_idxs, oneref_percat (+ targets_name, ref_scene_ims).
+
+    `dets` maps "<scene:06d>_<image:06d>" to the image's detection dicts in file order (the runner deep-copies it
+    for the detections json, like ``data_loader.dataset.dets``)."""
 
     def __init__(self, cfg, eval_dataset_name="lmo", detetion_path=None):
         assert detetion_path is not None
-        get = (lambda k, d=None: cfg.get(k, d)) if hasattr(cfg, "get") else (lambda k, d=None: getattr(cfg, k, d))
-        self.cfg = cfg
-        self.dataset = eval_dataset_name
-        self.data_dir = get("data_dir")
-        self.ref_targets_name = get("ref_targets_name")
-        self.rgb_mask_flag = get("rgb_mask_flag")
-        self.img_size = get("img_size")
-        self.n_sample_observed_point = get("n_sample_observed_point")
-        self.n_sample_template_point = get("n_sample_template_point")
-        self.minimum_n_point = get("minimum_n_point")
-        self.seg_filter_score = get("seg_filter_score")
-        self.rgb_to_bgr = get("rgb_to_bgr", False)
-        obj_idxs = get("obj_idxs", None)
-        if obj_idxs is None:
-            obj_idxs = {obj_id: i for i, obj_id in enumerate(DATASET_OBJ_IDS[eval_dataset_name])}
-        self.obj_idxs = obj_idxs
+        opt = (lambda k, d=None: cfg.get(k, d)) if hasattr(cfg, "get") else (lambda k, d=None: getattr(cfg, k, d))
+        self.cfg, self.dataset = cfg, eval_dataset_name
+        for name in ("data_dir", "ref_targets_name", "rgb_mask_flag", "img_size", "n_sample_observed_point",
+                     "n_sample_template_point", "minimum_n_point", "seg_filter_score"):
+            setattr(self, name, opt(name))
+        self.rgb_to_bgr = opt("rgb_to_bgr", False)
+        self.obj_idxs = opt("obj_idxs") or {obj_id: i for i, obj_id in enumerate(DATASET_OBJ_IDS[eval_dataset_name])}
         self.data_folder = osp.join(self.data_dir, eval_dataset_name, "test")
-        if get("oneref_percat", False):
-            assert get("targets_name") is not None
-            self.test_ref_target = self.load_single_ref_per_dset(
-                osp.join(self.data_dir, eval_dataset_name, get("targets_name")), get("ref_scene_ims"))
+        self.files = SceneFiles()
+        self.ref_views = ReferenceViews(self.files, self.img_size, self.rgb_mask_flag, self.rgb_to_bgr)
+        root = osp.join(self.data_dir, eval_dataset_name)
+        if opt("oneref_percat", False):
+            assert opt("targets_name") is not None
+            self.test_ref_target = self.load_single_ref_per_dset(osp.join(root, opt("targets_name")), opt("ref_scene_ims"))
         else:
-            self.test_ref_target = self.load_ref(osp.join(self.data_dir, eval_dataset_name, self.ref_targets_name))
-        self.det_keys, self.dets = [], {}
+            self.test_ref_target = self.load_ref(osp.join(root, self.ref_targets_name))
+        self.dets = {}
         for det in load_json(detetion_path):
-            key = str(det["scene_id"]).zfill(6) + "_" + str(det["image_id"]).zfill(6)
-            if key not in self.dets:
-                self.det_keys.append(key)
-                self.dets[key] = []
-            self.dets[key].append(det)
+            self.dets.setdefault(f"{int(det['scene_id']):06d}_{int(det['image_id']):06d}", []).append(det)
+        self.det_keys = list(self.dets)  # first-appearance order of the images in the detection file
 
     def __len__(self):
         return len(self.det_keys)
 
+    # ---- one image --------------------------------------------------------------------------------------------
     def __getitem__(self, index):
-        dets = self.dets[self.det_keys[index]]
-        instances, inst_ids = [], []
-        for det_i, det in enumerate(dets):
-            if det["score"] > self.seg_filter_score:
-                instance = self.get_instance(det)
-                if instance is not None:
-                    instances.append(instance)
-                    inst_ids.append(det_i)
-        if len(instances) == 0:  # keep at least the best detection (:113-124)
-            scores = [det["score"] for det in dets]
-            best = scores.index(max(scores))
-            instance = self.get_instance(dets[best])
-            if instance is None:
-                raise ValueError(f"no qulified instance in {self.det_keys[index]}")
-            instances.append(instance)
-            inst_ids.append(best)
-        ret = {}
-        for key in instances[0].keys():
-            if key == "ref_key":  # this provider's addition: identifies the reference view (runner.ReferenceCache)
-                ret["ref_keys"] = [inst[key] for inst in instances]
-            else:
-                ret[key] = torch.stack([inst[key] for inst in instances])
-        ret["scene_id"] = torch.IntTensor([int(self.det_keys[index][0:6])])
-        ret["img_id"] = torch.IntTensor([int(self.det_keys[index][7:13])])
-        ret["inst_ids"] = torch.IntTensor(inst_ids)
-        ret["seg_time"] = torch.FloatTensor([dets[0]["time"]])
-        return ret
+        key = self.det_keys[index]
+        dets = self.dets[key]
+        picked = [(i, inst) for i, inst in ((i, self.get_instance(d)) for i, d in enumerate(dets) if d["score"] > self.seg_filter_score)
+                  if inst is not None]
+        if not picked:  # nothing passed the score filter (or survived it): fall back to the best-scored detection
+            best = max(range(len(dets)), key=lambda i: (dets[i]["score"], -i))
+            inst = self.get_instance(dets[best])
+            if inst is None:
+                raise ValueError(f"no qulified instance in {key}")
+            picked = [(best, inst)]
+        insts = [inst for _, inst in picked]
+        item = {k: torch.stack([inst[k] for inst in insts]) for k in insts[0] if k != "ref_key"}
+        item["ref_keys"] = [inst["ref_key"] for inst in insts]  # this provider's addition (runner.ReferenceCache)
+        item["scene_id"] = torch.IntTensor([int(key[:6])])
+        item["img_id"] = torch.IntTensor([int(key[7:13])])
+        item["inst_ids"] = torch.IntTensor([i for i, _ in picked])
+        item["seg_time"] = torch.FloatTensor([dets[0]["time"]])
+        return item
 
-    def get_instance(self, data):
-        scene_id, img_id, obj_id = data["scene_id"], data["image_id"], data["category_id"]
-        seg, score = data["segmentation"], data["score"]
-        scene_camera = load_json(osp.join(self.data_folder, f"{scene_id:06d}", "scene_camera.json"))
-        K = np.array(scene_camera[str(img_id)]["cam_K"]).reshape((3, 3)).copy()
-        depth_scale = scene_camera[str(img_id)]["depth_scale"]
-        inst = dict(scene_id=scene_id, img_id=img_id, data_folder=self.data_folder)
-        obj_idx = self.obj_idxs[obj_id]
-        depth = get_bop_depth_map(inst) * depth_scale
-        mask = np.logical_and(rle_decode(seg) > 0, depth > 0)  # segmentation restricted to valid depth
-        if not np.sum(mask) > self.minimum_n_point:
+    # ---- one detection ----------------------------------------------------------------------------------------
+    def get_instance(self, det):
+        """Query side of one (detection, reference) pair, or None when the detection has too little valid depth, no
+        reference target, or too few points near the reference's size.  Consumes the global ``np.random`` stream
+        exactly like the reference: the reference-view draw first, then the query draw (:187-203, :296-304)."""
+        scene_id, img_id, obj_id = det["scene_id"], det["image_id"], det["category_id"]
+        K, depth_scale = self.files.camera(self.data_folder, scene_id, img_id)
+        depth = self.files.depth_m(self.data_folder, scene_id, img_id, depth_scale)
+        valid = np.logical_and(rle_decode(det["segmentation"]) > 0, depth > 0)  # segmentation restricted to measured depth
+        if not np.sum(valid) > self.minimum_n_point:
             return None
-        y1, y2, x1, x2 = get_bbox(mask)
-        mask = mask[y1:y2, x1:x2]
-        choose = mask.astype(np.float32).flatten().nonzero()[0]
-        cloud = backproject(depth, K, [y1, y2, x1, x2]).reshape(-1, 3)[choose, :]
-        tmp_cloud = cloud - np.mean(cloud, axis=0)[None, :]
+        win = Window.around(valid)
+        inside = win.crop(valid)
+        pixels = np.flatnonzero(inside)
+        cloud = lift_depth(depth, K, win).reshape(-1, 3)[pixels]
+        centred = cloud - np.mean(cloud, axis=0)[None, :]
 
-        tem_rgb, tem_choose, tem_pts, pose_camref_obj, ref_key = self._get_ref_instance(scene_id, img_id, obj_id)
-        if tem_rgb is None:
+        ref = self._reference_instance(scene_id, img_id, obj_id)
+        if ref is None:
             return None
-        # outlier filter: keep points within 1.2 reference radii of the observed centroid (:187-198)
-        radius = np.max(np.linalg.norm(tem_pts - np.mean(tem_pts, axis=0).reshape(1, 3), axis=1))
-        flag = np.linalg.norm(tmp_cloud, axis=1) < 1.2 * radius
-        if np.sum(flag) < self.minimum_n_point:
+        ref_crop, ref_choose, ref_pts, ref_pose, ref_key = ref
+        # keep what lies within 1.2 reference radii of the observed centroid (drops background leaking into the mask)
+        radius = np.max(np.linalg.norm(ref_pts - np.mean(ref_pts, axis=0).reshape(1, 3), axis=1))
+        near = np.linalg.norm(centred, axis=1) < 1.2 * radius
+        if np.sum(near) < self.minimum_n_point:
             return None
-        choose, cloud = choose[flag], cloud[flag]
+        pixels, cloud = pixels[near], cloud[near]
         n = self.n_sample_observed_point
-        choose_idx = np.random.choice(np.arange(len(choose)), size=n, replace=len(choose) <= n)
-        choose, cloud = choose[choose_idx], cloud[choose_idx]
-
-        rgb = get_bop_image(inst, [y1, y2, x1, x2], self.img_size, mask if self.rgb_mask_flag else None,
-                            rgb_to_bgr=self.rgb_to_bgr)
-        rgb = to_tensor_normalize(np.array(rgb))
-        rgb_choose = get_resize_rgb_choose(choose, [y1, y2, x1, x2], self.img_size)
+        take = np.random.choice(np.arange(len(pixels)), size=n, replace=len(pixels) <= n)
+        pixels, cloud = pixels[take], cloud[take]
+        crop = _normalised_crop(self.files.colour(self.data_folder, scene_id, img_id), win, self.img_size,
+                                inside if self.rgb_mask_flag else None, self.rgb_to_bgr)
         return {
             "pts": torch.FloatTensor(cloud),
-            "rgb": torch.FloatTensor(rgb),
-            "rgb_choose": torch.IntTensor(rgb_choose).long(),
-            "obj": torch.IntTensor([obj_idx]).long(),
+            "rgb": torch.FloatTensor(crop),
+            "rgb_choose": torch.IntTensor(win.to_resized(pixels, self.img_size)).long(),
+            "obj": torch.IntTensor([self.obj_idxs[obj_id]]).long(),
             "obj_id": torch.IntTensor([obj_id]),
-            "score": torch.FloatTensor([score]),
-            "tem1_rgb": torch.FloatTensor(tem_rgb),
-            "tem1_choose": torch.IntTensor(tem_choose).long(),
-            "tem1_pts": torch.FloatTensor(tem_pts),
-            "tem1_pose": torch.FloatTensor(pose_camref_obj),
+            "score": torch.FloatTensor([det["score"]]),
+            "tem1_rgb": torch.FloatTensor(ref_crop),
+            "tem1_choose": torch.IntTensor(ref_choose).long(),
+            "tem1_pts": torch.FloatTensor(ref_pts),
+            "tem1_pose": torch.FloatTensor(ref_pose),
             "ref_key": ref_key,
         }
 
-    def _ref_data_folder(self, ref_scene_id):
-        if self.dataset == "ycbv":  # references outside the 12 test scenes live in train_real (:246-251)
-            return self.data_folder if ref_scene_id in range(48, 60) else osp.join(self.data_dir, self.dataset, "train_real")
-        if self.dataset == "tudl":
-            return osp.join(self.data_dir, self.dataset, "train_real")
-        return self.data_folder
+    def _ref_split_folder(self, ref_scene_id):
+        """Where a reference scene lives: ycbv references outside the 12 test scenes and all tudl references come
+        from train_real (:246-251)."""
+        train_real = osp.join(self.data_dir, self.dataset, "train_real")
+        if self.dataset == "ycbv":
+            return self.data_folder if 48 <= ref_scene_id < 60 else train_real
+        return train_real if self.dataset == "tudl" else self.data_folder
 
-    def _get_ref_instance(self, scene_id, img_id, obj_id):
-        none = (None, None, None, None, None)
-        key = f"{scene_id}_{img_id}_{obj_id}"
-        if key not in self.test_ref_target:
-            return none
-        ref_scene_id, ref_im_id = (int(v) for v in self.test_ref_target[key].split("_"))
-        data_folder = self._ref_data_folder(ref_scene_id)
-        scene_folder = osp.join(data_folder, f"{ref_scene_id:06d}")
-        scene_camera = load_json(osp.join(scene_folder, "scene_camera.json"))
-        K = np.array(scene_camera[str(ref_im_id)]["cam_K"]).reshape((3, 3)).copy()
-        pose_camref_obj = ref_mask_path = None
-        for i, gt in enumerate(load_json(osp.join(scene_folder, "scene_gt.json"))[str(ref_im_id)]):
-            if gt["obj_id"] == obj_id:
-                ref_mask_path = osp.join(data_folder, f"{ref_scene_id:06d}/mask_visib/{ref_im_id:06d}_{i:06d}.png")
-                pose_camref_obj = np.eye(4, dtype=np.float32)
-                pose_camref_obj[:3, :3] = np.array(gt["cam_R_m2c"], dtype=np.float32).reshape(3, 3)
-                pose_camref_obj[:3, 3] = np.array(gt["cam_t_m2c"], dtype=np.float32).reshape(3) * 0.001
-                break
-        if pose_camref_obj is None:
-            return none
-        depth_scale = scene_camera[str(ref_im_id)]["depth_scale"]
-        inst = dict(scene_id=ref_scene_id, img_id=ref_im_id, data_folder=data_folder)
-        depth = (get_bop_depth_map(inst) * depth_scale).astype("float32")
-        mask = np.array(read_image(ref_mask_path)).astype(bool)
-        bbox = get_bbox(mask)
-        y1, y2, x1, x2 = bbox
-        mask = mask[y1:y2, x1:x2]
-        ref_xyz = backproject(depth, K, bbox)
-        ref_xyz *= mask.astype("float32")[:, :, None]
-        ref_rgb = get_bop_image(inst, [y1, y2, x1, x2], self.img_size, mask if self.rgb_mask_flag else None,
-                                rgb_to_bgr=self.rgb_to_bgr)
-        ref_rgb = to_tensor_normalize(np.array(ref_rgb))
-        ref_choose = (mask > 0).astype(np.float32).flatten().nonzero()[0]
-        n = self.n_sample_template_point
-        if len(ref_choose) <= n:
-            choose_idx = np.random.choice(np.arange(len(ref_choose)), n)
+    def _reference_instance(self, scene_id, img_id, obj_id):
+        target = self.test_ref_target.get(f"{scene_id}_{img_id}_{obj_id}")
+        if target is None:
+            return None
+        ref_scene, ref_im = (int(v) for v in target.split("_"))
+        view = self.ref_views.get(self._ref_split_folder(ref_scene), ref_scene, ref_im, obj_id)
+        if view is None:
+            return None
+        pixels, n = view["pixels"], self.n_sample_template_point
+        if len(pixels) <= n:  # same two call forms as the reference, so the random stream advances identically
+            take = np.random.choice(np.arange(len(pixels)), n)
         else:
-            choose_idx = np.random.choice(np.arange(len(ref_choose)), n, replace=False)
-        ref_choose = ref_choose[choose_idx]
-        ref_xyz = ref_xyz.reshape(-1, 3)[ref_choose, :]
-        ref_rgb_choose = get_resize_rgb_choose(ref_choose, [y1, y2, x1, x2], self.img_size)
-        return ref_rgb, ref_rgb_choose, ref_xyz, pose_camref_obj, (ref_scene_id, ref_im_id, obj_id)
+            take = np.random.choice(np.arange(len(pixels)), n, replace=False)
+        pixels = pixels[take]
+        return (view["crop"], view["window"].to_resized(pixels, self.img_size), view["cloud"][pixels, :], view["pose"],
+                (ref_scene, ref_im, obj_id))
 
+    # ---- target lists -----------------------------------------------------------------------------------------
     @staticmethod
     def load_ref(path):
         """[{scene_id, im_id, obj_id, ref_scene_id, ref_im_id}] -> {"scene_im_obj": "refscene_refim"} (:314-331)."""
@@ -442,14 +484,9 @@ class BOPTestsetOneRef:
                 for t in load_json(path)}
 
     def load_single_ref_per_dset(self, test_target_path, ref_scene_ims):
-        """One fixed reference view per object id (:333-354)."""
+        """One fixed reference view per object id, `ref_scene_ims[i]` = "scene_im" of object i + 1 (:333-354)."""
         assert len(ref_scene_ims) == len(self.obj_idxs)
-        ref_dict = {i + 1: tuple(int(v) for v in s.split("_")) for i, s in enumerate(ref_scene_ims)}
-        out = {}
-        for t in load_json(test_target_path):
-            rs, ri = ref_dict[t["obj_id"]]
-            out[f"{t['scene_id']}_{t['im_id']}_{t['obj_id']}"] = f"{rs}_{ri}"
-        return out
+        return {f"{t['scene_id']}_{t['im_id']}_{t['obj_id']}": ref_scene_ims[t["obj_id"] - 1] for t in load_json(test_target_path)}
 
 
 def collate_image(item):
