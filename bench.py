@@ -37,6 +37,10 @@ def parse(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (same GPU time: "
                     "the step is GPU-bound, not launch-bound, at every batch size measured)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="forwards in flight per GPU: consecutive steps are dealt round-robin over this many HIP streams (a "
+                         "step is still one forward over one batch; the latency-bound tail of one batch then overlaps the "
+                         "ViT of the next).  Large library GEMMs are serialised across the streams (ops.SERIALIZE_BIG_GEMMS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the extra fp32 (reference default precision) leg")
@@ -314,10 +318,25 @@ def main():
 
         graphed = GraphedForward(model, batch, torch.bfloat16 if amp else None)
 
+    streams = None
+    if args.inflight > 1 and not args.dry_run:
+        from unopose_amd import ops
+
+        ops.SERIALIZE_BIG_GEMMS = True
+        streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
+        for s_ in streams:
+            s_.wait_stream(torch.cuda.current_stream())
+    step_no = [0]
+
     def step(use_amp=amp):
         ep = dict(batch)
         if graphed is not None:  # inputs copied into the graph's static buffers, one hipGraphLaunch
             return graphed(ep)
+        if streams is not None:
+            s_ = streams[step_no[0] % len(streams)]
+            step_no[0] += 1
+            with torch.cuda.stream(s_):
+                return forward(ep, use_amp)
         return forward(ep, use_amp)
 
     log("model + batch ready (rank %d of %d)" % (rank, world))
@@ -330,7 +349,7 @@ def main():
     sync()
     # per-step HIP events on the launch stream (median / p10 / p90); `value` keeps the contract's wall clock
     evs = None
-    if not args.dry_run:
+    if not args.dry_run and streams is None:
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -339,6 +358,9 @@ def main():
         out = step()
     if evs is not None:
         evs[-1].record()
+    if streams is not None:  # the default stream (pose gather, sanity) joins every launch stream
+        for s_ in streams:
+            torch.cuda.current_stream().wait_stream(s_)
     poses = torch.cat([out["pred_R"].reshape(B, 9), out["pred_t"], out["pred_pose_score"].reshape(B, 1)], 1)
     if world > 1:  # gather of poses to rank 0 (the reference lacks it: every rank writes the same file)
         poses = poses.to(comm_dev)
@@ -374,6 +396,7 @@ def main():
                                f"random-init (trained-like) weights",
                    "sharding": f"dp{world} (independent pairs, weights broadcast, poses gathered)"},
         "launch": "hipGraph replay" if graphed is not None else "eager",
+        "forwards_in_flight": args.inflight,
         "sanity": {"median_rot_err_vs_gt": rot_err.median().item(),
                    "frac_pairs_solved(<0.05)": (rot_err < 0.05).float().mean().item()},
     }

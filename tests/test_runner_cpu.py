@@ -156,3 +156,23 @@ def test_detections_json_keeps_the_reference_layout():
         assert "pred_R" not in lst[0] and "pred_R" not in lst[-1] and lst[0]["bbox"] == [1, 2, 3, 4]
         for det in lst[1:-1]:
             assert len(det["pred_R"]) == 9 and len(det["pred_t"]) == 3 and det["segmentation"]["counts"] == [16]
+
+
+def test_runner_reproduces_the_reference_loop_capture():
+    """tests/golden/runner_capture.json: CSV rows (minus the wall-clock column) and the detections JSON written by the
+    reference's inference_and_save_oneref_v1 on tests/runner_case.py's inputs with the same stand-in model."""
+    import json
+
+    from runner_case import StubModel, make_case
+
+    cap = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "runner_capture.json")))
+    images, dets = make_case()
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "result.csv")
+        lines = runner.inference_and_save(StubModel(), images, path, instance_batch_size=4, dets=dets)
+        out_dets = json.load(open(path.replace(".csv", ".json")))
+    assert _strip_time(lines) == cap["csv_without_time"]
+    assert [len(l.split(",")) for l in lines] == cap["n_time_fields"]
+    assert all(float(l.rsplit(",", 1)[1]) > 0.25 for l in lines)  # time = loop time + the detector's seg_time
+    assert out_dets == cap["dets"]
+    assert "pred_R" not in dets["000048_000001"][1]  # caller's detections untouched (deep copy)

@@ -59,7 +59,7 @@ constexpr int VA_BUF = VA_CHUNK * VA_LDK + 4 * VA_VSUB;  // u16 per chunk buffer
 // larger workgroup amortises the staging (global loads, LDS writes, barriers: ~1/3 of the kernel at NW = 4
 // by ablation) over twice the MFMA work.
 template <int QB, int NBUF, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1 ? 3 : 2, QB == 1 ? 4 : 2))) void vit_attn_kernel(const u16 *__restrict__ qkv, int T, int H, int BH, int nq,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1 ? 3 : (QB == 4 ? 1 : 2), QB == 1 ? 4 : (QB == 4 ? 1 : 2)))) void vit_attn_kernel(const u16 *__restrict__ qkv, int T, int H, int BH, int nq,
                                                        float scale_log2e, u16 *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16 (*Ot)[32][72] = reinterpret_cast<u16 (*)[32][72]>(smem);
@@ -337,6 +337,8 @@ int unopose_vit_attention(const void *qkv, int B, int T, int H, void *out, unopo
   UNOPOSE_REQUIRE(B >= 0 && T >= 1 && H >= 1 && (long)B * H * cdiv(T, 128) < (1L << 31), "vit_attention: bad sizes");
   if (B == 0) return UNOPOSE_OK;
   static const int nw_env = getenv("UNOPOSE_VIT_NW") ? atoi(getenv("UNOPOSE_VIT_NW")) : 8;
+  static const int qb4_env = getenv("UNOPOSE_VIT_QB4") ? atoi(getenv("UNOPOSE_VIT_QB4")) : 0;  // experiment: 1 wave / SIMD, 128 queries / wave
+  if (T >= 1024 && qb4_env == 1) return launch_vit_attn<4, 2, 4>(qkv, B, T, H, out, (hipStream_t)stream);
   if (T >= 1024 && nw_env == 8) return launch_vit_attn<2, 2, 8>(qkv, B, T, H, out, (hipStream_t)stream);
   if (T >= 512) return launch_vit_attn<2, 2, 4>(qkv, B, T, H, out, (hipStream_t)stream);
   return launch_vit_attn<1, 1, 4>(qkv, B, T, H, out, (hipStream_t)stream);

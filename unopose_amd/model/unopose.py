@@ -230,11 +230,14 @@ class UNOPose(nn.Module):
                     ref_radius=radius, ref_lrf=ops.lrf_global(tem1_pts, self.use_ref_rad))
 
     def _side_stream(self, device):
-        s = getattr(self, "_side", None)
-        if s is None or s.device != device:
-            s = torch.cuda.Stream(device=device)
-            self._side = s
-        return s
+        """The helper stream paired with the CURRENT stream (one per launch stream, so several forwards in flight on
+        different streams do not funnel their side work through one queue)."""
+        cur = torch.cuda.current_stream(device)
+        pool = self.__dict__.setdefault("_side_streams", {})
+        key = (device, cur.cuda_stream)
+        if key not in pool:
+            pool[key] = torch.cuda.Stream(device=device)
+        return pool[key]
 
     def _sample_wlrf(self, pts, pts_lrf, feats, npoint):
         """U:156-177 (gathers done in (B,N,C) layout)."""

@@ -78,6 +78,33 @@ def linear_backend():
         if USE_HIP_GEMM else "hipBLASLt (through torch)"
 
 
+# ---- several forwards in flight on different HIP streams (bench.py --inflight N, a production runner that pipelines
+# batches): hipBLASLt picks stream-K kernels ("..._SK3_...") for the large ViT linears, whose workgroups spin on
+# partner workgroups' partial tiles; two of them co-scheduled from different streams can each hold CUs the other's
+# partners need (observed as a GPU hang in round 1).  With SERIALIZE_BIG_GEMMS set, every large library GEMM waits
+# for the previous one -- whichever stream it ran on -- so at most ONE kernel with inter-workgroup waits is ever in
+# flight; every other kernel on the path (all hand-written ones, the small non-stream-K library GEMMs) is free of
+# such waits and overlaps freely.
+SERIALIZE_BIG_GEMMS = False
+_big_gemm_last = None  # (event, stream) of the last large library GEMM
+
+
+def _big_gemm_enter():
+    if SERIALIZE_BIG_GEMMS and _big_gemm_last is not None:
+        cur = torch.cuda.current_stream()
+        if _big_gemm_last[1] != cur:
+            cur.wait_event(_big_gemm_last[0])
+
+
+def _big_gemm_exit():
+    global _big_gemm_last
+    if SERIALIZE_BIG_GEMMS:
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        _big_gemm_last = (ev, cur)
+
+
 def _bf16_weights(lin):
     key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.device)
     cache = getattr(lin, "_bf16_cache", None)
@@ -123,7 +150,12 @@ def linear(x, lin, relu=False, gelu=False):
         if relu and cache[2] is not None:
             x2 = xb.reshape(-1, xb.shape[-1])
             return torch._addmm_activation(cache[2], x2, cache[1].t()).reshape(*xb.shape[:-1], cache[1].shape[0])
+        big = rows >= HIP_GEMM_MIN_ROWS
+        if big:
+            _big_gemm_enter()
         y = F.linear(xb, cache[1], cache[2])
+        if big:
+            _big_gemm_exit()
         return F.relu(y) if relu else (F.gelu(y) if gelu else y)
 
 
