@@ -69,7 +69,7 @@ class _Block(nn.Module):
         return x, ops.scale_residual_layernorm_(x, y, self.ls2.gamma, next_norm)
 
     def forward(self, x):
-        if torch.is_autocast_enabled() and x.dtype == torch.float32 and x.is_cuda:
+        if torch.is_autocast_enabled() and x.dtype == torch.float32 and x.is_cuda and not ops.is_differentiable():
             # fused glue (csrc/fused.hip): LayerNorm -> bf16 in one pass, LayerScale residual in one pass;
             # the residual stream itself stays fp32 exactly as under the reference's autocast
             # (x is updated IN PLACE: ViT.forward owns the residual stream and rebinds it every block)
@@ -120,7 +120,8 @@ class ViT(nn.Module):
         n = self.depth // 4
         taps = {self.depth - 1, self.depth - n - 1, self.depth - 2 * n - 1, self.depth - 3 * n - 1}
         outs = []
-        if x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32 and x.shape[-1] % 4 == 0:
+        if x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 \
+                and not ops.is_differentiable():
             # fused glue: each block's LayerScale residual also produces the next LayerNorm (csrc/fused.hip)
             x = x.contiguous()
             n1 = ops.add_layernorm(x, None, self.blocks[0].norm1, torch.bfloat16)
@@ -137,8 +138,8 @@ class ViT(nn.Module):
         for i, blk in enumerate(self.blocks):
             x = blk(x)
             if i in taps:
-                outs.append(ops.add_layernorm(x, None, self.norm) if x.is_cuda and torch.is_autocast_enabled()
-                            else self.norm(x))
+                outs.append(ops.add_layernorm(x, None, self.norm)
+                            if x.is_cuda and torch.is_autocast_enabled() and not ops.is_differentiable() else self.norm(x))
         return outs
 
 
@@ -213,7 +214,7 @@ class ViT_AE(nn.Module):
         return z.reshape(B, -1, 4, 4, self.out_dim), (H, W), 0
 
     def pixel_features(self, x, choose):
-        if x.is_cuda and self.out_dim == 256:
+        if x.is_cuda and self.out_dim == 256 and not ops.is_differentiable():
             z, (H, W), off = self.upprojected_tokens(x)
             return ops.bilinear_sample_native(z, choose, H, W, tok_offset=off)
         low, (H, W) = self.lowres_map(x)
@@ -281,7 +282,7 @@ class _AttentionOutput(nn.Module):
 
     def forward(self, x):
         y = ops.linear(ops.linear(x, self.expand, relu=True), self.squeeze)
-        if x.is_cuda:
+        if x.is_cuda and not ops.is_differentiable():
             return ops.add_layernorm(x, y, self.norm)  # one pass (csrc/fused.hip); bf16 out under autocast
         return self.norm(x + y)
 
@@ -300,7 +301,7 @@ class TransformerLayer(nn.Module):
         if mem is None:  # self-attention
             mem = x
         h = ops.token_attention(x, mem, a.attention, self.heads, embed)
-        if x.is_cuda:
+        if x.is_cuda and not ops.is_differentiable():
             if ops.USE_FUSED_TAIL and torch.is_autocast_enabled() and x.shape[-1] == 256:
                 return ops.transformer_tail(h, x, self)
             x = ops.add_layernorm(ops.linear(h, a.linear), x, a.norm)
@@ -380,7 +381,7 @@ class LinearTransformerLayer(nn.Module):
     def forward(self, x, mem):
         a = self.attention
         h = ops.focused_linear_attention(x, mem, a.attention, self.heads, self.focusing_factor)
-        if x.is_cuda:
+        if x.is_cuda and not ops.is_differentiable():
             if ops.USE_FUSED_TAIL and torch.is_autocast_enabled() and x.shape[-1] == 256:
                 return ops.transformer_tail(h, x, self)
             x = ops.add_layernorm(ops.linear(h, a.linear), x, a.norm)
@@ -457,6 +458,13 @@ class _SharedMLP(nn.Module):
     def layers(self):
         return [getattr(self, f"layer{i}") for i in range(self.n)]
 
+    def forward(self, x):
+        """(B,C,N,S) through the unfolded layers: 1x1 Conv2d -> BatchNorm2d (train or eval statistics per module mode) ->
+        ReLU.  The inference path never calls this (csrc/pe.hip runs the BN-folded chain); training does."""
+        for l in self.layers():
+            x = F.relu(l.normlayer.bn(l.conv(x)))
+        return x
+
 
 class _Conv1d(nn.Module):
     def __init__(self, cin, cout):
@@ -478,6 +486,14 @@ class PositionalEncoding(nn.Module):
         """Both scales' grouped features, max-pooled: (B,N,3) -> (B,N,256) fp32 = [scale 1 | scale 2].  Only the two
         fused HIP launches (no library GEMM, no inter-workgroup waits), so it may run on a side stream."""
         pts = pts.float()
+        if ops.is_differentiable():
+            # training: grouped features from the fused grouping kernel (constants w.r.t. the weights, as in the
+            # reference, whose `_ext` outputs carry no gradient), then the REAL Conv2d / BatchNorm2d modules -- batch
+            # statistics and running-stat updates in train mode (pytorch_utils.py:25-132) -- recorded by autograd
+            with torch.autocast("cuda", enabled=False):
+                f1 = self.mlp1(ops.query_lrf_group(pts, self.r1, self.ns1)).max(dim=3)[0]
+                f2 = self.mlp2(ops.query_lrf_group(pts, self.r2, self.ns2)).max(dim=3)[0]
+            return torch.cat([f1, f2], dim=1).transpose(1, 2)
         if pts.is_cuda and torch.is_autocast_enabled() and self.r2 >= self.r1 and self.ns1 % 32 == 0 and self.ns2 % 32 == 0:
             # the wide scale first: its neighbour lists are the candidates of the narrow scale (csrc/pe.hip)
             f2, cand = ops.pe_group_mlp_max(pts, self.r2, self.ns2, self.mlp2, want_cand=True)

@@ -1,13 +1,17 @@
 """UNOPose for MI355X: same constructor / ``forward(end_points)`` / state_dict contract as
 core/unopose/model/oneref_grf_predator_pose_estimation_model.py:11-76 (M), with
 C = oneref_predator_coarse_point_matching.py, Fi = oneref_predator_fine_point_matching.py,
-F = oneref_feature_extraction.py, U = utils/model_utils.py.  Inference only (eval branch)."""
+F = oneref_feature_extraction.py, U = utils/model_utils.py.  `.eval()`: the fused inference path.  `.train()`: the
+reference's training branches (per-block overlap / saliency / correspondence losses, C:78-107, Fi:101-117) on
+autograd-recorded composites (ops.differentiable), the frozen backbone still on the fused kernels."""
 import os
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import ops
+from ..losses import aug_pose_noise, overlap_losses
 from .config import to_cfg
 from .modules import (GeometricStructureEmbedding, GeometricTransformer, PositionalEncoding,
                       SparseToDenseTransformer, ViTEncoderOneRef, _adjacent)
@@ -24,6 +28,20 @@ def _scores(scores, n1):
     return torch.clamp(torch.sigmoid(torch.cat((s1, s2), dim=1).squeeze(-1).float()), 0, 1)
 
 
+def _block_outputs(out_proj, score_head, f1, f2, n1, temp):
+    """What the training branch keeps per transformer block (C:62-76, Fi:85-99): the similarity of the projected
+    features, the overlap scores and the saliency = overlap scores propagated through the row / column softmax."""
+    scores = score_head(torch.cat((f1, f2), dim=1))
+    atten = ops.feature_similarity(out_proj(f1), out_proj(f2), temp)
+    s1, s2 = scores[:, 1:(n1 + 1)], scores[:, (n1 + 2):]
+    inner = atten[:, 1:, 1:]
+    m1 = torch.matmul(F.softmax(inner, dim=2), s2)
+    m2 = torch.matmul(F.softmax(inner.transpose(1, 2), dim=2), s1)
+    score = torch.clamp(torch.sigmoid(torch.cat((s1, s2), dim=1).squeeze(-1)), min=0, max=1)
+    saliency = torch.clamp(torch.sigmoid(torch.cat((m1, m2), dim=1).squeeze(-1)), min=0, max=1)
+    return atten, score, saliency
+
+
 class CoarsePointMatchingOneRef(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -36,9 +54,32 @@ class CoarsePointMatchingOneRef(nn.Module):
         self.transformers = nn.ModuleList([GeometricTransformer(cfg.hidden_dim, 4) for _ in range(self.nblock)])
         self.taps = None  # assign a dict to receive (f1, f2, atten, score) of the next forward (tests)
 
+    def forward_train(self, p1, f1, geo1, p2, f2, geo2, radius, end_points):
+        """C:46-107, training branch: every block contributes (similarity, score, saliency) to the losses; the fine stage
+        is then started from the ground-truth pose perturbed by `aug_pose_noise` (or by end_points["aug_pose"] =
+        (R, t) when the caller injects the draw, as the parity tests do)."""
+        B, n1 = f1.shape[:2]
+        bg = self.bg_token.expand(B, -1, -1)
+        f1 = torch.cat([bg, self.in_proj(f1)], dim=1)
+        f2 = torch.cat([bg, self.in_proj(f2)], dim=1)
+        attens, scores, sals = [], [], []
+        for blk, head in zip(self.transformers, self.score_heads):
+            f1, f2 = blk(f1, geo1, f2, geo2)
+            a, sc, sa = _block_outputs(self.out_proj, head, f1, f2, n1, self.cfg.temp)
+            attens.append(a)
+            scores.append(sc)
+            sals.append(sa)
+        gt_R = end_points["rotation_label"]
+        gt_t = end_points["translation_label"] / (radius.reshape(-1, 1) + 1e-6)
+        init_R, init_t = end_points["aug_pose"] if "aug_pose" in end_points else aug_pose_noise(gt_R, gt_t)
+        overlap_losses(end_points, attens, scores, sals, p1, p2, gt_R, gt_t, self.cfg.loss_predator_thres,
+                       self.cfg.loss_dis_thres, "coarse_hard")
+        end_points["init_R"], end_points["init_t"] = init_R, init_t
+        return end_points
+
     def forward(self, p1, f1, geo1, p2, f2, geo2, radius, end_points):
         if self.training:
-            raise NotImplementedError("training path is out of scope (SURVEY.md 8(f-4))")
+            return self.forward_train(p1, f1, geo1, p2, f2, geo2, radius, end_points)
         B, n1 = f1.shape[:2]
         f1 = ops.linear(f1, self.in_proj)
         f2 = ops.linear(f2, self.in_proj)
@@ -80,9 +121,30 @@ class FinePointMatchingOneRef(nn.Module):
             [SparseToDenseTransformer(d, 4, cfg.focusing_factor) for _ in range(self.nblock)])
         self.taps = None  # assign a dict to receive (f1, f2, atten, score) of the next forward (tests)
 
+    def forward_train(self, p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points):
+        """Fi:58-117, training branch.  The positional encoding is evaluated per cloud, query first (its BatchNorm layers
+        use -- and update -- batch statistics per call, exactly as the reference's two PE calls do)."""
+        B, n1 = p1.shape[:2]
+        p1_ = (p1 - end_points["init_t"].unsqueeze(1)) @ end_points["init_R"] if "init_R" in end_points else p1
+        bg = self.bg_token.expand(B, -1, -1)
+        f1 = torch.cat([bg, self.in_proj(f1) + self.PE(p1_)], dim=1)
+        f2 = torch.cat([bg, self.in_proj(f2) + self.PE(p2)], dim=1)
+        attens, scores, sals = [], [], []
+        for blk, head in zip(self.transformers, self.score_heads):
+            f1, f2 = blk(f1, geo1, fps_idx1, f2, geo2, fps_idx2)
+            a, sc, sa = _block_outputs(self.out_proj, head, f1, f2, n1, self.cfg.temp)
+            attens.append(a)
+            scores.append(sc)
+            sals.append(sa)
+        gt_R = end_points["rotation_label"]
+        gt_t = end_points["translation_label"] / (radius.reshape(-1, 1) + 1e-6)
+        overlap_losses(end_points, attens, scores, sals, p1, p2, gt_R, gt_t, self.cfg.loss_predator_thres,
+                       self.cfg.loss_dis_thres, "fine")
+        return end_points
+
     def forward(self, p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points, pe2_groups=None):
         if self.training:
-            raise NotImplementedError("training path is out of scope (SURVEY.md 8(f-4))")
+            return self.forward_train(p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points)
         B, n1 = p1.shape[:2]
         if "init_R" in end_points and "init_t" in end_points:
             p1_ = (p1 - end_points["init_t"].unsqueeze(1)) @ end_points["init_R"]
@@ -244,9 +306,52 @@ class UNOPose(nn.Module):
         idx = ops.furthest_point_sample(pts, npoint)
         return ops.gather_rows(pts.float(), idx), ops.gather_rows(pts_lrf, idx), ops.gather_rows(feats, idx), idx
 
+    # ---- training (M:25-76 with self.training; F:245-298) ----------------------------------------------------------
+    def _pixel_features_train(self, rgb, choose):
+        """(B,3,S,S), (B,Np) -> (B,Np,256) with the gradient path of the reference: the backbone's taps (under no_grad
+        and on the fused kernels when it is frozen, F:194-198) -> trainable up-projection -> bilinear resize evaluated
+        at the chosen pixels (= F.interpolate + gather, recorded by autograd)."""
+        net = self.feature_extraction.rgb_net
+        frozen = not any(p.requires_grad for p in net.vit.parameters())
+        if frozen:
+            with torch.no_grad(), ops.differentiable(False):
+                taps = net.vit(rgb)
+        else:
+            taps = net.vit(rgb)
+        B, _, H, W = rgb.shape
+        side = H // 14
+        z = torch.cat([o[:, 5:, :] for o in taps], dim=2).float()
+        z = net.output_upscaling(z).reshape(B, side, side, 4, 4, net.out_dim)
+        low = z.permute(0, 1, 3, 2, 4, 5).reshape(B, 4 * side, 4 * side, net.out_dim)
+        return ops.bilinear_sample_pixels(low, choose, H, W)
+
+    def forward_train(self, end_points):
+        tem_pts = end_points["tem1_pts"]
+        radius = torch.norm(tem_pts - tem_pts.mean(1, keepdim=True), dim=2).max(1)[0]
+        scale = radius.reshape(-1, 1, 1) + 1e-6
+        dense_pm, tem_n = end_points["pts"] / scale, tem_pts / scale
+        idx_o = ops.furthest_point_sample(tem_n, self.fine_npoint)
+        dense_po = ops.gather_rows(tem_n, idx_o)
+        dense_fm = self._pixel_features_train(end_points["rgb"], end_points["rgb_choose"])
+        # features of the FPS-selected reference pixels only (the reference gathers all 5000 and then selects: same values,
+        # and only the selected ones receive gradient there too)
+        dense_fo = self._pixel_features_train(end_points["tem1_rgb"], torch.gather(end_points["tem1_choose"], 1, idx_o.long()))
+        pm_lrf = ops.lrf_global(end_points["pts"], self.use_ref_rad)
+        po_lrf = ops.lrf_global(tem_pts, self.use_ref_rad)  # NB App-E.1: frames of the FULL cloud, gathered with subset indices
+        B = dense_pm.size(0)
+        bg_point = torch.ones(B, 1, 3, device=dense_pm.device)
+        sparse_pm, sparse_pm_lrf, sparse_fm, fps_idx_m = self._sample_wlrf(dense_pm, pm_lrf, dense_fm, self.coarse_npoint)
+        sparse_po, sparse_po_lrf, sparse_fo, fps_idx_o = self._sample_wlrf(dense_po, po_lrf, dense_fo, self.coarse_npoint)
+        geo_m = self.geo_embedding(torch.cat([bg_point, sparse_pm_lrf], dim=1))
+        geo_o = self.geo_embedding(torch.cat([bg_point, sparse_po_lrf], dim=1))
+        end_points = self.coarse_point_matching(sparse_pm, sparse_fm, geo_m, sparse_po, sparse_fo, geo_o, radius, end_points)
+        return self.fine_point_matching(dense_pm, dense_fm, geo_m, fps_idx_m, dense_po, dense_fo, geo_o, fps_idx_o, radius,
+                                        end_points)
+
     def forward(self, end_points):
         if self.training:
-            raise NotImplementedError("training path is out of scope (SURVEY.md 8(f-4))")
+            with ops.differentiable():
+                return self.forward_train(end_points)
         dense_pm, dense_fm, dense_po, dense_fo, radius, pre = self._features(end_points)
         if pre is not None:
             return self._forward_from(pre, end_points, dense_pm, dense_fm, dense_po, dense_fo, radius)

@@ -14,6 +14,33 @@ def _c(x):
     return x if x.is_contiguous() else x.contiguous()
 
 
+# ---- differentiable mode (training) -------------------------------------------------------------
+# The fused HIP operators are inference kernels (no autograd).  Inside `with ops.differentiable():` every dispatcher
+# below takes its op-by-op torch composite instead -- the same formulas on the GPU, recorded by autograd -- while
+# index-producing kernels (FPS, ball query, LRF frames), whose outputs carry no gradient in the reference either,
+# keep running on HIP.  UNOPose.forward enters this mode when `model.training`.
+_DIFF = False
+
+
+class differentiable:
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        global _DIFF
+        self.prev, _DIFF = _DIFF, bool(self.on)
+        return self
+
+    def __exit__(self, *a):
+        global _DIFF
+        _DIFF = self.prev
+        return False
+
+
+def is_differentiable():
+    return _DIFF
+
+
 def lrf_global(pts, use_ref_rad=False):
     """get_batch_lrf (oneref_grf_predator_pose_estimation_model.py:78-93). (B,N,3)->(B,N,3)."""
     pts = _c(pts.float())
@@ -134,7 +161,7 @@ def linear(x, lin, relu=False, gelu=False):
     the up-projection) run on the hand-written GEMM of csrc/gemm.hip with the bias -- and, for `gelu=True`, timm
     Mlp's exact-erf GELU -- fused into its epilogue; the rest goes to hipBLASLt, where `relu=True` rides in the
     library epilogue (RELU_BIAS through torch._addmm_activation)."""
-    if not (torch.is_autocast_enabled() and x.is_cuda):
+    if _DIFF or not (torch.is_autocast_enabled() and x.is_cuda):
         y = lin(x)
         return F.relu(y) if relu else (F.gelu(y) if gelu else y)
     cache = _bf16_weights(lin)
@@ -169,6 +196,8 @@ def gather_rows(feats, idx):
 def vit_attention(qkv, heads):
     """timm Attention core: qkv (B,T,3C) -> (B,T,C).  bf16 (autocast) inputs run the flash-style HIP
     kernel (csrc/vit_attn.hip, head dim 64); fp32 inputs the op-by-op composite."""
+    if _DIFF:
+        return vit_attention_torch(qkv, heads)
     if qkv.dtype == torch.bfloat16 and qkv.shape[-1] == 3 * heads * 64:
         B, T, C3 = qkv.shape
         qkv = _c(qkv)
@@ -277,7 +306,7 @@ def geo_embedding(points, m, out_dtype=None):
     (sinusoid generation -> MFMA -> max-over-k epilogue; csrc/embed.hip).  Under autocast(bf16) the
     result is bf16 with plain bf16 operands (what proj_d / proj_a produce under autocast in the
     reference); otherwise fp32 with hi/lo-split operands (fp32-class accuracy)."""
-    if m.proj_d.weight.shape != (256, 256) or m.angle_k != 3 or points.shape[1] < 4:
+    if _DIFF or m.proj_d.weight.shape != (256, 256) or m.angle_k != 3 or points.shape[1] < 4:
         return geo_embedding_torch(points, m)  # other widths / k: op-by-op GPU composite
     points = _c(points.float())
     check_f32(points, "points")
@@ -342,7 +371,7 @@ def token_attention(x, mem, att, heads, embed=None):
     Under autocast(bf16) the whole core (q k^T, folded RPE term, softmax, P v) is ONE HIP kernel on the
     bf16 matrix cores (csrc/attn.hip) that streams E once; in fp32 the op-by-op composite below runs."""
     global _KEY_PAD
-    if x.is_cuda and heads == 4 and x.shape[-1] == 256:
+    if not _DIFF and x.is_cuda and heads == 4 and x.shape[-1] == 256:
         if _KEY_PAD is None:
             from ._lib import lib
             _KEY_PAD = lib().unopose_token_attention_key_pad()
@@ -473,7 +502,7 @@ def focused_linear_attention(xq, xkv, att, heads, focusing):
     """LinearAttention.forward (transformer.py:533-568).  With 4 heads x 64 the focusing + per-head
     contraction + z scaling run in ONE HIP kernel per side (csrc/linattn.hip): bf16 MFMAs under autocast,
     hi/lo-split (fp32-class) MFMAs on fp32 data; other shapes take the op-by-op composite."""
-    if heads == 4 and xq.shape[-1] == 256 and xq.is_cuda and float(focusing) == 3.0:
+    if not _DIFF and heads == 4 and xq.shape[-1] == 256 and xq.is_cuda and float(focusing) == 3.0:
         if torch.is_autocast_enabled():
             return _focused_linear_attention_hip(xq, xkv, att, int(focusing))
         if xq.dtype == torch.float32 and xkv.dtype == torch.float32:
@@ -642,6 +671,8 @@ def feature_similarity(f1, f2, temp):
     Under autocast on the GPU the bf16 GEMM writes its fp32 accumulators straight out (`out_dtype`) with
     1/temp folded into the (small) left operand: one 4-byte write of the (B,N1,N2) matrix instead of a
     bf16 write, a division pass and the fp32 cast the pose heads ask for (1.6 GB per step at B=32)."""
+    if _DIFF:  # the reference's expression, dtype and all (model_utils.py:260-282)
+        return F.normalize(f1, p=2, dim=2) @ F.normalize(f2, p=2, dim=2).transpose(1, 2) / temp
     a, b = F.normalize(f1.float(), p=2, dim=2), F.normalize(f2.float(), p=2, dim=2)
     if f1.is_cuda and torch.is_autocast_enabled():
         with torch.autocast("cuda", enabled=False):
