@@ -30,6 +30,13 @@ def overlap_losses(end_points, atten_list, score_list, saliency_list, pts1, pts2
     """Per-block overlap-score, saliency and correspondence (InfoNCE) losses plus the monitoring scalars of the last
     block (loss_utils.py:132-203).  pts1 = query (tgt), pts2 = reference (src); (gt_R, gt_t) maps reference to query.
     Adds `<prefix>_score_loss<i>`, `_saliency_loss<i>`, `_atten_loss<i>`, `_acc`, `_fg_num`, `_dis`, each (B,)."""
+    with torch.autocast(pts1.device.type, enabled=False):  # fp32 island: BCE on probabilities is not autocast-safe
+        return _overlap_losses(end_points, [a.float() for a in atten_list], [s.float() for s in score_list],
+                               [s.float() for s in saliency_list], pts1.float(), pts2.float(), gt_R.float(), gt_t.float(),
+                               predator_thres, dis_thres, prefix)
+
+
+def _overlap_losses(end_points, atten_list, score_list, saliency_list, pts1, pts2, gt_R, gt_t, predator_thres, dis_thres, prefix):
     n1 = pts1.shape[1]
     in_ref = (pts1 - gt_t.unsqueeze(1)) @ gt_R  # query points expressed in the reference frame
     dist = torch.sqrt(_pairwise_sq_dist(in_ref, pts2))  # (B, n1, n2)
