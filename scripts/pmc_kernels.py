@@ -36,5 +36,11 @@ for _ in range(3):
 qkv = torch.randn(2 * B, 1374, 2304, device=dev).bfloat16()
 for _ in range(3):
     ops.vit_attention(qkv, 12)
+# the fused fc1 + GELU GEMM at the ViT size (M = 2B x 1374 rows, 768 -> 3072)
+a = torch.randn(2 * B * 1374, 768, device=dev).bfloat16()
+w = (torch.randn(3072, 768, device=dev) / 768 ** 0.5).bfloat16()
+bias = torch.randn(3072, device=dev)
+for _ in range(3):
+    ops.linear_bf16_hip(a, w, bias, True)
 torch.cuda.synchronize()
 print("done")

@@ -6,7 +6,7 @@ import re
 import sys
 
 SHORT = ["token_attn_kernel<true", "vit_attn_kernel", "group_points_lds_kernel", "pe_group_mlp_max_bf16x3_kernel",
-         "ball_query_kernel", "geo_embed_kernel", "geo_knn_kernel"]
+         "ball_query_kernel", "geo_embed_kernel", "geo_knn_kernel", "gemm_bf16_kernel"]
 
 
 def load(path):

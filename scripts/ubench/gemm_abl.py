@@ -3,12 +3,13 @@ Build here (CPU): python scripts/ubench/gemm_abl.py build ; run on the GPU box: 
 import ctypes, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-NAMES = {0: "full", 1: "no LDS-DMA in loop", 2: "no MFMA", 3: "no fragment reads", 10: "full + K rotation", 12: "no MFMA + K rotation"}
+NAMES = {10: "full (K rotation)", 12: "no MFMA", 410: "full, 4 x 8 patches", 412: "no MFMA, 4 x 8 patches", 810: "full, 8 x 4 patches",
+         812: "no MFMA, 8 x 4 patches"}
 def so(v): return os.path.join(HERE, f"_gemm_abl{v}.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     for v in NAMES:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-honor-nans",
-                               f"-DGEMM_ABL={v % 10}", f"-DGEMM_ROT={v // 10}", os.path.join(ROOT, "unopose_amd/csrc/gemm.hip"), os.path.join(ROOT, "unopose_amd/csrc/abi.hip"), "-o", so(v)])
+                               f"-DGEMM_ABL={v % 10}", f"-DGEMM_ROT={(v // 10) % 10}", f"-DGEMM_GM={max(1, v // 100)}", os.path.join(ROOT, "unopose_amd/csrc/gemm.hip"), os.path.join(ROOT, "unopose_amd/csrc/abi.hip"), "-o", so(v)])
     sys.exit(0)
 import torch
 torch.set_grad_enabled(False)
@@ -21,7 +22,7 @@ def timeit(f, n=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
 libs = {v: ctypes.CDLL(so(v)) for v in NAMES}
-for K, N in ((768, 2304), (3072, 4096)):
+for K, N in ((768, 2304), (3072, 768), (3072, 4096)):
     a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
     b = torch.randn(N, device="cuda"); out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -33,6 +33,9 @@ typedef unsigned short u16;
 #ifndef GEMM_ROT
 #define GEMM_ROT 1  // K-tile rotation (measured +7 % at K = 768, neutral at K = 3072; scripts/ubench/gemm_abl.py)
 #endif
+#ifndef GEMM_GM
+#define GEMM_GM 1
+#endif
 #define GEMM_BM 256
 #define GEMM_BN 256
 #define GEMM_BK 64
@@ -68,7 +71,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   __shared__ __attribute__((aligned(1024))) char smem[2 * GEMM_BUFBYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = xcd_swizzle(blockIdx.x, tiles);
+  // tile order inside an XCD's range: groups of GEMM_GM row panels, column tiles fastest across the group, so the ~32
+  // tiles resident on an XCD at a time form a (GM x 32/GM) patch and share GM A panels + 32/GM W panels in its L2
+#if GEMM_GM > 1
+  const int tiles_m = tiles / tiles_n, per_group = GEMM_GM * tiles_n;
+  const int mg = t / per_group, rr = t - mg * per_group;
+  const int gm = min(GEMM_GM, tiles_m - mg * GEMM_GM);
+  const int tn = rr / gm, tm = mg * GEMM_GM + (rr - tn * gm);
+#else
   const int tm = t / tiles_n, tn = t - tm * tiles_n;
+#endif
   const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, hi = lane >> 5;
