@@ -3,13 +3,14 @@ Build here (CPU): python scripts/ubench/gemm_abl.py build ; run on the GPU box: 
 import ctypes, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-NAMES = {10: "full (K rotation)", 12: "no MFMA", 410: "full, 4 x 8 patches", 412: "no MFMA, 4 x 8 patches", 810: "full, 8 x 4 patches",
-         812: "no MFMA, 8 x 4 patches"}
+NAMES = {10: "full (K rotation)", 12: "no MFMA", 13: "no fragment reads", 15: "DMA only, vmcnt(0) per tile... see 16",
+         16: "placeholder"}
+NAMES = {410: "full", 416: "DMA only", 2410: "full, skew 2", 2416: "DMA only, skew 2", 4410: "full, skew 4", 4416: "DMA only, skew 4", 8410: "full, skew 8", 8416: "DMA only, skew 8"}
 def so(v): return os.path.join(HERE, f"_gemm_abl{v}.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     for v in NAMES:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-honor-nans",
-                               f"-DGEMM_ABL={v % 10}", f"-DGEMM_ROT={(v // 10) % 10}", f"-DGEMM_GM={max(1, v // 100)}", os.path.join(ROOT, "unopose_amd/csrc/gemm.hip"), os.path.join(ROOT, "unopose_amd/csrc/abi.hip"), "-o", so(v)])
+                               f"-DGEMM_ABL={v % 10}", f"-DGEMM_ROT={(v // 10) % 10}", f"-DGEMM_GM={max(1, (v // 100) % 10)}", f"-DGEMM_SKEW={v // 1000}", os.path.join(ROOT, "unopose_amd/csrc/gemm.hip"), os.path.join(ROOT, "unopose_amd/csrc/abi.hip"), "-o", so(v)])
     sys.exit(0)
 import torch
 torch.set_grad_enabled(False)

@@ -34,7 +34,7 @@ typedef unsigned short u16;
 #define GEMM_ROT 1  // K-tile rotation (measured +7 % at K = 768, neutral at K = 3072; scripts/ubench/gemm_abl.py)
 #endif
 #ifndef GEMM_GM
-#define GEMM_GM 1
+#define GEMM_GM 4  // row panels per patch of co-resident tiles
 #endif
 #define GEMM_BM 256
 #define GEMM_BN 256
@@ -57,58 +57,29 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return fmaf(fabsf(hx), erfz, hx);  // 0.5 x + 0.5 |x| erf(|x|/sqrt2) = 0.5 x (1 + sign(x) erf(.))
 }
 
-// XCD-aware, bijective tile order: workgroup b runs on XCD b % 8 (observed dispatch rule; a speed assumption only),
-// each XCD walks one contiguous range of tiles so neighbouring tiles (same A row panel) share an L2.
-__device__ __forceinline__ int xcd_swizzle(int bid, int n) {
-  const int q = n >> 3, r = n & 7, xcd = bid & 7, k = bid >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
 template <int EPI>  // 0: bias; 1: bias + exact GELU
 __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict__ A, const u16 *__restrict__ W,
                                                            const float *__restrict__ bias, u16 *__restrict__ C, int M,
                                                            int N, int K, int tiles_n, int tiles) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * GEMM_BUFBYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t = xcd_swizzle(blockIdx.x, tiles);
-  // tile order inside an XCD's range: groups of GEMM_GM row panels, column tiles fastest across the group, so the ~32
-  // tiles resident on an XCD at a time form a (GM x 32/GM) patch and share GM A panels + 32/GM W panels in its L2
-#if GEMM_GM > 1
-  const int tiles_m = tiles / tiles_n, per_group = GEMM_GM * tiles_n;
-  const int mg = t / per_group, rr = t - mg * per_group;
-  const int gm = min(GEMM_GM, tiles_m - mg * GEMM_GM);
-  const int tn = rr / gm, tm = mg * GEMM_GM + (rr - tn * gm);
-#else
-  const int tm = t / tiles_n, tn = t - tm * tiles_n;
-#endif
-  const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, hi = lane >> 5;
-
-  // ---- LDS-DMA (buffer_load_dwordx4 ... lds): piece j = wave * 4 + i covers tile rows 8j .. 8j+7; per-lane byte offset
-  //      in the VGPR, K-tile offset in an SGPR; rows past M (ragged last tile) fall outside the descriptor -> zeros
-  uint32_t a_off[4], w_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    a_off[i] = (uint32_t)(((size_t)(m0 + row) * K + c * 8) * 2);
-    w_off[i] = (uint32_t)(((size_t)(n0 + row) * K + c * 8) * 2);
-  }
+  // ---- persistent, lock-stepped tile walk.  The grid is ONE workgroup per CU (gridDim.x <= 256, a multiple of 8;
+  // 128 KiB of LDS admits one per CU).  Workgroup b sits on XCD b % 8 (observed dispatch rule: a SPEED assumption
+  // only) and is slot b / 8 of that XCD; XCD x owns one contiguous range of the tile sequence and its slots take
+  // tiles slot, slot + nslots, ... of it.  All workgroups start together and every tile costs the same, so the ~32
+  // tiles an XCD has in flight are 32 CONSECUTIVE tiles walking K in lock step: a (GEMM_GM x 32/GEMM_GM) patch of the
+  // output that shares GEMM_GM A panels and 32/GEMM_GM W panels K-slice by K-slice in that XCD's L2.  (With one
+  // workgroup per tile in dispatch order the resident tiles drift apart in K and the L2 -> LDS stream runs at half
+  // the rate: scripts/ubench/gemm_abl.py)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int cq = tiles >> 3, cr = tiles & 7;
+  const int chunk_base = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, chunk_len = cq + (xcd < cr ? 1 : 0);
+  const int tiles_m = tiles / tiles_n, per_group = GEMM_GM * tiles_n;
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, (int)((size_t)M * K * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, (int)((size_t)N * K * 2), 0x00020000);
-  // K-tile rotation: tile t walks K starting at a tile-dependent K-tile, so concurrently running tiles touch
-  // different 128-byte columns of their row panels at any instant (spreads the L2 / fabric channels)
   const int nk_ = K / GEMM_BK;
-  const int rot = GEMM_ROT ? (tm * 5 + tn * 3) % nk_ : 0;
-  auto stage1 = [&](int buf, int kt, int i) {  // pieces i of A and W of K-tile kt (i = 0..3)
-    kt += rot;
-    if (kt >= nk_) kt -= nk_;
-    char *la = smem + buf * GEMM_BUFBYTES + wave * 4096 + i * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void *)la, 16, a_off[i], kt * (GEMM_BK * 2), 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (__attribute__((address_space(3))) void *)(la + GEMM_OPBYTES), 16, w_off[i],
-                                             kt * (GEMM_BK * 2), 0, 0);
-  };
 
   // ---- fragment read addresses: tile row r = base + l31 (base a multiple of 32), chunk c = 2 ks + hi:
   //      byte = (r >> 3) * 1024 + (r & 7) * 128 + ((c ^ ((r >> 1) & 7)) << 4)
@@ -118,6 +89,41 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   for (int ks = 0; ks < 4; ++ks) fr_off[ks] = (uint32_t)((l31 >> 3) * 1024 + (l31 & 7) * 128 + ((((ks << 1) | hi) ^ fx) << 4));
   const uint32_t a_base = (uint32_t)(wm * 128 * 128);                // A rows wm*128 .. (+ mb * 32 rows = mb * 4096 B)
   const uint32_t w_base = (uint32_t)(GEMM_OPBYTES + wn * 64 * 128);  // W rows wn*64 ..  (+ nb * 4096 B)
+
+  for (int ti = slot, step = 0; ti < chunk_len; ti += nslots, ++step) {
+  const int t = chunk_base + ti;
+  // tile order: groups of GEMM_GM row panels, column tiles fastest across the group
+  const int mg = t / per_group, rr = t - mg * per_group;
+  const int gm = min(GEMM_GM, tiles_m - mg * GEMM_GM);
+  const int tn = rr / gm, tm = mg * GEMM_GM + (rr - tn * gm);
+  const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+  // ---- LDS-DMA (buffer_load_dwordx4 ... lds): piece j = wave * 4 + i covers tile rows 8j .. 8j+7; per-lane byte offset
+  //      in the VGPR, K-tile offset in an SGPR; rows past M (ragged last tile) fall outside the descriptor -> zeros
+  uint32_t a_off[4], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    a_off[i] = (uint32_t)(((size_t)((GEMM_ABL == 7 ? 0 : m0) + row) * K + c * 8) * 2);  // ABL 7: every tile streams tile (0, 0): all L2 hits
+    w_off[i] = (uint32_t)(((size_t)((GEMM_ABL == 7 ? 0 : n0) + row) * K + c * 8) * 2);
+  }
+  // K-tile rotation, uniform over the tiles an XCD runs together (they must stay on the same K-slice to share it) and
+  // different between XCDs / steps: the chip as a whole touches different 128-byte columns at any instant
+#ifndef GEMM_SKEW
+#define GEMM_SKEW 4
+#endif
+  // GEMM_SKEW: tiles sharing a panel start 0..SKEW-1 K-tiles apart, so a K-slice one of them has fetched is RESIDENT in L2
+  // when the others ask for it (requests for a line still in flight do not merge into one fetch)
+  const int skew = ((tm & 3) + tn) % (GEMM_SKEW > 1 ? GEMM_SKEW : 1);
+  const int rot = GEMM_ROT ? (xcd * 5 + step * 3 + skew) % nk_ : 0;
+  auto stage1 = [&](int buf, int kt, int i) {  // pieces i of A and W of K-tile kt (i = 0..3)
+    kt += rot;
+    if (kt >= nk_) kt -= nk_;
+    char *la = smem + buf * GEMM_BUFBYTES + wave * 4096 + i * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void *)la, 16, a_off[i], kt * (GEMM_BK * 2), 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (__attribute__((address_space(3))) void *)(la + GEMM_OPBYTES), 16, w_off[i],
+                                             kt * (GEMM_BK * 2), 0, 0);
+  };
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -144,20 +150,20 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   bf16x8 wf0[2], af0[4], wf1[2], af1[4];
   read_frags(smem, 0, wf0, af0);
 #define GEMM_STEP(MORE, KS, WC, AC, WN, AN)                                                             \
-    if ((KS) < 3 && GEMM_ABL != 3) read_frags(lb, (KS) + 1, WN, AN);                                   \
+    if ((KS) < 3 && GEMM_ABL != 3 && GEMM_ABL < 5) read_frags(lb, (KS) + 1, WN, AN);                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    if (GEMM_ABL == 2) { asm volatile("" ::"v"(WC[0]), "v"(WC[1]), "v"(AC[0]), "v"(AC[1]), "v"(AC[2]), "v"(AC[3])); } \
-    if (GEMM_ABL != 2) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[0], acc[0][0], 0, 0, 0);            \
-    if (GEMM_ABL != 2) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[1], acc[0][1], 0, 0, 0);            \
+    if (GEMM_ABL == 2 || GEMM_ABL >= 5) { asm volatile("" ::"v"(WC[0]), "v"(WC[1]), "v"(AC[0]), "v"(AC[1]), "v"(AC[2]), "v"(AC[3])); } \
+    if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[0], acc[0][0], 0, 0, 0);            \
+    if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[1], acc[0][1], 0, 0, 0);            \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     if (MORE && GEMM_ABL != 1) stage1(buf ^ 1, kt + 1, (KS));                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    if (GEMM_ABL != 2) acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[2], acc[0][2], 0, 0, 0);            \
-    if (GEMM_ABL != 2) acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[3], acc[0][3], 0, 0, 0);            \
-    if (GEMM_ABL != 2) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[0], acc[1][0], 0, 0, 0);            \
-    if (GEMM_ABL != 2) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[1], acc[1][1], 0, 0, 0);            \
-    if (GEMM_ABL != 2) acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[2], acc[1][2], 0, 0, 0);            \
-    if (GEMM_ABL != 2) acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[3], acc[1][3], 0, 0, 0);            \
+    if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[2], acc[0][2], 0, 0, 0);            \
+    if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[3], acc[0][3], 0, 0, 0);            \
+    if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[0], acc[1][0], 0, 0, 0);            \
+    if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[1], acc[1][1], 0, 0, 0);            \
+    if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[2], acc[1][2], 0, 0, 0);            \
+    if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[3], acc[1][3], 0, 0, 0);            \
     __builtin_amdgcn_sched_barrier(0);
   for (int kt = 0; kt < nk - 1; ++kt) {
     const int buf = kt & 1;
@@ -166,9 +172,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
     GEMM_STEP(true, 1, wf1, af1, wf0, af0)
     GEMM_STEP(true, 2, wf0, af0, wf1, af1)
     GEMM_STEP(true, 3, wf1, af1, wf0, af0)
+#if GEMM_ABL == 5  // probe: is the LDS-DMA stream latency- or bandwidth-bound?  One whole K-tile stays in flight across the barrier
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (GEMM_ABL != 3) read_frags(smem + (buf ^ 1) * GEMM_BUFBYTES, 0, wf0, af0);
+#endif
+    if (GEMM_ABL != 3 && GEMM_ABL < 5) read_frags(smem + (buf ^ 1) * GEMM_BUFBYTES, 0, wf0, af0);
   }
   {
     const int kt = nk - 1, buf = kt & 1;
@@ -216,6 +227,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
     const int m = m0 + wm * 128 + row;
     if (m < M) *reinterpret_cast<uint4 *>(Cb + ((size_t)m * N + n0 + wn * 64 + q * 8) * 2) = v;
   }
+  __syncthreads();  // every wave has read its staged outputs: the next tile's DMA may overwrite the buffers
+  }  // tile loop
 }
 
 }  // namespace unopose
@@ -235,11 +248,19 @@ int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C
   UNOPOSE_REQUIRE(epilogue == 0 || epilogue == 1, "linear_bf16: epilogue must be 0 (bias) or 1 (bias + GELU)");
   const int tiles_m = cdiv(M, GEMM_BM), tiles_n = N / GEMM_BN, tiles = tiles_m * tiles_n;
   hipStream_t s = (hipStream_t)stream;
+  static int n_cu = 0;  // one persistent workgroup per CU
+  if (n_cu == 0) {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8)
+      cu = 256;
+    n_cu = cu & ~7;
+  }
+  const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
   if (epilogue == 1)
-    hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(tiles), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
+    hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
                        K, tiles_n, tiles);
   else
-    hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(tiles), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
+    hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
                        K, tiles_n, tiles);
   return check_launch("linear_bf16");
 }
