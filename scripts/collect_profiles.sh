@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
 for img in 518 224; do
   rm -rf /tmp/ks$img
-  rocprofv3 --kernel-trace --stats -d /tmp/ks$img -o ks -- python3 $R/bench.py --img $img --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $R/gpurun_out/${TAG}_bench_under_rocprof_s$img.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats -d /tmp/ks$img -o ks -- python3 $R/bench.py --img $img --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-fp32 > $R/gpurun_out/${TAG}_bench_under_rocprof_s$img.json 2>/dev/null
   python3 $R/scripts/rocpd_stats.py $(find /tmp/ks$img -name "*.db" | head -1) 60 > $R/gpurun_out/${TAG}_kernel_stats_b32_s$img.csv
 done
 for c in FETCH_SIZE WRITE_SIZE; do

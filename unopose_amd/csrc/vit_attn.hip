@@ -58,7 +58,7 @@ constexpr int VA_BUF = VA_CHUNK * VA_LDK + 4 * VA_VSUB;  // u16 per chunk buffer
 // NW = wavefronts per workgroup: the K / V chunk staged in LDS is shared by NW * 32 QB queries, so a
 // larger workgroup amortises the staging (global loads, LDS writes, barriers: ~1/3 of the kernel at NW = 4
 // by ablation) over twice the MFMA work.
-template <int QB, int NBUF, int NW>
+template <int QB, int NBUF, int NW, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1 ? 3 : (QB == 4 ? 1 : 2), QB == 1 ? 4 : (QB == 4 ? 1 : 2)))) void vit_attn_kernel(const u16 *__restrict__ qkv, int T, int H, int BH, int nq,
                                                        float scale_log2e, u16 *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
@@ -233,10 +233,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
   auto chunk_compute = [&](int c0, const u16 *buf) {
     const int nk = min(VA_CHUNK, T - c0);  // valid keys of this chunk
     int kt = 0;
-    for (; kt + 32 <= nk; kt += 32) {  // full tiles: no masking, no branch between the MFMA groups
-      f32x16 s[QB];
-      qk_tile(buf, kt, s);
-      softmax_pv_tile(buf, kt, s);
+    if (PIPE) {
+      // software pipeline over the chunk's full tiles: the K Q^T MFMAs of tile t+1 are issued BEFORE the softmax of tile t
+      // (two named score sets, static indexing), so the matrix pipe works under the exp / max / sum VALU stream
+      if (nk >= 32) {
+        f32x16 sa[QB], sb[QB];
+        qk_tile(buf, 0, sa);
+        for (;;) {
+          const bool more_b = kt + 64 <= nk;
+          if (more_b) qk_tile(buf, kt + 32, sb);
+          softmax_pv_tile(buf, kt, sa);
+          kt += 32;
+          if (!more_b) break;
+          const bool more_a = kt + 64 <= nk;
+          if (more_a) qk_tile(buf, kt + 32, sa);
+          softmax_pv_tile(buf, kt, sb);
+          kt += 32;
+          if (!more_a) break;
+        }
+      }
+    } else {
+      for (; kt + 32 <= nk; kt += 32) {  // full tiles: no masking, no branch between the MFMA groups
+        f32x16 s[QB];
+        qk_tile(buf, kt, s);
+        softmax_pv_tile(buf, kt, s);
+      }
     }
     if (kt < nk) {  // the one partial tile of the sequence: keys >= T are masked out
       f32x16 s[QB];
@@ -310,12 +331,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
 
 using namespace unopose;
 
-template <int QB, int NBUF, int NW>
+template <int QB, int NBUF, int NW, bool PIPE = false>
 static int launch_vit_attn(const void *qkv, int B, int T, int H, void *out, hipStream_t stream) {
   static bool attr_set = false;  // > 64 KiB of LDS needs the opt-in (idempotent; benign if raced)
   const size_t lds = (size_t)NBUF * VA_BUF * sizeof(u16);
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vit_attn_kernel<QB, NBUF, NW>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vit_attn_kernel<QB, NBUF, NW, PIPE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       set_error("vit_attention: cannot reserve %zu bytes of LDS", lds);
       return UNOPOSE_ELAUNCH;
@@ -325,7 +346,7 @@ static int launch_vit_attn(const void *qkv, int B, int T, int H, void *out, hipS
   const int BH = B * H, nq = cdiv(T, 32 * NW * QB);
   const float scale_log2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
   const long blocks = (long)cdiv(BH, 8) * nq * 8;
-  hipLaunchKernelGGL((vit_attn_kernel<QB, NBUF, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, (const u16 *)qkv, T,
+  hipLaunchKernelGGL((vit_attn_kernel<QB, NBUF, NW, PIPE>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, (const u16 *)qkv, T,
                      H, BH, nq, scale_log2e, (u16 *)out);
   return check_launch("vit_attention");
 }
@@ -339,6 +360,8 @@ int unopose_vit_attention(const void *qkv, int B, int T, int H, void *out, unopo
   static const int nw_env = getenv("UNOPOSE_VIT_NW") ? atoi(getenv("UNOPOSE_VIT_NW")) : 8;
   static const int qb4_env = getenv("UNOPOSE_VIT_QB4") ? atoi(getenv("UNOPOSE_VIT_QB4")) : 0;  // experiment: 1 wave / SIMD, 128 queries / wave
   if (T >= 1024 && qb4_env == 1) return launch_vit_attn<4, 2, 4>(qkv, B, T, H, out, (hipStream_t)stream);
+  static const int pipe_env = getenv("UNOPOSE_VIT_PIPE") ? atoi(getenv("UNOPOSE_VIT_PIPE")) : 0;
+  if (T >= 1024 && pipe_env == 1) return launch_vit_attn<2, 2, 8, true>(qkv, B, T, H, out, (hipStream_t)stream);
   if (T >= 1024 && nw_env == 8) return launch_vit_attn<2, 2, 8>(qkv, B, T, H, out, (hipStream_t)stream);
   if (T >= 512) return launch_vit_attn<2, 2, 4>(qkv, B, T, H, out, (hipStream_t)stream);
   return launch_vit_attn<1, 1, 4>(qkv, B, T, H, out, (hipStream_t)stream);
