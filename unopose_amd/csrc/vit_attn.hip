@@ -58,6 +58,14 @@ constexpr int VA_BUF = VA_CHUNK * VA_LDK + 4 * VA_VSUB;  // u16 per chunk buffer
 // NW = wavefronts per workgroup: the K / V chunk staged in LDS is shared by NW * 32 QB queries, so a
 // larger workgroup amortises the staging (global loads, LDS writes, barriers: ~1/3 of the kernel at NW = 4
 // by ablation) over twice the MFMA work.
+// Ask the scheduler for an MFMA : VALU interleave in the pipelined tile (one matrix instruction, then up to VA_FILL
+// vector instructions, 16 times): the matrix pipe hides a few VALU issues per MFMA only if they sit in its shadow.
+#ifndef VA_FILL
+#define VA_FILL 6
+#endif
+#define VA_IL1 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, VA_FILL, 0);
+#define VA_INTERLEAVE VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1
+
 template <int QB, int NBUF, int NW, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1 ? 3 : (QB == 4 ? 1 : 2), QB == 1 ? 4 : (QB == 4 ? 1 : 2)))) void vit_attn_kernel(const u16 *__restrict__ qkv, int T, int H, int BH, int nq,
                                                        float scale_log2e, u16 *__restrict__ out) {
@@ -243,11 +251,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
           const bool more_b = kt + 64 <= nk;
           if (more_b) qk_tile(buf, kt + 32, sb);
           softmax_pv_tile(buf, kt, sa);
+          VA_INTERLEAVE
           kt += 32;
           if (!more_b) break;
           const bool more_a = kt + 64 <= nk;
           if (more_a) qk_tile(buf, kt + 32, sa);
           softmax_pv_tile(buf, kt, sb);
+          VA_INTERLEAVE
           kt += 32;
           if (!more_a) break;
         }
