@@ -11,8 +11,10 @@
  * so THIS FILE IS "PARITY UNPINNED" AGAINST A CUDA RUN.  What pins it instead:
  *   - furthest_point_sampling emulates the thread block literally (per-thread
  *     strided scan + shared-memory tree with the __update tie rule) and is
- *     cross-checked in tests/ against the closed-form rule
- *     "argmax d, ties -> min (k mod bs, k)" (SURVEY.md App-B.1);
+ *     cross-checked in tests/ against the closed-form rule the emulation revealed:
+ *     "argmax d, ties -> min (bitreverse_{log2 bs}(k mod bs), k)" -- the tree keeps the
+ *     lower SLOT at every level, which is bit-reversed order, not the plain
+ *     "lowest k mod bs" SURVEY.md App-B.1 assumed (tests/helpers.py::fps_closed_form);
  *   - the Python callers of these ops (QueryAndLRFGroup, sample_pts_feats, ...)
  *     are run from /root/reference with `_ext` bound to this library when the
  *     golden fixtures under tests/golden/ are generated.
