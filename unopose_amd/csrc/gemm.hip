@@ -35,6 +35,9 @@ typedef unsigned short u16;
 #endif
 #ifndef GEMM_GM
 #define GEMM_GM 4  // row panels per patch of co-resident tiles
+#ifndef GEMM_SKEW
+#define GEMM_SKEW 4  // tiles sharing a panel start 0..SKEW-1 K-tiles apart
+#endif
 #endif
 #define GEMM_BM 256
 #define GEMM_BN 256
@@ -62,6 +65,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
                                                            const float *__restrict__ bias, u16 *__restrict__ C, int M,
                                                            int N, int K, int tiles_n, int tiles) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * GEMM_BUFBYTES];
+  __shared__ __attribute__((aligned(16))) float bias_lds[GEMM_BN];  // this tile's bias slice (LDS reads: no vmcnt traffic in the epilogue)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -90,40 +94,70 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   const uint32_t a_base = (uint32_t)(wm * 128 * 128);                // A rows wm*128 .. (+ mb * 32 rows = mb * 4096 B)
   const uint32_t w_base = (uint32_t)(GEMM_OPBYTES + wn * 64 * 128);  // W rows wn*64 ..  (+ nb * 4096 B)
 
-  for (int ti = slot, step = 0; ti < chunk_len; ti += nslots, ++step) {
-  const int t = chunk_base + ti;
-  // tile order: groups of GEMM_GM row panels, column tiles fastest across the group
-  const int mg = t / per_group, rr = t - mg * per_group;
-  const int gm = min(GEMM_GM, tiles_m - mg * GEMM_GM);
-  const int tn = rr / gm, tm = mg * GEMM_GM + (rr - tn * gm);
-  const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
-  // ---- LDS-DMA (buffer_load_dwordx4 ... lds): piece j = wave * 4 + i covers tile rows 8j .. 8j+7; per-lane byte offset
-  //      in the VGPR, K-tile offset in an SGPR; rows past M (ragged last tile) fall outside the descriptor -> zeros
-  uint32_t a_off[4], w_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    a_off[i] = (uint32_t)(((size_t)((GEMM_ABL == 7 ? 0 : m0) + row) * K + c * 8) * 2);  // ABL 7: every tile streams tile (0, 0): all L2 hits
-    w_off[i] = (uint32_t)(((size_t)((GEMM_ABL == 7 ? 0 : n0) + row) * K + c * 8) * 2);
-  }
-  // K-tile rotation, uniform over the tiles an XCD runs together (they must stay on the same K-slice to share it) and
-  // different between XCDs / steps: the chip as a whole touches different 128-byte columns at any instant
-#ifndef GEMM_SKEW
-#define GEMM_SKEW 4
-#endif
-  // GEMM_SKEW: tiles sharing a panel start 0..SKEW-1 K-tiles apart, so a K-slice one of them has fetched is RESIDENT in L2
-  // when the others ask for it (requests for a line still in flight do not merge into one fetch)
-  const int skew = ((tm & 3) + tn) % (GEMM_SKEW > 1 ? GEMM_SKEW : 1);
-  const int rot = GEMM_ROT ? (xcd * 5 + step * 3 + skew) % nk_ : 0;
-  auto stage1 = [&](int buf, int kt, int i) {  // pieces i of A and W of K-tile kt (i = 0..3)
-    kt += rot;
-    if (kt >= nk_) kt -= nk_;
-    char *la = smem + buf * GEMM_BUFBYTES + wave * 4096 + i * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void *)la, 16, a_off[i], kt * (GEMM_BK * 2), 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (__attribute__((address_space(3))) void *)(la + GEMM_OPBYTES), 16, w_off[i],
-                                             kt * (GEMM_BK * 2), 0, 0);
+  // per-tile DMA parameters: tile origin, K rotation, per-lane source offsets of the wave's 4 + 4 pieces
+  struct TileP {
+    int m0, n0, rot;
+    uint32_t a_off[4], w_off[4];
   };
+  auto tile_params = [&](int ti, int step, TileP &p) {
+    const int t = chunk_base + ti;
+    // tile order: groups of GEMM_GM row panels, column tiles fastest across the group
+    const int mg = t / per_group, rr = t - mg * per_group;
+    const int gm = min(GEMM_GM, tiles_m - mg * GEMM_GM);
+    const int tn = rr / gm, tm = mg * GEMM_GM + (rr - tn * gm);
+    p.m0 = __builtin_amdgcn_readfirstlane(tm * GEMM_BM);
+    p.n0 = __builtin_amdgcn_readfirstlane(tn * GEMM_BN);
+    // LDS-DMA (buffer_load_dwordx4 ... lds): piece j = wave * 4 + i covers tile rows 8j .. 8j+7; per-lane byte offset in the
+    // VGPR, K-tile offset in an SGPR; rows past M (ragged last tile) fall outside the descriptor -> zeros
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 32 + i * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      p.a_off[i] = (uint32_t)(((size_t)((GEMM_ABL == 7 ? 0 : p.m0) + row) * K + c * 8) * 2);  // ABL 7: every tile streams tile (0, 0)
+      p.w_off[i] = (uint32_t)(((size_t)((GEMM_ABL == 7 ? 0 : p.n0) + row) * K + c * 8) * 2);
+    }
+    // K-tile rotation, uniform over the tiles an XCD runs together (they must stay on the same K-slice to share it) and
+    // different between XCDs / steps: the chip as a whole touches different 128-byte columns at any instant.
+    // GEMM_SKEW: tiles sharing a panel start 0..SKEW-1 K-tiles apart, so a K-slice one of them has fetched is RESIDENT in L2
+    // when the others ask for it (requests for a line still in flight do not merge into one fetch)
+    const int skew = ((tm & 3) + tn) % (GEMM_SKEW > 1 ? GEMM_SKEW : 1);
+    p.rot = __builtin_amdgcn_readfirstlane(GEMM_ROT ? (xcd * 5 + step * 3 + skew) % nk_ : 0);
+  };
+  // The DMA is issued from inline asm: the compiler does not see an LDS write and so keeps its own s_waitcnt vmcnt out of
+  // the LDS reads (it would otherwise drain the queue before every fragment read and every epilogue access); the waits
+  // on DMA data are the explicit vmcnt + barrier pairs below.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+  auto dma16 = [&](uint32_t lds_byte, uint32_t vo, __amdgpu_buffer_rsrc_t rs, int so) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_byte), "v"(vo), "s"(rs), "s"(so)
+                 : "memory");
+  };
+  auto stage_p = [&](const TileP &p, int buf, int kt, int i) {  // pieces i of A and W of K-tile kt (i = 0..3)
+    kt += p.rot;
+    if (kt >= nk_) kt -= nk_;
+    const uint32_t la = lds0 + (uint32_t)(buf * GEMM_BUFBYTES + wave * 4096 + i * 1024);
+    dma16(la, p.a_off[i], a_rs, kt * (GEMM_BK * 2));
+    dma16(la + GEMM_OPBYTES, p.w_off[i], w_rs, kt * (GEMM_BK * 2));
+  };
+  // Cross-tile prefetch: the first K-tile of the NEXT tile is put in flight (into buffer 0) right after the last K-tile
+  // of this one, so its DMA latency runs under the epilogue (bias / GELU / stores), which stages C through buffer 1 only.
+  // Needs the last K-tile in buffer 1, i.e. an even number of K-tiles (768 / 64, 3072 / 64).
+  const bool can_prefetch = (nk_ & 1) == 0;
+  TileP cur;
+  float4 cur_bv;  // bias[n0 + 4 lane ..] of the tile (every wave loads it: no branch, no early wait; wave 0 publishes it)
+  bool have = false;
+  for (int ti = slot, step = 0; ti < chunk_len; ti += nslots, ++step) {
+  if (!have) {
+    tile_params(ti, step, cur);
+    cur_bv = *reinterpret_cast<const float4 *>(bias + cur.n0 + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_p(cur, 0, 0, i);
+  }
+  const int m0 = __builtin_amdgcn_readfirstlane(cur.m0), n0 = __builtin_amdgcn_readfirstlane(cur.n0);
+  cur.rot = __builtin_amdgcn_readfirstlane(cur.rot);
+  auto stage1 = [&](int buf, int kt, int i) { stage_p(cur, buf, kt, i); };
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -140,9 +174,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) af[mb] = *reinterpret_cast<const bf16x8 *>(lb + a_base + mb * 4096 + fr_off[ks]);
   };
-#pragma unroll
-  for (int i = 0; i < 4; ++i) stage1(0, 0, i);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K-tile 0 (staged above or prefetched under the previous epilogue)
+  if (wave == 0) *reinterpret_cast<float4 *>(bias_lds + lane * 4) = cur_bv;  // read after the K loop's barriers
   __syncthreads();
   // Software pipeline inside a K-tile: the fragment reads of k-substep ks+1 are issued BEFORE the 8 MFMAs of substep ks
   // (two register sets), and the 8 LDS-DMA pieces of the next K-tile are spread over the four MFMA groups (2 per
@@ -192,42 +225,65 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   }
 #undef GEMM_STEP
 
-  // ---- epilogue: acc[nb][mb][4g + e] = C[m = wm*128 + mb*32 + l31][n = wn*64 + nb*32 + 8g + 4hi + e]
-  char *cw = smem + wave * (128 * 128);  // this wave's [128 rows][64 n] bf16 image, 16-byte slots XOR-swizzled by row
+  // ---- next tile's first K-tile in flight under this tile's epilogue
+  const bool more = can_prefetch && ti + nslots < chunk_len;
+  TileP nxt;
+  float4 nxt_bv;
+  if (more) {
+    tile_params(ti + nslots, step + 1, nxt);
+    nxt_bv = *reinterpret_cast<const float4 *>(bias + nxt.n0 + lane * 4);
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int nl = nb * 32 + 8 * g + 4 * hi;  // local column of the 4 values
-      const float4 bv = *reinterpret_cast<const float4 *>(bias + n0 + wn * 64 + nl);
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        float v0 = acc[nb][mb][4 * g + 0] + bv.x, v1 = acc[nb][mb][4 * g + 1] + bv.y;
-        float v2 = acc[nb][mb][4 * g + 2] + bv.z, v3 = acc[nb][mb][4 * g + 3] + bv.w;
-        if (EPI == 1) {
-          v0 = gelu_erf(v0);
-          v1 = gelu_erf(v1);
-          v2 = gelu_erf(v2);
-          v3 = gelu_erf(v3);
-        }
-        const int row = mb * 32 + l31;
-        const int slot = (nl >> 3) ^ (row & 7);
-        *reinterpret_cast<uint2 *>(cw + row * 128 + slot * 16 + (nl & 4) * 2) = make_uint2(cvt_pk_bf16_f32(v0, v1), cvt_pk_bf16_f32(v2, v3));
-      }
-    }
+    for (int i = 0; i < 4; ++i) stage_p(nxt, 0, 0, i);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // ---- epilogue: acc[nb][mb][4g + e] = C[m = wm*128 + mb*32 + l31][n = wn*64 + nb*32 + 8g + 4hi + e]
+  //      two passes of 64 rows per wave through buffer 1 (8 KiB per wave, 16-byte slots XOR-swizzled by row)
+  char *cw = smem + GEMM_BUFBYTES + wave * (64 * 128);
   char *Cb = reinterpret_cast<char *>(C);
 #pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int row = it * 8 + (lane >> 3), q = lane & 7;
-    const uint4 v = *reinterpret_cast<const uint4 *>(cw + row * 128 + ((q ^ (row & 7)) << 4));
-    const int m = m0 + wm * 128 + row;
-    if (m < M) *reinterpret_cast<uint4 *>(Cb + ((size_t)m * N + n0 + wn * 64 + q * 8) * 2) = v;
+  for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = nb * 32 + 8 * g + 4 * hi;  // local column of the 4 values
+        const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + wn * 64 + nl);
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+          const int mb = ps * 2 + mh;
+          float v0 = acc[nb][mb][4 * g + 0] + bv.x, v1 = acc[nb][mb][4 * g + 1] + bv.y;
+          float v2 = acc[nb][mb][4 * g + 2] + bv.z, v3 = acc[nb][mb][4 * g + 3] + bv.w;
+          if (EPI == 1) {
+            v0 = gelu_erf(v0);
+            v1 = gelu_erf(v1);
+            v2 = gelu_erf(v2);
+            v3 = gelu_erf(v3);
+          }
+          const int row = mh * 32 + l31;
+          const int slot = (nl >> 3) ^ (row & 7);
+          *reinterpret_cast<uint2 *>(cw + row * 128 + slot * 16 + (nl & 4) * 2) = make_uint2(cvt_pk_bf16_f32(v0, v1), cvt_pk_bf16_f32(v2, v3));
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (lane >> 3), q = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4 *>(cw + row * 128 + ((q ^ (row & 7)) << 4));
+      const int m = m0 + wm * 128 + ps * 64 + row;
+      if (m < M) *reinterpret_cast<uint4 *>(Cb + ((size_t)m * N + n0 + wn * 64 + q * 8) * 2) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  __syncthreads();  // every wave has read its staged outputs: the next tile's DMA may overwrite the buffers
+  __syncthreads();  // every wave has read its staged outputs: the next tile's K loop may overwrite buffer 1
+  have = more;
+  if (more) {
+    cur = nxt;
+    cur_bv = nxt_bv;
+  }
   }  // tile loop
 }
 
