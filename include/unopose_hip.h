@@ -188,6 +188,16 @@ int unopose_fine_correspondences(const float *atten, int B, int R, int C, const 
                                  const float *w2, const float *pts2, float *weight, float *pred,
                                  unopose_stream_t stream);
 
+/* fine stage without the similarity matrix (bf16 / autocast path; replaces compute_feature_similarity :260-282 followed by
+ * assign_labels + fine_correspondences): f1 (B,R,D) and f2 (B,C,D) are the L2-normalised out_proj features as bf16, f1
+ * already multiplied by 1/temp; x_ij = f1_i . f2_j is recomputed tile by tile on the matrix cores in each of the three
+ * reduction passes instead of being stored (16.8 MB per pair) and re-read.  shift = 1/temp (any bound of |x|: the softmax is
+ * evaluated as exp(x - shift) / sum, no running maxima).  D must be 256.  ws: B*(R+C) + B*(ceil((R-1)/256) + ceil((C-1)/256))
+ * floats of scratch.  Outputs as assign_labels / fine_correspondences: w1 (B,R-1), w2 (B,C-1), weight (B,R-1), pred (B,R-1,3). */
+int unopose_fine_assign(const void *f1, const void *f2, int B, int R, int C, int D, float shift, const float *score1,
+                        const float *score2, const float *pts2, float *ws, float *w1, float *w2, float *weight,
+                        float *pred, unopose_stream_t stream);
+
 /* out[bc,i] = min_j |p'_i - q_j| with p' = (p_i - t_bc) R_bc when R/t are given (row-vector
  * convention of the reference, :481, :559), bc = b*cand_per_b + c.  p (B,N,3), q (B,M,3). */
 int unopose_min_dist(const float *p, const float *q, int B, int N, int M, const float *R,

@@ -170,6 +170,9 @@ class FinePointMatchingOneRef(nn.Module):
             sc = self.score_heads[self.nblock - 1](f)
             scores = torch.cat((sc[:B], sc[B:]), dim=1)
             o = ops.linear(f, self.out_proj)
+            if self.taps is None and ops.fine_pose_fused_ok(o[:B], o[B:]):  # the similarity is never materialised
+                R, t, s = ops.fine_pose_from_features(o[:B], o[B:], self.cfg.temp, _scores(scores, n1), p1, p2)
+                return self._finish(end_points, R, t, s, radius)
             atten = ops.feature_similarity(o[:B], o[B:], self.cfg.temp)
         else:
             if p1_.shape == p2.shape:  # both clouds through the fused PE kernels as one batch of 2B
@@ -185,11 +188,19 @@ class FinePointMatchingOneRef(nn.Module):
             for blk in self.transformers:
                 f1, f2 = blk(f1, geo1, fps_idx1, f2, geo2, fps_idx2)
             scores = self.score_heads[self.nblock - 1](torch.cat((f1, f2), dim=1))
-            atten = ops.feature_similarity(ops.linear(f1, self.out_proj), ops.linear(f2, self.out_proj), self.cfg.temp)
+            o1, o2 = ops.linear(f1, self.out_proj), ops.linear(f2, self.out_proj)
+            if self.taps is None and ops.fine_pose_fused_ok(o1, o2):
+                R, t, s = ops.fine_pose_from_features(o1, o2, self.cfg.temp, _scores(scores, n1), p1, p2)
+                return self._finish(end_points, R, t, s, radius)
+            atten = ops.feature_similarity(o1, o2, self.cfg.temp)
         score = _scores(scores, n1)
         if self.taps is not None:
             self.taps.update(f1=f1, f2=f2, atten=atten, score=score)
         R, t, s = ops.fine_pose(atten, score, p1, p2)
+        return self._finish(end_points, R, t, s, radius)
+
+    @staticmethod
+    def _finish(end_points, R, t, s, radius):
         end_points["pred_R"] = R
         end_points["pred_t"] = t * (radius.reshape(-1, 1) + 1e-6)
         end_points["pred_pose_score"] = s

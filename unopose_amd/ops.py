@@ -806,6 +806,45 @@ def fine_pose(atten, score, pts1, pts2, dis_thres=0.15):
     return R, t, ps * w1.mean(1)
 
 
+USE_FUSED_FINE = True  # bf16 fine stage without the (B,N1+1,N2+1) similarity (csrc/fineassign.hip)
+
+
+def fine_pose_fused_ok(f1, f2):
+    """True when `fine_pose_from_features` may stand in for feature_similarity + fine_pose: HIP device, autocast (the
+    bf16 product the reference's autocast matmul makes), inference, 256-wide features."""
+    return (USE_FUSED_FINE and f1.is_cuda and torch.is_autocast_enabled() and not _DIFF and f1.shape[-1] == 256
+            and f2.shape[-1] == 256)
+
+
+def fine_pose_from_features(f1, f2, temp, score, pts1, pts2, dis_thres=0.15):
+    """compute_feature_similarity (cosine, /temp; model_utils.py:260-282) + compute_fine_Rt_overlap (:527-566) with the
+    similarity recomputed tile by tile inside the three reduction passes instead of stored: f1 (B,N1+1,256), f2
+    (B,N2+1,256) are the out_proj features (row 0 = background token).  Same bf16 operands / fp32 accumulation as the
+    autocast bmm of `feature_similarity`."""
+    B, N1, _ = pts1.shape
+    N2 = pts2.shape[1]
+    assert f1.shape == (B, N1 + 1, 256) and f2.shape == (B, N2 + 1, 256)
+    a = _c((F.normalize(f1.float(), p=2, dim=2) / temp).to(torch.bfloat16))
+    b = _c(F.normalize(f2.float(), p=2, dim=2).to(torch.bfloat16))
+    pts1, pts2 = _c(pts1.float()), _c(pts2.float())
+    score1, score2 = _c(score[:, :N1].float()), _c(score[:, N1:].float())
+    dev = pts1.device
+    R, C = N1 + 1, N2 + 1
+    with torch.cuda.device(dev):
+        ws = torch.empty(B * (R + C) + B * (-(-N1 // 256) - (-N2 // 256)), dtype=torch.float32, device=dev)
+        w1 = torch.empty(B, N1, dtype=torch.float32, device=dev)
+        w2 = torch.empty(B, N2, dtype=torch.float32, device=dev)
+        weight = torch.empty(B, N1, dtype=torch.float32, device=dev)
+        pred = torch.empty(B, N1, 3, dtype=torch.float32, device=dev)
+        call("unopose_fine_assign", ptr(a), ptr(b), B, R, C, 256, 1.0 / temp, ptr(score1), ptr(score2), ptr(pts2), ptr(ws),
+             ptr(w1), ptr(w2), ptr(weight), ptr(pred), stream_ptr())
+        Rm, t = weighted_procrustes(pred, pts1, weight, 0.001)
+        dis = torch.empty(B, N1, dtype=torch.float32, device=dev)
+        call("unopose_min_dist", ptr(pts1), ptr(pts2), B, N1, N2, ptr(Rm), ptr(t), 1, ptr(dis), stream_ptr())
+    ps = ((dis < dis_thres).float() * w1).sum(1) / (w1.sum(1) + 1e-8)
+    return Rm, t, ps * w1.mean(1)
+
+
 def add_layernorm(a, b, norm, out_dtype=None, out=None):
     """LayerNorm(a + b) in one HIP pass (b may be None); a/b fp32 or bf16, output `out_dtype`
     (default: bf16 under autocast, else a.dtype).  norm: nn.LayerNorm.  `out`: optional destination, a view
