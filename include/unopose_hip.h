@@ -188,6 +188,26 @@ int unopose_fine_correspondences(const float *atten, int B, int R, int C, const 
                                  const float *w2, const float *pts2, float *weight, float *pred,
                                  unopose_stream_t stream);
 
+/* ---- pixel features without the dense up-projection (ViT_AE, oneref_feature_extraction.py:200-236 + get_chosen_pixel_feats,
+ * model_utils.py:215-227): only the <= 4 cells of the (4 side)^2 x 256 map a chosen pixel's bilinear tap reads are computed.
+ * upproj_plan: choose (B2,Np) int64 pixel indices of the (H,W) crops -> row_list (cap_rows) activation row of every needed
+ * cell, grouped by sub-position s = 4 (Y & 3) + (X & 3) (groups padded to 256-row tiles with -1), cellmap (B2, 16 side^2)
+ * compact row of a cell, tile_info[18] = {tiles, first tile of group 0..16}.  Activation row = crop * tok_stride + tok_offset
+ * + token.  ws: B2 * (16 side^2 + 32) ints; cap_rows: a multiple of 256, >= B2 * min(4 Np, 16 side^2) + 4096. */
+int unopose_upproj_plan(const long long *choose, int B2, int Np, int H, int W, int side, int tok_offset, int tok_stride,
+                        int cap_rows, int *ws, int *row_list, int *cellmap, int *tile_info, unopose_stream_t stream);
+
+/* Row-gathered grouped form of linear_bf16: C[r] = A[row_list[r]] . W[g(r)*256 .. +255]^T + bias, g(r) = the group of r's tile
+ * (tile_info as written by upproj_plan; N / 256 groups).  A (M,K), W (N,K), C (max_tiles * 256, 256) bf16; bias fp32 (N).
+ * The tile count is read on the device. */
+int unopose_linear_bf16_gather(const void *A, long M, int K, const void *W, int N, const float *bias, const int *row_list,
+                               const int *tile_info, int max_tiles, void *C, unopose_stream_t stream);
+
+/* out (B2,Np,256) fp32 = bilinear blend of the 4 compact rows of each chosen pixel (torch upsample_bilinear2d,
+ * align_corners=False, then the pixel gather). */
+int unopose_bilinear_sample_compact(const void *Cc, const int *cellmap, const long long *choose, int B2, int side, int Np,
+                                    int H, int W, float *out, unopose_stream_t stream);
+
 /* fine stage without the similarity matrix (bf16 / autocast path; replaces compute_feature_similarity :260-282 followed by
  * assign_labels + fine_correspondences): f1 (B,R,D) and f2 (B,C,D) are the L2-normalised out_proj features as bf16, f1
  * already multiplied by 1/temp; x_ij = f1_i . f2_j is recomputed tile by tile on the matrix cores in each of the three

@@ -49,6 +49,26 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16_f32(float a, float b) {
   return r.u;
 }
 
+// ---- bilinear tap of a pixel of the (H, W) crop in the (hw, hw) feature map
+// torch upsample_bilinear2d, align_corners=False: src = max(0, (dst + 0.5) * in/out - 0.5)  (oneref_feature_extraction.py:229)
+struct BilinearTap {
+  int y0, x0, y1, x1;
+  float ly, lx;
+};
+__device__ __forceinline__ BilinearTap bilinear_tap(long long pix, int H, int W, int hw) {
+  BilinearTap t;
+  const int py = (int)(pix / W), px = (int)(pix - (long long)py * W);
+  const float sy = fmaxf(((float)py + 0.5f) * ((float)hw / (float)H) - 0.5f, 0.f);
+  const float sx = fmaxf(((float)px + 0.5f) * ((float)hw / (float)W) - 0.5f, 0.f);
+  t.y0 = min((int)sy, hw - 1);
+  t.x0 = min((int)sx, hw - 1);
+  t.y1 = t.y0 < hw - 1 ? t.y0 + 1 : t.y0;
+  t.x1 = t.x0 < hw - 1 ? t.x0 + 1 : t.x0;
+  t.ly = sy - (float)t.y0;
+  t.lx = sx - (float)t.x0;
+  return t;
+}
+
 // ---- wave64 DPP reductions (gfx9 row_shr / row_bcast) ----------------------
 // dpp_ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
 template <int CTRL, int ROW_MASK>

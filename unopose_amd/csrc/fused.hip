@@ -155,14 +155,10 @@ __global__ __launch_bounds__(256) void bilinear_sample_kernel(const void *__rest
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= Np) return;
   const long long pix = choose[(size_t)b * Np + p];
-  const int py = (int)(pix / W), px = (int)(pix - (long long)py * W);
   const int hw = 4 * side;
-  // torch upsample_bilinear2d, align_corners=False: src = max(0, (dst + 0.5) * in/out - 0.5)
-  const float sy = fmaxf(((float)py + 0.5f) * ((float)hw / (float)H) - 0.5f, 0.f);
-  const float sx = fmaxf(((float)px + 0.5f) * ((float)hw / (float)W) - 0.5f, 0.f);
-  const int y0 = min((int)sy, hw - 1), x0 = min((int)sx, hw - 1);
-  const int y1 = y0 < hw - 1 ? y0 + 1 : y0, x1 = x0 < hw - 1 ? x0 + 1 : x0;
-  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  const BilinearTap tp = bilinear_tap(pix, H, W, hw);
+  const int y0 = tp.y0, x0 = tp.x0, y1 = tp.y1, x1 = tp.x1;
+  const float ly = tp.ly, lx = tp.lx;
   auto at = [&](int Y, int X) -> size_t {  // element offset of map pixel (Y,X), channel 0
     // patch token (Y>>2, X>>2) of image b sits at row tok_off + index of a (B, tok_stride, 16, 256) tensor
     return ((((size_t)b * tok_stride + tok_off + (size_t)(Y >> 2) * side + (X >> 2))) * 16 + (Y & 3) * 4 + (X & 3)) * 256;

@@ -60,10 +60,16 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return fmaf(fabsf(hx), erfz, hx);  // 0.5 x + 0.5 |x| erf(|x|/sqrt2) = 0.5 x (1 + sign(x) erf(.))
 }
 
-template <int EPI>  // 0: bias; 1: bias + exact GELU
+// GATHER (grouped, row-gathered form; unopose_linear_bf16_gather): output row r of tile t is A row row_list[256 t + r]
+// times the 256-row weight block of the group tile t belongs to (tile_info[1 + g] = first tile of group g, g = 0..N/256;
+// tile_info[0] = number of tiles, read on the device: the host never learns it); C is (tiles * 256, 256).
+template <int EPI, bool GATHER = false>  // EPI 0: bias; 1: bias + exact GELU
 __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict__ A, const u16 *__restrict__ W,
                                                            const float *__restrict__ bias, u16 *__restrict__ C, int M,
-                                                           int N, int K, int tiles_n, int tiles) {
+                                                           int N, int K, int tiles_n, int tiles_arg,
+                                                           const int *__restrict__ row_list = nullptr,
+                                                           const int *__restrict__ tile_info = nullptr) {
+  const int tiles = GATHER ? __builtin_amdgcn_readfirstlane(tile_info[0]) : tiles_arg;
   __shared__ __attribute__((aligned(1024))) char smem[2 * GEMM_BUFBYTES];
   __shared__ __attribute__((aligned(16))) float bias_lds[GEMM_BN];  // this tile's bias slice (LDS reads: no vmcnt traffic in the epilogue)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,10 +107,20 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   };
   auto tile_params = [&](int ti, int step, TileP &p) {
     const int t = chunk_base + ti;
-    // tile order: groups of GEMM_GM row panels, column tiles fastest across the group
-    const int mg = t / per_group, rr = t - mg * per_group;
-    const int gm = min(GEMM_GM, tiles_m - mg * GEMM_GM);
-    const int tn = rr / gm, tm = mg * GEMM_GM + (rr - tn * gm);
+    int tn, tm;
+    if (GATHER) {
+      tm = t;
+      tn = 0;
+      const int ng = N / GEMM_BN;
+      for (int g = 1; g < ng; ++g) tn += t >= tile_info[1 + g] ? 1 : 0;  // the group of tile t (uniform scalar loads)
+      tn = __builtin_amdgcn_readfirstlane(tn);
+    } else {
+      // tile order: groups of GEMM_GM row panels, column tiles fastest across the group
+      const int mg = t / per_group, rr = t - mg * per_group;
+      const int gm = min(GEMM_GM, tiles_m - mg * GEMM_GM);
+      tn = rr / gm;
+      tm = mg * GEMM_GM + (rr - tn * gm);
+    }
     p.m0 = __builtin_amdgcn_readfirstlane(tm * GEMM_BM);
     p.n0 = __builtin_amdgcn_readfirstlane(tn * GEMM_BN);
     // LDS-DMA (buffer_load_dwordx4 ... lds): piece j = wave * 4 + i covers tile rows 8j .. 8j+7; per-lane byte offset in the
@@ -113,7 +129,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
     for (int i = 0; i < 4; ++i) {
       const int row = wave * 32 + i * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((row >> 1) & 7);
-      p.a_off[i] = (uint32_t)(((size_t)((GEMM_ABL == 7 ? 0 : p.m0) + row) * K + c * 8) * 2);  // ABL 7: every tile streams tile (0, 0)
+      int arow = (GEMM_ABL == 7 ? 0 : p.m0) + row;  // ABL 7: every tile streams tile (0, 0)
+      if (GATHER) arow = max(row_list[p.m0 + row], 0);  // padding rows of a group (-1) compute on row 0; nobody reads them
+      p.a_off[i] = (uint32_t)(((size_t)arow * K + c * 8) * 2);
       p.w_off[i] = (uint32_t)(((size_t)((GEMM_ABL == 7 ? 0 : p.n0) + row) * K + c * 8) * 2);
     }
     // K-tile rotation, uniform over the tiles an XCD runs together (they must stay on the same K-slice to share it) and
@@ -272,7 +290,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
       const int row = it * 8 + (lane >> 3), q = lane & 7;
       const uint4 v = *reinterpret_cast<const uint4 *>(cw + row * 128 + ((q ^ (row & 7)) << 4));
       const int m = m0 + wm * 128 + ps * 64 + row;
-      if (m < M) *reinterpret_cast<uint4 *>(Cb + ((size_t)m * N + n0 + wn * 64 + q * 8) * 2) = v;
+      if (GATHER) *reinterpret_cast<uint4 *>(Cb + ((size_t)m * GEMM_BN + wn * 64 + q * 8) * 2) = v;
+      else if (m < M) *reinterpret_cast<uint4 *>(Cb + ((size_t)m * N + n0 + wn * 64 + q * 8) * 2) = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -319,6 +338,27 @@ int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C
     hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
                        K, tiles_n, tiles);
   return check_launch("linear_bf16");
+}
+
+int unopose_linear_bf16_gather(const void *A, long M, int K, const void *W, int N, const float *bias, const int *row_list,
+                               const int *tile_info, int max_tiles, void *C, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(A && W && bias && C && row_list && tile_info, "linear_bf16_gather: null pointer");
+  UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && N / GEMM_BN <= 64 && K >= GEMM_BK && K % GEMM_BK == 0,
+                  "linear_bf16_gather: needs N %% 256 == 0 and K %% 64 == 0 (got M=%ld N=%d K=%d)", M, N, K);
+  UNOPOSE_REQUIRE((size_t)M * K * 2 < (1UL << 32) && (size_t)N * K * 2 < (1UL << 32), "linear_bf16_gather: operand larger than 4 GiB");
+  UNOPOSE_REQUIRE(max_tiles >= 0, "linear_bf16_gather: bad tile capacity");
+  if (max_tiles == 0) return UNOPOSE_OK;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8)
+      cu = 256;
+    n_cu = cu & ~7;
+  }
+  const int grid = max_tiles >= n_cu ? n_cu : ((max_tiles + 7) & ~7);
+  hipLaunchKernelGGL((gemm_bf16_kernel<0, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, (const u16 *)A, (const u16 *)W, bias,
+                     (u16 *)C, (int)M, N, K, 1, 0, row_list, tile_info);
+  return check_launch("linear_bf16_gather");
 }
 
 }  // extern "C"

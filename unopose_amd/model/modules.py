@@ -206,7 +206,11 @@ class ViT_AE(nn.Module):
         the 5 class / register tokens stay in place (tok_offset = 5: the pixel sampler skips them by index
         math), so neither the tap concatenation nor the prefix slice (F:213) costs a copy."""
         B, _, H, W = x.shape
-        outs = self.vit(x, taps_side_by_side=True)
+        return self.upproject(self.vit(x, taps_side_by_side=True), H, W)
+
+    def upproject(self, outs, H, W):
+        """The second half of `upprojected_tokens`, on what `self.vit(x, taps_side_by_side=True)` returned."""
+        B = outs.shape[0] if torch.is_tensor(outs) else outs[0].shape[0]
         if torch.is_tensor(outs):
             z = ops.linear(outs, self.output_upscaling)
             return z.reshape(B, outs.shape[1], 4, 4, self.out_dim), (H, W), outs.shape[1] - (H // 14) * (W // 14)

@@ -254,6 +254,15 @@ class UNOPose(nn.Module):
             sel_choose = torch.gather(tem_choose, 1, idx_o.long())
             for t in (idx_o, dense_po, sel_choose):
                 t.record_stream(main)
+            plan = None
+            if ops.sparse_upproj_ok(rgb) and sel_choose.shape == choose.shape and net.out_dim == 256 and rgb.shape == tem_rgb.shape:
+                # which cells of the up-projected map the 2 x 2048 chosen pixels read: known before the ViT has run
+                sd = rgb.shape[-1] // 14
+                npre = net.vit.cls_token.shape[1] + net.vit.reg_token.shape[1]
+                plan = ops.upproj_plan(torch.cat([choose, sel_choose], 0), rgb.shape[-2], rgb.shape[-1], sd, npre, npre + sd * sd)
+                for t in plan.values():
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
             pre = None
             if GEOM_UNDER_VIT:
                 # the other latency-bound, feature-independent steps ride along: both global LRFs, the two
@@ -275,7 +284,15 @@ class UNOPose(nn.Module):
                     t.record_stream(main)
         # both crops through the ViT as ONE batch of 2B images
         B = rgb.shape[0]
-        z, (H, W), off = net.upprojected_tokens(torch.cat([rgb, tem_rgb], 0))
+        if plan is not None:
+            acts = net.vit(torch.cat([rgb, tem_rgb], 0), taps_side_by_side=True)
+            if torch.is_tensor(acts) and acts.shape[1] == plan["tok_stride"]:
+                main.wait_stream(side)
+                both = ops.sparse_pixel_features(acts, net.output_upscaling, plan)  # query | reference, stacked
+                return dense_pm, both[:B], dense_po, both[B:], radius, pre
+            z, (H, W), off = net.upproject(acts, rgb.shape[-2], rgb.shape[-1])
+        else:
+            z, (H, W), off = net.upprojected_tokens(torch.cat([rgb, tem_rgb], 0))
         # query | reference features land in ONE (2B,N,256) buffer: the fine matcher takes them stacked
         both = torch.empty(2 * B, choose.shape[1], 256, dtype=torch.float32, device=z.device) \
             if sel_choose.shape == choose.shape else None

@@ -253,6 +253,59 @@ def bilinear_sample_native(z, choose, H, W, out=None, tok_offset=0):
     return out
 
 
+USE_SPARSE_UPPROJ = True  # only the map cells the chosen pixels' bilinear taps read are up-projected (csrc/upproj.hip)
+
+
+def sparse_upproj_ok(x):
+    """True when `upproj_plan` + `sparse_pixel_features` may stand in for the dense up-projection + pixel sampling:
+    HIP device, autocast (bf16 operands, as the dense autocast GEMM), inference."""
+    return USE_SPARSE_UPPROJ and x.is_cuda and torch.is_autocast_enabled() and not _DIFF
+
+
+def upproj_plan(choose, H, W, side, tok_offset, tok_stride):
+    """choose (B2,Np) int64 pixel indices of (H,W) crops -> the gather plan of csrc/upproj.hip (device tensors only;
+    needs nothing from the ViT, so it can be built on a side stream while the ViT runs)."""
+    choose = _c(choose.long())
+    B2, Np = choose.shape
+    cells = 16 * side * side
+    cap_rows = (B2 * min(4 * Np, cells) + 16 * 256 + 255) // 256 * 256
+    dev = choose.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    plan = dict(choose=choose, H=int(H), W=int(W), side=int(side), tok_offset=int(tok_offset), tok_stride=int(tok_stride),
+                cap_rows=cap_rows, ws=torch.empty(B2 * (cells + 32), **i32), row_list=torch.empty(cap_rows, **i32),
+                cellmap=torch.empty(B2 * cells, **i32), tile_info=torch.empty(18, **i32))
+    with torch.cuda.device(dev):
+        call("unopose_upproj_plan", ptr(choose), B2, Np, int(H), int(W), int(side), int(tok_offset), int(tok_stride), cap_rows,
+             ptr(plan["ws"]), ptr(plan["row_list"]), ptr(plan["cellmap"]), ptr(plan["tile_info"]), stream_ptr())
+    return plan
+
+
+def sparse_pixel_features(acts, lin, plan, out=None):
+    """ViT_AE's Linear 3072->4096 + pixel shuffle + bilinear upsampling + pixel gather (oneref_feature_extraction.py:
+    200-236, model_utils.py:215-227) evaluated only where the chosen pixels look: acts (B2, tok_stride, K) bf16 token
+    activations (prefix tokens in place), lin the up-projection -> (B2, Np, 256) fp32.  Same bf16 operands, fp32
+    accumulation and bf16 rounding of the cell values as the dense path (`linear` + `bilinear_sample_native`)."""
+    acts = _c(acts)
+    B2, ts, K = acts.shape
+    assert acts.dtype == torch.bfloat16 and ts == plan["tok_stride"] and B2 == plan["choose"].shape[0]
+    cache = _bf16_weights(lin)
+    w, bias = cache[1], cache[3]
+    N = w.shape[0]
+    assert N == 16 * 256 and w.shape[1] == K
+    Np = plan["choose"].shape[1]
+    dev = acts.device
+    if out is None:
+        out = torch.empty(B2, Np, 256, dtype=torch.float32, device=dev)
+    assert out.shape == (B2, Np, 256) and out.dtype == torch.float32 and out.is_contiguous()
+    with torch.cuda.device(dev):
+        cells = torch.empty(plan["cap_rows"], 256, dtype=torch.bfloat16, device=dev)
+        call("unopose_linear_bf16_gather", ptr(acts), B2 * ts, K, ptr(w), N, ptr(bias), ptr(plan["row_list"]),
+             ptr(plan["tile_info"]), plan["cap_rows"] // 256, ptr(cells), stream_ptr())
+        call("unopose_bilinear_sample_compact", ptr(cells), ptr(plan["cellmap"]), ptr(plan["choose"]), B2, plan["side"], Np,
+             plan["H"], plan["W"], ptr(out), stream_ptr())
+    return out
+
+
 def bilinear_sample_pixels(low, choose, H, W):
     """F.interpolate(map, (H,W), bilinear, align_corners=False) followed by the pixel gather of
     get_chosen_pixel_feats (oneref_feature_extraction.py:229, model_utils.py:215-227), fused: only the
