@@ -66,6 +66,71 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const void *__restri
   }
 }
 
+// The same, four contiguous channels per lane (16-byte fp32 / 8-byte bf16 accesses): C % 4 == 0, ldo % 4 == 0, C <= 1024.
+// Same arithmetic per element as add_layernorm_kernel; the row sums run over a different partition of the row.
+template <bool BF>
+__device__ __forceinline__ float4 fu_load4(const void *p, size_t i) {
+  if (BF) {
+    const uint2 r = *reinterpret_cast<const uint2 *>(reinterpret_cast<const u16 *>(p) + i);
+    return make_float4(fu_bf2f((u16)(r.x & 0xFFFF)), fu_bf2f((u16)(r.x >> 16)), fu_bf2f((u16)(r.y & 0xFFFF)), fu_bf2f((u16)(r.y >> 16)));
+  }
+  return *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p) + i);
+}
+template <bool A_BF16, bool B_BF16, bool HAS_B, bool OUT_BF16>
+__global__ __launch_bounds__(256) void add_layernorm_vec4_kernel(const void *__restrict__ a, const void *__restrict__ b,
+                                                                 const float *__restrict__ w, const float *__restrict__ bias, long rows,
+                                                                 int C, float eps, void *__restrict__ out, long ldo) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+      x = fu_load4<A_BF16>(a, (size_t)r * C + c);
+      if (HAS_B) {
+        const float4 y = fu_load4<B_BF16>(b, (size_t)r * C + c);
+        x.x += y.x;
+        x.y += y.y;
+        x.z += y.z;
+        x.w += y.w;
+      }
+    }
+    v[i] = x;
+    s += (x.x + x.y) + (x.z + x.w);
+  }
+  const float mean = wave_sum_f32(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if ((i * 64 + lane) * 4 < C) {
+      const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum_f32(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+      const float4 wv = *reinterpret_cast<const float4 *>(w + c), bv = *reinterpret_cast<const float4 *>(bias + c);
+      const float y0 = (v[i].x - mean) * rstd * wv.x + bv.x, y1 = (v[i].y - mean) * rstd * wv.y + bv.y;
+      const float y2 = (v[i].z - mean) * rstd * wv.z + bv.z, y3 = (v[i].w - mean) * rstd * wv.w + bv.w;
+      if (OUT_BF16) {
+        uint2 o;
+        o.x = (uint32_t)fu_f2bf(y0) | ((uint32_t)fu_f2bf(y1) << 16);
+        o.y = (uint32_t)fu_f2bf(y2) | ((uint32_t)fu_f2bf(y3) << 16);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<u16 *>(out) + (size_t)r * ldo + c) = o;
+      } else {
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(out) + (size_t)r * ldo + c) = make_float4(y0, y1, y2, y3);
+      }
+    }
+  }
+}
+
 // x[r,:] += gamma * y[r,:] (fp32 residual stream, in place) AND out[r,:] = LayerNorm(x[r,:]) (bf16):
 // the LayerScale residual of one ViT branch fused with the LayerNorm that opens the next branch, so the
 // residual stream is read once instead of twice.  One wavefront per row, C <= 1024.
@@ -207,8 +272,14 @@ int unopose_add_layernorm_strided(const void *a, int a_bf16, const void *b, int 
   if (rows == 0) return UNOPOSE_OK;
   dim3 grid((unsigned)((rows + 3) / 4));
   hipStream_t s = (hipStream_t)stream;
-#define UNOPOSE_LN(AB, BB, HB, OB)                                                                         \
-  hipLaunchKernelGGL((add_layernorm_kernel<AB, BB, HB, OB>), grid, dim3(256), 0, s, a, b, w, bias, rows, C, eps, out, ld_out)
+  const bool vec4 = C % 4 == 0 && ld_out % 4 == 0;  // every model shape (C = 256, 768); the scalar form covers the rest
+#define UNOPOSE_LN(AB, BB, HB, OB)                                                                                               \
+  do {                                                                                                                           \
+    if (vec4)                                                                                                                    \
+      hipLaunchKernelGGL((add_layernorm_vec4_kernel<AB, BB, HB, OB>), grid, dim3(256), 0, s, a, b, w, bias, rows, C, eps, out, ld_out); \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((add_layernorm_kernel<AB, BB, HB, OB>), grid, dim3(256), 0, s, a, b, w, bias, rows, C, eps, out, ld_out);      \
+  } while (0)
   const int key = (a_bf16 ? 8 : 0) | (b ? (b_bf16 ? 4 : 0) | 2 : 0) | (out_bf16 ? 1 : 0);
   switch (key) {
     case 0: UNOPOSE_LN(false, false, false, false); break;
