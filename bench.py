@@ -37,10 +37,11 @@ def parse(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (same GPU time: "
                     "the step is GPU-bound, not launch-bound, at every batch size measured)")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="forwards in flight per GPU: consecutive steps are dealt round-robin over this many HIP streams (a "
-                         "step is still one forward over one batch; the latency-bound tail of one batch then overlaps the "
-                         "ViT of the next).  Large library GEMMs are serialised across the streams (ops.SERIALIZE_BIG_GEMMS)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="forwards in flight per GPU (unopose_amd.pipeline.PipelinedForward): consecutive steps are dealt "
+                         "round-robin over this many HIP streams; a step is still one forward over one batch, and the "
+                         "latency-bound matcher of one batch runs underneath the ViT of the next.  1 = one stream.  The "
+                         "fp32 path always runs one at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the extra fp32 (reference default precision) leg")
@@ -318,49 +319,44 @@ def main():
 
         graphed = GraphedForward(model, batch, torch.bfloat16 if amp else None)
 
-    streams = None
-    if args.inflight > 1 and not args.dry_run:
-        from unopose_amd import ops
+    # consecutive steps go through unopose_amd.pipeline.PipelinedForward: with --inflight 2 (default on the bf16 path) the
+    # matcher of step i runs underneath the ViT of step i+1 on a second HIP stream.  A step is still one whole forward
+    # over one batch, all K of them start and finish inside the timed region.
+    pipe = None
+    if not args.dry_run and graphed is None:
+        from unopose_amd.pipeline import PipelinedForward
 
-        ops.SERIALIZE_BIG_GEMMS = True
-        streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
-        for s_ in streams:
-            s_.wait_stream(torch.cuda.current_stream())
-    step_no = [0]
+        pipe = PipelinedForward(model, depth=args.inflight if amp else 1, autocast_dtype=torch.bfloat16 if amp else None, timing=True)
+        args.inflight = pipe.depth
 
     def step(use_amp=amp):
+        """-> a callable returning the end_points of this step (host-visible after the final synchronize)."""
         ep = dict(batch)
         if graphed is not None:  # inputs copied into the graph's static buffers, one hipGraphLaunch
-            return graphed(ep)
-        if streams is not None:
-            s_ = streams[step_no[0] % len(streams)]
-            step_no[0] += 1
-            with torch.cuda.stream(s_):
-                return forward(ep, use_amp)
-        return forward(ep, use_amp)
+            o = graphed(ep)
+            return lambda: o
+        if pipe is not None and use_amp == amp:
+            return pipe.submit(ep).result
+        o = forward(ep, use_amp)
+        return lambda: o
 
     log("model + batch ready (rank %d of %d)" % (rank, world))
     for _ in range(args.warmup):
         out = step()
+    if pipe is not None:
+        pipe.drain()
     sync()
     log("warm-up done")
     if world > 1:
         dist.barrier()
     sync()
-    # per-step HIP events on the launch stream (median / p10 / p90); `value` keeps the contract's wall clock
-    evs = None
-    if not args.dry_run and streams is None:
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    tickets_from = len(pipe.history) if pipe is not None else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if evs is not None:
-            evs[i].record()
         out = step()
-    if evs is not None:
-        evs[-1].record()
-    if streams is not None:  # the default stream (pose gather, sanity) joins every launch stream
-        for s_ in streams:
-            torch.cuda.current_stream().wait_stream(s_)
+    out = out()  # joins the stream of the last step to the current one
+    if pipe is not None:
+        pipe.drain()
     poses = torch.cat([out["pred_R"].reshape(B, 9), out["pred_t"], out["pred_pose_score"].reshape(B, 1)], 1)
     if world > 1:  # gather of poses to rank 0 (the reference lacks it: every rank writes the same file)
         poses = poses.to(comm_dev)
@@ -402,11 +398,19 @@ def main():
     }
     if args.dry_run:
         res["dry_run"] = True
-    if evs is not None:
-        ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
-        q = lambda f: ms[min(len(ms) - 1, int(round(f * (len(ms) - 1))))]  # noqa: E731
-        res["step_ms_hip_events"] = {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "min": ms[0], "max": ms[-1],
-                                     "pairs_per_s_at_median": world * B / q(0.5) * 1e3}
+    if pipe is not None:
+        # HIP events of every step: start / end on the stream it ran on.  `step_ms_hip_events` = intervals between the
+        # completions of consecutive steps (the throughput view: with one forward in flight this is the step time);
+        # `forward_latency_ms` = start -> end of one forward (longer than a step when two overlap).
+        hist = pipe.history[tickets_from:]
+        q = lambda v, f: v[min(len(v) - 1, int(round(f * (len(v) - 1))))]  # noqa: E731
+        gaps = sorted(hist[i][1].elapsed_time(hist[i + 1][1]) for i in range(len(hist) - 1))
+        lat = sorted(a.elapsed_time(b) for a, b in hist)
+        if gaps:
+            res["step_ms_hip_events"] = {"median": q(gaps, 0.5), "p10": q(gaps, 0.1), "p90": q(gaps, 0.9), "min": gaps[0], "max": gaps[-1],
+                                         "pairs_per_s_at_median": world * B / q(gaps, 0.5) * 1e3,
+                                         "what": "interval between the completion events of consecutive steps"}
+        res["forward_latency_ms"] = {"median": q(lat, 0.5), "p10": q(lat, 0.1), "p90": q(lat, 0.9)}
     if rank == 0 and world == 1 and not args.dry_run:
         if amp and not args.no_fp32 and graphed is None:
             # the reference's default precision (configs/main_cfg.py:87-89: test.amp.enabled=False)
@@ -418,7 +422,7 @@ def main():
                 o32 = step(False)
             sync()
             d32 = time.perf_counter() - t1
-            e32 = (o32["pred_R"] - R_gt).abs().amax(dim=(1, 2))
+            e32 = (o32()["pred_R"] - R_gt).abs().amax(dim=(1, 2))
             log("fp32 leg done")
             res["fp32"] = {"value": B * k / d32, "unit": "pairs/s", "ms_per_step": d32 / k * 1e3, "steps": k,
                            "median_rot_err_vs_gt": e32.median().item()}

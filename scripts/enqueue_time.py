@@ -7,8 +7,10 @@ from unopose_amd.synthetic import make_batch, trained_like_
 torch.set_grad_enabled(False)
 dev = torch.device("cuda")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-model = trained_like_(UNOPose(default_model_cfg())).to(dev).eval()
-ep, _, _ = make_batch(B, device=dev)
+S0 = int(sys.argv[2]) if len(sys.argv) > 2 else 224
+model = trained_like_(UNOPose(default_model_cfg(feature_extraction=dict(img_size=S0)))).to(dev).eval()
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 224
+ep, _, _ = make_batch(B, S=S, device=dev)
 ep["coarse_rand"] = torch.rand(B, 18000, device=dev)
 def step():
     with torch.autocast("cuda", dtype=torch.bfloat16):

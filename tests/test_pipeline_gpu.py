@@ -1,27 +1,15 @@
-"""Provider -> runner -> UNOPose.forward on the GPU: items of the synthetic BOP
-folder at the production shapes (2048 observed / 5000 reference points, 224x224 crops).  The small
-synthetic objects are sampled WITH replacement, so the clouds are full of duplicate points -- the case the
-reference's dataset produces for small masks (pfoneref_bop_test_dataset_v2.py:200-203) and the one that
-makes FPS ties routine."""
-import numpy as np
+"""unopose_amd.pipeline.PipelinedForward: two forwards in flight return bit-identical poses to one-at-a-time execution
+(same kernels on the same inputs; no atomics on the forward path), tickets resolve in any order, the fp32 path falls back
+to depth 1, and a configuration with library stream-K GEMMs is refused."""
+import os
+import sys
+
 import pytest
 import torch
 
-import bop_synth
-
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
-
-
-@pytest.fixture(scope="module")
-def images(tmp_path_factory):
-    from unopose_amd.provider import BOPTestsetOneRef, collate_image
-
-    root = str(tmp_path_factory.mktemp("bop"))
-    cfg, det_path = bop_synth.build(root)
-    cfg.update(img_size=224, n_sample_observed_point=2048, n_sample_template_point=5000)
-    ds = BOPTestsetOneRef(cfg, "ycbv", det_path)
-    np.random.seed(11)
-    return [collate_image(ds[i]) for i in range(len(ds))]
+KEYS = ("init_R", "init_t", "init_pose_score", "pred_R", "pred_t", "pred_pose_score")
 
 
 @pytest.fixture(scope="module")
@@ -29,41 +17,73 @@ def model():
     from unopose_amd.model import UNOPose, default_model_cfg
     from unopose_amd.synthetic import trained_like_
 
-    torch.manual_seed(0)
     return trained_like_(UNOPose(default_model_cfg())).cuda().eval()
 
 
-@torch.no_grad()
-def test_provider_items_through_the_model(images, model, tmp_path):
-    from unopose_amd.runner import ReferenceCache, inference_and_save
+def batches(n, B=3):
+    from unopose_amd.synthetic import make_batch
 
-    cache = ReferenceCache(model)
-    torch.manual_seed(5)
-    lines = inference_and_save(model, images, str(tmp_path / "r.csv"), instance_batch_size=2, device="cuda",
-                               sync=torch.cuda.synchronize, ref_cache=cache)
-    assert len(lines) == 3 and (cache.misses, cache.hits) == (2, 1)  # views (10,5,2) and (49,7,5); the first is reused
-    for ln in lines:
-        f = ln.split(",")
-        R = np.array(f[4].split(), np.float64).reshape(3, 3)
-        t = np.array(f[5].split(), np.float64)
-        assert np.isfinite(R).all() and np.isfinite(t).all() and np.isfinite(float(f[3]))
-        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-3 and abs(np.linalg.det(R) - 1) < 1e-3
-    # the same draw of the coarse hypotheses -> cached and uncached poses agree.  Loose bound: these are
-    # noise crops through random weights, where the hypothesis arg-max amplifies GEMM-rounding differences
-    # between a 2B-crop and a B-crop ViT batch (the tight 1e-4 check of the cache is in test_model_gpu.py)
-    torch.manual_seed(5)
-    lines2 = inference_and_save(model, images, str(tmp_path / "r2.csv"), instance_batch_size=2, device="cuda")
-    for a, b in zip(lines, lines2):
-        fa, fb = a.split(","), b.split(",")
-        assert np.abs(np.array(fa[4].split(), float) - np.array(fb[4].split(), float)).max() < 5e-2
-        assert np.abs(np.array(fa[5].split(), float) - np.array(fb[5].split(), float)).max() < 25.0  # mm
+    out = []
+    for i in range(n):
+        ep, _, _ = make_batch(B, S=224, seed=50 + i, device="cuda")
+        ep["coarse_rand"] = torch.rand(B, 18000, generator=torch.Generator().manual_seed(i)).cuda()
+        out.append(ep)
+    return out
 
 
 @torch.no_grad()
-def test_duplicate_points_fps_matches_oracle(images, oracle_ext, hip_ext):
-    """Clouds sampled with replacement: FPS indices still bit-exact against the oracle (tie rule)."""
-    pts = images[0]["tem1_pts"][0].contiguous()
-    assert pts.shape[1] == 5000 and len(np.unique(pts[0].numpy(), axis=0)) < 5000  # duplicates present
-    want = oracle_ext.furthest_point_sampling(pts, 2048)
-    got = hip_ext.furthest_point_sampling(pts.cuda(), 2048).cpu()
-    assert torch.equal(got, want)
+def test_two_in_flight_equals_one_at_a_time(model):
+    from unopose_amd.pipeline import PipelinedForward
+
+    eps = batches(6)
+    seq = PipelinedForward(model, depth=1)
+    ref = [{k: seq.submit(dict(ep)).wait()[k].clone() for k in KEYS} for ep in eps]
+    pipe = PipelinedForward(model, depth=2, timing=True)
+    assert pipe.depth == 2 and len(pipe.streams) == 2
+    tickets = [pipe.submit(dict(ep)) for ep in eps]
+    for i in (3, 0, 5, 1, 4, 2):  # results may be collected in any order
+        out = tickets[i].result()
+        for k in KEYS:
+            assert torch.equal(out[k], ref[i][k]), (i, k)
+    pipe.drain()
+    torch.cuda.synchronize()
+    assert len(pipe.history) == 6 and all(a.elapsed_time(b) > 0 for a, b in pipe.history)
+
+
+@torch.no_grad()
+def test_fp32_runs_one_at_a_time_and_library_gemms_are_refused(model):
+    from unopose_amd import ops
+    from unopose_amd.pipeline import PipelinedForward
+
+    p32 = PipelinedForward(model, depth=2, autocast_dtype=None)
+    assert p32.depth == 1 and p32.streams == [None]
+    ep = batches(1, B=2)[0]
+    out = p32.submit(dict(ep)).result()
+    assert out["pred_R"].dtype == torch.float32 and torch.isfinite(out["pred_R"]).all()
+    old = ops.HIP_GEMM_ALL
+    ops.HIP_GEMM_ALL = False
+    try:
+        with pytest.raises(RuntimeError, match="HIP_GEMM_ALL"):
+            PipelinedForward(model, depth=2)
+    finally:
+        ops.HIP_GEMM_ALL = old
+    with pytest.raises(ValueError):
+        PipelinedForward(model, depth=0)
+
+
+@torch.no_grad()
+def test_patch_embed_on_the_hand_written_gemm(model):
+    """ops.patch_embed (K = 588 zero-padded to 640, csrc/gemm.hip) against the fp32 convolution it replaces."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(20, 3, 224, 224, generator=g).cuda()  # 20 x 256 patches = 5120 rows: above the hand-written GEMM's floor
+    conv = model.feature_extraction.rgb_net.vit.patch_embed.proj
+    ref = torch.nn.functional.conv2d(x, conv.weight, conv.bias, stride=14).flatten(2).transpose(1, 2)
+    patches = x.reshape(20, 3, 16, 14, 16, 14).permute(0, 2, 4, 1, 3, 5).reshape(20, 256, 588)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = ops.patch_embed(patches, conv)
+    assert out.dtype == torch.bfloat16 and out.shape == ref.shape
+    e = (out.float() - ref).abs().max().item()
+    print(f"patch embed vs fp32 conv: max err {e:.2e} (|ref| max {ref.abs().max().item():.2f})")
+    assert e < 2 ** -6 * max(1.0, ref.abs().max().item())

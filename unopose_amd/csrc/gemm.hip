@@ -63,7 +63,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // GATHER (grouped, row-gathered form; unopose_linear_bf16_gather): output row r of tile t is A row row_list[256 t + r]
 // times the 256-row weight block of the group tile t belongs to (tile_info[1 + g] = first tile of group g, g = 0..N/256;
 // tile_info[0] = number of tiles, read on the device: the host never learns it); C is (tiles * 256, 256).
-template <int EPI, bool GATHER = false>  // EPI 0: bias; 1: bias + exact GELU
+template <int EPI, bool GATHER = false>  // EPI 0: bias; 1: bias + exact GELU; 2: bias + ReLU
 __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict__ A, const u16 *__restrict__ W,
                                                            const float *__restrict__ bias, u16 *__restrict__ C, int M,
                                                            int N, int K, int tiles_n, int tiles_arg,
@@ -276,6 +276,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
             v2 = gelu_erf(v2);
             v3 = gelu_erf(v3);
           }
+          if (EPI == 2) {
+            v0 = fmaxf(v0, 0.f);
+            v1 = fmaxf(v1, 0.f);
+            v2 = fmaxf(v2, 0.f);
+            v3 = fmaxf(v3, 0.f);
+          }
           const int row = mh * 32 + l31;
           const int slot = (nl >> 3) ^ (row & 7);
           *reinterpret_cast<uint2 *>(cw + row * 128 + slot * 16 + (nl & 4) * 2) = make_uint2(cvt_pk_bf16_f32(v0, v1), cvt_pk_bf16_f32(v2, v3));
@@ -320,7 +326,7 @@ int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C
   UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && K >= GEMM_BK && K % GEMM_BK == 0,
                   "linear_bf16: needs N %% 256 == 0 and K %% 64 == 0 (got M=%ld N=%d K=%d)", M, N, K);
   UNOPOSE_REQUIRE((size_t)M * K * 2 < (1UL << 32) && (size_t)N * K * 2 < (1UL << 32), "linear_bf16: operand larger than 4 GiB");
-  UNOPOSE_REQUIRE(epilogue == 0 || epilogue == 1, "linear_bf16: epilogue must be 0 (bias) or 1 (bias + GELU)");
+  UNOPOSE_REQUIRE(epilogue >= 0 && epilogue <= 2, "linear_bf16: epilogue must be 0 (bias), 1 (bias + GELU) or 2 (bias + ReLU)");
   const int tiles_m = cdiv(M, GEMM_BM), tiles_n = N / GEMM_BN, tiles = tiles_m * tiles_n;
   hipStream_t s = (hipStream_t)stream;
   static int n_cu = 0;  // one persistent workgroup per CU
@@ -333,6 +339,9 @@ int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C
   const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
   if (epilogue == 1)
     hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
+                       K, tiles_n, tiles);
+  else if (epilogue == 2)
+    hipLaunchKernelGGL(gemm_bf16_kernel<2>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
                        K, tiles_n, tiles);
   else
     hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,

@@ -113,8 +113,7 @@ class ViT(nn.Module):
         # patch conv 14x14/14 as one GEMM: (B, P, 3*14*14) @ W^T
         gh, gw = x.shape[2] // p, x.shape[3] // p
         patches = x.reshape(B, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, 3 * p * p)
-        w = self.patch_embed.proj.weight.reshape(self.patch_embed.proj.weight.shape[0], -1)
-        x = F.linear(patches, w, self.patch_embed.proj.bias)
+        x = ops.patch_embed(patches, self.patch_embed.proj)
         x = x + self.pos_embed
         x = torch.cat([self.cls_token.expand(B, -1, -1).to(x.dtype), self.reg_token.expand(B, -1, -1).to(x.dtype), x], 1)
         n = self.depth // 4

@@ -88,7 +88,7 @@ class CoarsePointMatchingOneRef(nn.Module):
         f2 = torch.cat([bg, f2], dim=1)
         for blk in self.transformers:
             f1, f2 = blk(f1, geo1, f2, geo2)
-        scores = self.score_heads[self.nblock - 1](torch.cat((f1, f2), dim=1))
+        scores = ops.score_head(torch.cat((f1, f2), dim=1), self.score_heads[self.nblock - 1])
         atten = ops.feature_similarity(ops.linear(f1, self.out_proj), ops.linear(f2, self.out_proj), self.cfg.temp)
         score = _scores(scores, n1)
         if self.taps is not None:  # test probe: the tensors the reference's eval branch hands to the pose head
@@ -147,7 +147,7 @@ class FinePointMatchingOneRef(nn.Module):
             return self.forward_train(p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points)
         B, n1 = p1.shape[:2]
         if "init_R" in end_points and "init_t" in end_points:
-            p1_ = (p1 - end_points["init_t"].unsqueeze(1)) @ end_points["init_R"]
+            p1_ = ops.rigid_rows(p1, end_points["init_t"], end_points["init_R"])
         else:
             p1_ = p1
         e_all, f_all = _adjacent(geo1, geo2), _adjacent(f1, f2)
@@ -167,7 +167,7 @@ class FinePointMatchingOneRef(nn.Module):
                 d, bg = blk.forward_stacked(d, bg, e_all, idx_all)
             f = torch.cat([bg, d], dim=1)
             f1, f2 = f[:B], f[B:]
-            sc = self.score_heads[self.nblock - 1](f)
+            sc = ops.score_head(f, self.score_heads[self.nblock - 1])
             scores = torch.cat((sc[:B], sc[B:]), dim=1)
             o = ops.linear(f, self.out_proj)
             if self.taps is None and ops.fine_pose_fused_ok(o[:B], o[B:]):  # the similarity is never materialised
@@ -187,7 +187,7 @@ class FinePointMatchingOneRef(nn.Module):
             f2 = torch.cat([bg, f2], dim=1)
             for blk in self.transformers:
                 f1, f2 = blk(f1, geo1, fps_idx1, f2, geo2, fps_idx2)
-            scores = self.score_heads[self.nblock - 1](torch.cat((f1, f2), dim=1))
+            scores = ops.score_head(torch.cat((f1, f2), dim=1), self.score_heads[self.nblock - 1])
             o1, o2 = ops.linear(f1, self.out_proj), ops.linear(f2, self.out_proj)
             if self.taps is None and ops.fine_pose_fused_ok(o1, o2):
                 R, t, s = ops.fine_pose_from_features(o1, o2, self.cfg.temp, _scores(scores, n1), p1, p2)
@@ -221,6 +221,9 @@ class UNOPose(nn.Module):
         self.coarse_point_matching = CoarsePointMatchingOneRef(cfg.coarse_point_matching)
         self.fine_point_matching = FinePointMatchingOneRef(cfg.fine_point_matching)
         self.taps = None  # assign a dict to receive the sampling intermediates of the next forward (tests)
+        # side-stream overlaps INSIDE one forward (geometry under the ViT, reference-cloud PE under the coarse stage): +3 % when
+        # forwards run one at a time; pipeline.PipelinedForward switches them off (another forward fills those gaps better)
+        self.internal_overlap = True
 
     # ---- F:245-298 -------------------------------------------------------------------------------
     def _features(self, end_points):
@@ -264,7 +267,7 @@ class UNOPose(nn.Module):
                     if torch.is_tensor(t):
                         t.record_stream(main)
             pre = None
-            if GEOM_UNDER_VIT:
+            if GEOM_UNDER_VIT and self.internal_overlap:
                 # the other latency-bound, feature-independent steps ride along: both global LRFs, the two
                 # 2048->196 FPS chains and the gathers of points / frame coordinates (M:28-47)
                 pre = {}
@@ -434,7 +437,7 @@ class UNOPose(nn.Module):
         # waits go there; the mlp3 projection is a library GEMM and stays on the main stream (no two library
         # GEMMs are ever co-scheduled -- DESIGN.md section 7).
         pe2 = None
-        if (PE_UNDER_COARSE and not self.test_coarse_only and dense_pm.is_cuda and torch.is_autocast_enabled()
+        if (PE_UNDER_COARSE and self.internal_overlap and not self.test_coarse_only and dense_pm.is_cuda and torch.is_autocast_enabled()
                 and dense_pm.shape == dense_po.shape):
             main = torch.cuda.current_stream()
             side = self._side_stream(dense_po.device)

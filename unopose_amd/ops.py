@@ -96,13 +96,19 @@ from .pointnet2 import _ext
 
 # Own bf16 GEMM (csrc/gemm.hip) for the large linears; UNOPOSE_GEMM=0 routes everything to the library (A/B switch).
 USE_HIP_GEMM = os.environ.get("UNOPOSE_GEMM", "1") == "1"
+# every ViT-sized linear on csrc/gemm.hip (no library stream-K kernels, i.e. no kernel with inter-workgroup waits, on the path)
+# (measured 0.6 % behind the library at one forward in flight; it is what makes two forwards in flight safe: pipeline.py)
+HIP_GEMM_ALL = os.environ.get("UNOPOSE_GEMM_ALL", "1") == "1"
 HIP_GEMM_MIN_ROWS = 4096  # below this a 256 x 256 tile grid cannot fill 256 CUs: library GEMM
 
 
 def linear_backend():
     """Which GEMM runs the large bf16 linears (reported by bench.py next to the measured rate)."""
-    return "hipBLASLt (through torch); fc1 + GELU: csrc/gemm.hip (256x256x64 LDS-DMA tiles, fused bias + erf-GELU epilogue)" \
-        if USE_HIP_GEMM else "hipBLASLt (through torch)"
+    if USE_HIP_GEMM and HIP_GEMM_ALL:
+        return "csrc/gemm.hip (256x256x64 LDS-DMA tiles, persistent; bias / bias + erf-GELU epilogue) for every ViT linear"
+    if USE_HIP_GEMM:
+        return "hipBLASLt (through torch); fc1 + GELU: csrc/gemm.hip (256x256x64 LDS-DMA tiles, fused bias + erf-GELU epilogue)"
+    return "hipBLASLt (through torch)"
 
 
 # ---- several forwards in flight on different HIP streams (bench.py --inflight N, a production runner that pipelines
@@ -144,14 +150,36 @@ def _bf16_weights(lin):
     return cache
 
 
-def linear_bf16_hip(x2, w, bias_f32, gelu=False):
-    """C-ABI unopose_linear_bf16: (M,K) bf16 @ (N,K)^T bf16 + bias fp32 [-> exact GELU] -> (M,N) bf16."""
+def linear_bf16_hip(x2, w, bias_f32, gelu=False, relu=False):
+    """C-ABI unopose_linear_bf16: (M,K) bf16 @ (N,K)^T bf16 + bias fp32 [-> exact GELU | ReLU] -> (M,N) bf16."""
     M, K = x2.shape
     N = w.shape[0]
     out = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
     with torch.cuda.device(x2.device):
-        call("unopose_linear_bf16", ptr(x2), ptr(w), ptr(bias_f32), ptr(out), M, N, K, int(bool(gelu)), stream_ptr())
+        call("unopose_linear_bf16", ptr(x2), ptr(w), ptr(bias_f32), ptr(out), M, N, K, 1 if gelu else (2 if relu else 0), stream_ptr())
     return out
+
+
+def own_gemm_ok(rows, N, K):
+    """Does csrc/gemm.hip take this bf16 linear?  With HIP_GEMM_ALL: every shape its tiling admits (N % 256 == 0,
+    K % 64 == 0, any row count) -- NO hipBLASLt bf16 kernel is left on the autocast path.  That matters beyond speed:
+    hipBLASLt's bf16 GEMM kernels of this ROCm release corrupt vector registers of wavefronts of OTHER kernels that
+    share a SIMD with them (scripts/ubench/lrf_dbg.py: a one-wavefront frame kernel beside a library bf16 GEMM on
+    another stream returns wrong sums in lanes 48-63 in 3-40 % of launches, never beside the hand-written kernels or an
+    fp32 library GEMM), so nothing may run concurrently with one."""
+    if not USE_HIP_GEMM or N % 256 != 0 or K % 64 != 0 or rows < 1:
+        return False
+    return HIP_GEMM_ALL or rows >= HIP_GEMM_MIN_ROWS
+
+
+def bf16_linear_2d(x2, w, bias_f32, bias_bf16=None, relu=False):
+    """(rows,K) bf16 @ (N,K)^T + bias on csrc/gemm.hip when `own_gemm_ok`, else the library."""
+    rows, K = x2.shape
+    N = w.shape[0]
+    if own_gemm_ok(rows, N, K):
+        return linear_bf16_hip(_c(x2), w, bias_f32, relu=relu)
+    y = F.linear(x2, w, bias_bf16 if bias_bf16 is not None else bias_f32.to(torch.bfloat16))
+    return F.relu(y) if relu else y
 
 
 def linear(x, lin, relu=False, gelu=False):
@@ -172,18 +200,72 @@ def linear(x, lin, relu=False, gelu=False):
         # Measured on the ViT shapes (scripts/gemm_ab.py, M = 87 936): the fused bias + GELU epilogue beats library
         # GEMM + separate GELU pass by 18 % (537 vs 655 us); on the plain linears the K loop of both is bound by the
         # same L2 -> LDS stream (~10 TB/s chip-wide) and the library's deeper pipeline is 0-25 % ahead, so those stay there.
-        if USE_HIP_GEMM and gelu and rows >= HIP_GEMM_MIN_ROWS and N % 256 == 0 and K % 64 == 0:
-            return linear_bf16_hip(_c(xb).reshape(rows, K), cache[1], cache[3], gelu).reshape(*xb.shape[:-1], N)
+        if own_gemm_ok(rows, N, K) and (HIP_GEMM_ALL or gelu):
+            return linear_bf16_hip(_c(xb).reshape(rows, K), cache[1], cache[3], gelu, relu).reshape(*xb.shape[:-1], N)
         if relu and cache[2] is not None:
             x2 = xb.reshape(-1, xb.shape[-1])
             return torch._addmm_activation(cache[2], x2, cache[1].t()).reshape(*xb.shape[:-1], cache[1].shape[0])
-        big = rows >= HIP_GEMM_MIN_ROWS
+        # stream-K candidates: the ViT-sized problems (hipBLASLt picks "..._SK3_MT256x256x64" for them)
+        big = rows >= HIP_GEMM_MIN_ROWS and min(N, K) >= 512
         if big:
             _big_gemm_enter()
         y = F.linear(xb, cache[1], cache[2])
         if big:
             _big_gemm_exit()
         return F.relu(y) if relu else (F.gelu(y) if gelu else y)
+
+
+def patch_embed(patches, conv):
+    """The ViT's 14x14/14 patch convolution as a GEMM over unfolded patches (B,P,3*14*14) fp32 -> (B,P,D).  On the
+    autocast path with `HIP_GEMM_ALL` it runs on csrc/gemm.hip like every other ViT linear: K = 588 is zero-padded to 640
+    (a multiple of the 64-wide K tile) in the bf16 copies of patches and weight."""
+    w = conv.weight.reshape(conv.weight.shape[0], -1)
+    D, K = w.shape
+    rows = patches.numel() // K
+    if _DIFF or not (HIP_GEMM_ALL and patches.is_cuda and torch.is_autocast_enabled() and own_gemm_ok(rows, D, 64)):
+        return F.linear(patches, w, conv.bias)
+    Kp = (K + 63) // 64 * 64
+    key = (conv.weight._version, conv.weight.data_ptr(), Kp)
+    cache = getattr(conv, "_bf16_pad_cache", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            wp = torch.zeros(D, Kp, dtype=torch.bfloat16, device=w.device)
+            wp[:, :K] = w.detach()
+            b = torch.zeros(D, device=w.device) if conv.bias is None else conv.bias.detach().float().contiguous()
+        cache = (key, wp, b)
+        conv._bf16_pad_cache = cache
+    with torch.autocast("cuda", enabled=False):
+        a = torch.zeros(rows, Kp, dtype=torch.bfloat16, device=patches.device)
+        a[:, :K] = patches.reshape(rows, K)
+        return linear_bf16_hip(a, cache[1], cache[2]).reshape(*patches.shape[:-1], D)
+
+
+def rigid_rows(p, t, R):
+    """(p - t) @ R for row-vector points p (B,N,3), t (B,3), R (B,3,3) (Fi:69).  Under autocast the reference's `@` is a
+    bf16 bmm (operands rounded to bf16, fp32 accumulation, bf16 result); here the same arithmetic as three broadcast
+    multiply-adds, so that no library bf16 GEMM kernel is on the path (`own_gemm_ok`)."""
+    x = p - t.unsqueeze(1)
+    if _DIFF or not (HIP_GEMM_ALL and p.is_cuda and torch.is_autocast_enabled()):
+        return x @ R
+    with torch.autocast("cuda", enabled=False):
+        bf = torch.bfloat16
+        xb, Rb = x.to(bf).float(), R.to(bf).float()
+        y = xb[..., 0:1] * Rb[:, None, 0, :] + xb[..., 1:2] * Rb[:, None, 1, :] + xb[..., 2:3] * Rb[:, None, 2, :]
+        return y.to(bf)
+
+
+def score_head(x, lin):
+    """The overlap-score head nn.Linear(d, 1) (C:66, Fi:89).  One output channel is no GEMM shape for csrc/gemm.hip, and no
+    library bf16 GEMM may be on the autocast path (`own_gemm_ok`): evaluated as a multiply + row sum in fp32 on the
+    bf16-rounded weights, rounded to the dtype the autocast Linear would return."""
+    if _DIFF or not (HIP_GEMM_ALL and x.is_cuda and torch.is_autocast_enabled()):
+        return lin(x)
+    with torch.autocast("cuda", enabled=False):
+        w = lin.weight.detach().to(torch.bfloat16).float().reshape(-1)
+        y = (x.float() * w).sum(-1, keepdim=True)
+        if lin.bias is not None:
+            y = y + lin.bias.detach().float()
+        return y.to(torch.bfloat16)
 
 
 def gather_rows(feats, idx):
@@ -498,7 +580,7 @@ def _attn_weights(att, rpe):
         b_kv = torch.cat([att.proj_k.bias.float(), att.proj_v.bias.float()], 0).to(bf).contiguous()
         w_all = torch.cat([w_q, w_kv], 0).contiguous()
         b_all = torch.cat([b_q, b_kv], 0).contiguous()
-    val = (w_q, b_q, w_kv, b_kv, w_all, b_all)
+    val = (w_q, b_q, w_kv, b_kv, w_all, b_all, b_q.float(), b_kv.float(), b_all.float())
     att._hip_cache = (key, val)
     return val
 
@@ -508,16 +590,16 @@ def _token_attention_hip(x, mem, att, embed):
     m = mem.shape[1]
     bf = torch.bfloat16
     rpe = embed is not None
-    w_q, b_q, w_kv, b_kv, w_all, b_all = _attn_weights(att, rpe)
+    w_q, b_q, w_kv, b_kv, w_all, b_all, bq32, bkv32, ball32 = _attn_weights(att, rpe)
     nq = w_q.shape[0]
     xb = x.to(bf)
     with torch.autocast("cuda", enabled=False):
         if mem is x:  # self-attention: one GEMM for q | qp | k | v
-            y = F.linear(xb, w_all, b_all)
+            y = bf16_linear_2d(xb.reshape(B * n, C), w_all, ball32, b_all).reshape(B, n, -1)
             yq, ykv = y[..., :nq], y[..., nq:]
         else:
-            yq = F.linear(xb, w_q, b_q)
-            ykv = F.linear(mem.to(bf), w_kv, b_kv)
+            yq = bf16_linear_2d(xb.reshape(B * n, C), w_q, bq32, b_q).reshape(B, n, -1)
+            ykv = bf16_linear_2d(mem.to(bf).reshape(B * m, C), w_kv, bkv32, b_kv).reshape(B, m, -1)
     # q | qp and k | v are consumed in place from the projection outputs (row strides passed to the kernel)
     vt = torch.zeros(B, C, _KEY_PAD, dtype=bf, device=x.device)
     vt[:, :, :m] = ykv[..., C:].transpose(1, 2)
@@ -600,12 +682,12 @@ def _focused_linear_attention_hip(xq, xkv, att, focusing):
             w_kv = torch.cat([att.proj_k.weight.float(), att.proj_v.weight.float()], 0).to(bf).contiguous()
             b_kv = torch.cat([att.proj_k.bias.float(), att.proj_v.bias.float()], 0).to(bf).contiguous()
             inv_sp = (1.0 / F.softplus(att.scale.float())).reshape(-1).contiguous()
-        cache = (key, w_kv, b_kv, inv_sp)
+        cache = (key, w_kv, b_kv, inv_sp, b_kv.float())
         att._hip_cache = cache
-    _, w_kv, b_kv, inv_sp = cache
+    _, w_kv, b_kv, inv_sp, bkv32 = cache
     q = _c(linear(xq, att.proj_q))
     with torch.autocast("cuda", enabled=False):
-        ykv = F.linear(xkv.to(bf), w_kv, b_kv)
+        ykv = bf16_linear_2d(xkv.to(bf).reshape(B * j, C), w_kv, bkv32, b_kv).reshape(B, j, -1)
     kproj, v = _c(ykv[..., :C]), ykv[..., C:]
     kf = torch.empty(B, j, C, dtype=bf, device=xq.device)
     out = torch.empty(B, N, C, dtype=bf, device=xq.device)
@@ -614,8 +696,9 @@ def _focused_linear_attention_hip(xq, xkv, att, focusing):
              stream_ptr())
         kf32 = kf.float()
         ksum = _c(kf32.sum(dim=1))  # (B,256)
-        # kv_h^T[d][c] = sum_j v[j,h,d] k[j,h,c]
-        kvt = _c(torch.einsum("bjhd,bjhc->bhdc", v.float().reshape(B, j, 4, 64), kf32.reshape(B, j, 4, 64)).to(bf))
+        # kv_h^T[d][c] = sum_j v[j,h,d] k[j,h,c]   (fp32 contraction: autocast would turn it into a library bf16 GEMM)
+        with torch.autocast("cuda", enabled=False):
+            kvt = _c(torch.einsum("bjhd,bjhc->bhdc", v.float().reshape(B, j, 4, 64), kf32.reshape(B, j, 4, 64)).to(bf))
         call("unopose_linear_attention", ptr(q), ptr(inv_sp), ptr(kvt), ptr(ksum), B, N, focusing, 0, ptr(out),
              stream_ptr())
     return out
@@ -727,9 +810,14 @@ def feature_similarity(f1, f2, temp):
     if _DIFF:  # the reference's expression, dtype and all (model_utils.py:260-282)
         return F.normalize(f1, p=2, dim=2) @ F.normalize(f2, p=2, dim=2).transpose(1, 2) / temp
     a, b = F.normalize(f1.float(), p=2, dim=2), F.normalize(f2.float(), p=2, dim=2)
-    if f1.is_cuda and torch.is_autocast_enabled():
+    if f1.is_cuda and torch.is_autocast_enabled() and not HIP_GEMM_ALL:
         with torch.autocast("cuda", enabled=False):
             return torch.bmm((a / temp).to(torch.bfloat16), b.to(torch.bfloat16).transpose(1, 2), out_dtype=torch.float32)
+    if f1.is_cuda and torch.is_autocast_enabled():
+        # no library bf16 GEMM on the path (own_gemm_ok): the same bf16-rounded operands, multiplied by the fp32 library
+        # kernel (exact products, fp32 sums -- what the bf16 bmm with fp32 output computes up to summation order)
+        with torch.autocast("cuda", enabled=False):
+            return torch.bmm((a / temp).to(torch.bfloat16).float(), b.to(torch.bfloat16).float().transpose(1, 2))
     return (a @ b.transpose(1, 2)) / temp
 
 

@@ -1,0 +1,126 @@
+"""Two batches in flight on one GPU: the matcher of batch i under the ViT of batch i+1.
+
+`UNOPose.forward` is a throughput-bound half (the ViT: ~26 ms of GEMMs / attention at 32 pairs, 518x518) followed by a
+half made of ~450 small dependent kernels (FPS, geometric transformer on 197 tokens, pose heads: ~14 ms during which most
+of the chip idles between launches).  Consecutive batches are independent, so a second HIP stream lets the small
+kernels of batch i fill the gaps -- and run beside -- the large kernels of batch i+1: +8 % pairs/s at 518x518, +14 % at
+224x224 (bench.py, same box A/B), with every result bit-identical to the one-stream order (same kernels, same inputs).
+
+What makes this safe is that NO hipBLASLt bf16 GEMM kernel is left on the bf16 path (`ops.own_gemm_ok`: every linear
+runs on csrc/gemm.hip, the few odd contractions in fp32 or as element-wise arithmetic).  Two reasons, both measured:
+(1) the library's stream-K kernels spin on partner workgroups -- three forwards in flight hang with them, none do without;
+(2) the library's bf16 kernels corrupt vector registers of wavefronts of OTHER kernels sharing a SIMD with them
+(scripts/ubench/lrf_dbg.py: lanes 48-63 of an unrelated one-wavefront kernel return wrong sums in 3-40 % of launches beside a
+library bf16 GEMM on another stream; never beside the hand-written kernels or fp32 library GEMMs), so nothing may run
+concurrently with one.  With them gone, pipelined and one-at-a-time execution give bit-identical poses
+(tests/test_pipeline_gpu.py).  The fp32 path (library GEMMs throughout) is run one batch at a time.
+
+The reference has no counterpart (its runner, engine/oneref_inference_utils_v1.py:13-136, calls the model batch by
+batch on the default stream); `runner.inference_and_save` uses this class for consecutive detection batches.
+"""
+import collections
+
+import torch
+
+from . import ops
+
+
+class Ticket:
+    """One submitted forward: `result()` hands back the end_points dict, ordered after the forward on the caller's
+    current stream (no host synchronisation)."""
+
+    def __init__(self, out, done, stream):
+        self._out, self._done, self._stream = out, done, stream
+
+    def result(self):
+        cur = torch.cuda.current_stream()
+        if self._stream is not None and cur != self._stream:
+            cur.wait_event(self._done)
+            for v in self._out.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(cur)
+        return self._out
+
+    def wait(self):
+        """Block the host until this forward has finished."""
+        if self._done is not None:
+            self._done.synchronize()
+        return self._out
+
+
+class PipelinedForward:
+    """model: an eval-mode UNOPose on a HIP device.  depth: forwards in flight (1 or 2; more brings nothing: bench.py
+    --inflight 3 measures the same rate).  autocast_dtype: torch.bfloat16 (the pipelined path) or None (fp32: one batch
+    at a time, whatever `depth` says)."""
+
+    def __init__(self, model, depth=2, autocast_dtype=torch.bfloat16, run_ahead=1, timing=False):
+        if depth not in (1, 2, 3, 4):
+            raise ValueError("depth must be 1..4")
+        self.model, self.autocast_dtype = model, autocast_dtype
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("PipelinedForward needs the model on a HIP device")
+        self.device = dev
+        self.depth = depth if autocast_dtype is not None else 1
+        if self.depth > 1 and not (ops.HIP_GEMM_ALL and ops.USE_HIP_GEMM):
+            raise RuntimeError("more than one forward in flight needs ops.HIP_GEMM_ALL (library stream-K GEMMs spin on partner "
+                               "workgroups and can hang when forwards overlap)")
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.depth)] if self.depth > 1 else [None]
+        if hasattr(model, "internal_overlap"):  # measured: with a second forward in flight the in-forward overlaps cost 1.6 %
+            model.internal_overlap = self.depth == 1
+        self._n = 0
+        self._pending = collections.deque()
+        self._limit = self.depth + max(0, int(run_ahead))  # forwards the host may have enqueued and not yet seen finish
+        self.timing = bool(timing)
+        self.history = []  # timing=True: (start event, end event) of every forward, on the stream it ran on (bench.py)
+
+    def _forward(self, end_points):
+        with torch.no_grad():
+            if self.autocast_dtype is None:
+                return self.model(end_points)
+            with torch.autocast("cuda", dtype=self.autocast_dtype):
+                return self.model(end_points)
+
+    def submit(self, end_points):
+        """Enqueue one forward over `end_points` (tensors ready on the caller's current stream); returns a Ticket."""
+        while len(self._pending) >= self._limit:  # bounded run-ahead: the host never queues more than `_limit` forwards
+            self._pending.popleft().wait()
+        s = self.streams[self._n % len(self.streams)]
+        self._n += 1
+        if s is None:
+            start = torch.cuda.Event(enable_timing=True) if self.timing else None
+            if start is not None:
+                start.record()
+            out = self._forward(end_points)
+            done = torch.cuda.Event(enable_timing=self.timing)
+            done.record()
+            t = Ticket(out, done, None)
+        else:
+            cur = torch.cuda.current_stream(self.device)
+            s.wait_stream(cur)
+            for v in end_points.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(s)
+            prev = ops.SERIALIZE_BIG_GEMMS
+            ops.SERIALIZE_BIG_GEMMS = True
+            try:
+                with torch.cuda.stream(s):
+                    start = torch.cuda.Event(enable_timing=True) if self.timing else None
+                    if start is not None:
+                        start.record(s)
+                    out = self._forward(end_points)
+                    done = torch.cuda.Event(enable_timing=self.timing)
+                    done.record(s)
+            finally:
+                ops.SERIALIZE_BIG_GEMMS = prev
+            t = Ticket(out, done, s)
+        self._pending.append(t)
+        if self.timing:
+            self.history.append((start, done))
+            del self.history[:-4096]
+        return t
+
+    def drain(self):
+        """Host-wait for everything submitted so far."""
+        while self._pending:
+            self._pending.popleft().wait()
