@@ -25,6 +25,8 @@ a_s = torch.randn(12608, 256, device="cuda").to(BF); w_s = torch.randn(256, 256,
 a_d = torch.randn(131136, 256, device="cuda").to(BF)
 a32 = torch.randn(8192, 768, device="cuda"); w32 = torch.randn(3072, 768, device="cuda")
 x32 = torch.randn(8192, 768, device="cuda"); ln = torch.nn.LayerNorm(768).cuda()
+a_d32 = a_d.float(); w_s32 = w_s.float(); f197 = torch.randn(64, 197, 256, device="cuda")
+kv_a = torch.randn(256, 64, 196, device="cuda"); kv_b = torch.randn(256, 196, 64, device="cuda")
 loads = {
     "nothing": lambda: None,
     "own gemm (csrc/gemm.hip)": lambda: ops.linear_bf16_hip(a, w, bias, True),
@@ -35,6 +37,9 @@ loads = {
     "hipBLASLt bf16 12608x256x512": lambda: F.linear(a_s, w_s2),
     "hipBLASLt bf16 131136x256x256": lambda: F.linear(a_d, w_s),
     "hipBLASLt fp32 8192x768x3072": lambda: F.linear(a32, w32),
+    "hipBLASLt fp32 131136x256x256 (PE mlp3)": lambda: F.linear(a_d32, w_s32),
+    "hipBLASLt fp32 bmm 64x197x197x256": lambda: torch.bmm(f197, f197.transpose(1, 2)),
+    "hipBLASLt fp32 bmm 256x64x196x64 (kv)": lambda: torch.bmm(kv_a, kv_b),
 }
 def runw(stream):
     out = torch.empty_like(pts)

@@ -87,3 +87,51 @@ def test_patch_embed_on_the_hand_written_gemm(model):
     e = (out.float() - ref).abs().max().item()
     print(f"patch embed vs fp32 conv: max err {e:.2e} (|ref| max {ref.abs().max().item():.2f})")
     assert e < 2 ** -6 * max(1.0, ref.abs().max().item())
+
+
+@torch.no_grad()
+def test_forward_is_reproducible_run_to_run(model):
+    """The same batch ten times, internal side-stream overlaps on: bit-identical outputs.  (Before every bf16 linear moved to
+    csrc/gemm.hip, the library's bf16 GEMM kernels running beside the side-stream geometry kernels perturbed the global
+    reference frames in about a quarter of such small-batch forwards: scripts/ubench/lrf_dbg.py.)"""
+    ep = batches(1)[0]
+    model.internal_overlap = True
+    outs = []
+    for _ in range(10):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            o = model(dict(ep))
+        outs.append({k: o[k].clone() for k in KEYS})
+    for o in outs[1:]:
+        for k in KEYS:
+            assert torch.equal(o[k], outs[0][k]), k
+
+
+@torch.no_grad()
+def test_runner_with_pipelined_chunks_writes_the_same_lines(model, tmp_path):
+    from unopose_amd.pipeline import PipelinedForward
+    from unopose_amd.runner import inference_and_save
+    from unopose_amd.synthetic import make_batch
+
+    images = []
+    for i in range(2):
+        ep, _, _ = make_batch(5, S=224, seed=70 + i, device="cuda")
+        img = {k: v[None] for k, v in ep.items()}
+        img.update(score=torch.full((1, 5, 1), 0.5 + 0.1 * i, device="cuda"), obj_id=torch.arange(1, 6, dtype=torch.int32).reshape(1, 5, 1),
+                   scene_id=torch.IntTensor([48]), img_id=torch.IntTensor([3 + i]))
+        images.append(img)
+
+    class Amp(torch.nn.Module):  # the runner calls model(inputs); the autocast region is the caller's
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, ep):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return self.m(ep)
+
+    torch.manual_seed(5)  # the coarse stage draws its hypotheses inside forward (U:462): same draws for both runs
+    a = inference_and_save(Amp(model), images, str(tmp_path / "a.csv"), instance_batch_size=2)
+    torch.manual_seed(5)
+    b = inference_and_save(Amp(model), images, str(tmp_path / "b.csv"), instance_batch_size=2, pipeline=PipelinedForward(model, depth=2))
+    strip = lambda lines: [",".join(l.split(",")[:-1]) for l in lines]  # noqa: E731  (the last field is the wall-clock time)
+    assert strip(a) == strip(b) and len(a) == 10

@@ -85,21 +85,26 @@ class ReferenceCache:
 
 
 @torch.no_grad()
-def run_image(model, data, instance_batch_size=16, device=None, ref_cache=None):
+def run_image(model, data, instance_batch_size=16, device=None, ref_cache=None, pipeline=None):
     """One image = data[key] with a leading image dim of 1 and n_instance instances (:36-100).
     With `ref_cache` (a ReferenceCache) and `data["ref_keys"]` (one hashable per instance) the reference
-    side of every pair comes from the cache."""
+    side of every pair comes from the cache.  With `pipeline` (a pipeline.PipelinedForward over `model`) the
+    instance chunks of the image are submitted back to back -- the matcher of one chunk runs under the ViT of the next --
+    and collected in order; the numbers are those of the chunk-by-chunk loop."""
     if device is not None:
         data = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in data.items()}
     n = data["pts"].size(1)
     Rs, ts, scores = [], [], []
+    pending = []
     for s in range(0, n, instance_batch_size):
         e = min(n, s + instance_batch_size)
         inputs = {k: data[k][0][s:e].contiguous() for k in _INPUT_KEYS if k in data}
         if ref_cache is not None and "ref_keys" in data:
             inputs.update(ref_cache.lookup(list(data["ref_keys"][s:e]), inputs["tem1_rgb"], inputs["tem1_choose"],
                                            inputs["tem1_pts"]))
-        out = model(inputs)
+        pending.append((s, e, pipeline.submit(inputs).result if pipeline is not None else (lambda o=model(inputs): o)))
+    for s, e, get in pending:
+        out = get()
         R, t = compose_pose(out["pred_R"], out["pred_t"],
                             data["tem1_pose"][0][s:e].contiguous() if "tem1_pose" in data else None)
         Rs.append(R)
@@ -112,7 +117,7 @@ def run_image(model, data, instance_batch_size=16, device=None, ref_cache=None):
 
 
 def inference_and_save(model, images, save_path, instance_batch_size=16, device=None, sync=None, ref_cache=None,
-                       dets=None):
+                       dets=None, pipeline=None):
     """`images`: an indexable of per-image dicts (the reference's test dataset items, batch dim 1).
     Every rank processes its InferenceSampler shard; rows are gathered to rank 0, which writes the CSV
     and the detections JSON in global image order.  Returns the CSV lines on rank 0, None elsewhere.
@@ -121,7 +126,7 @@ def inference_and_save(model, images, save_path, instance_batch_size=16, device=
     detections -- ``{"<scene:06d>_<img:06d>": [detection dict, ...]}``, every field kept, detections the
     provider filtered out included -- with ``pred_R`` (9 floats, row major) and ``pred_t`` (3 floats, mm) added
     to the entries ``inst_ids`` names.  `dets` defaults to ``images.dets`` (the provider's attribute, like
-    ``data_loader.dataset.dets``)."""
+    ``data_loader.dataset.dets``).  `pipeline`: see `run_image`."""
     from copy import deepcopy
 
     world = dist.get_world_size() if dist.is_initialized() else 1
@@ -135,7 +140,7 @@ def inference_and_save(model, images, save_path, instance_batch_size=16, device=
         if sync is not None:
             sync()
         t0 = time.perf_counter()
-        Rs, ts, scores = run_image(model, data, instance_batch_size, device, ref_cache)
+        Rs, ts, scores = run_image(model, data, instance_batch_size, device, ref_cache, pipeline)
         if sync is not None:
             sync()
         image_time = time.perf_counter() - t0
