@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--img", type=int, default=518,
@@ -399,17 +399,19 @@ def main():
     if args.dry_run:
         res["dry_run"] = True
     if pipe is not None:
-        # HIP events of every step: start / end on the stream it ran on.  `step_ms_hip_events` = intervals between the
-        # completions of consecutive steps (the throughput view: with one forward in flight this is the step time);
-        # `forward_latency_ms` = start -> end of one forward (longer than a step when two overlap).
+        # HIP events of every step: start / end on the stream it ran on.  `step_ms_hip_events` = time between the completions of
+        # steps i and i + depth (two consecutive steps of ONE stream), divided by depth: the per-step period of the pipeline
+        # (with one forward in flight: the step time).  `forward_latency_ms` = start -> end of one forward, which is longer than
+        # a step when two overlap.
         hist = pipe.history[tickets_from:]
         q = lambda v, f: v[min(len(v) - 1, int(round(f * (len(v) - 1))))]  # noqa: E731
-        gaps = sorted(hist[i][1].elapsed_time(hist[i + 1][1]) for i in range(len(hist) - 1))
+        d = pipe.depth
+        gaps = sorted(hist[i][1].elapsed_time(hist[i + d][1]) / d for i in range(len(hist) - d))
         lat = sorted(a.elapsed_time(b) for a, b in hist)
         if gaps:
             res["step_ms_hip_events"] = {"median": q(gaps, 0.5), "p10": q(gaps, 0.1), "p90": q(gaps, 0.9), "min": gaps[0], "max": gaps[-1],
                                          "pairs_per_s_at_median": world * B / q(gaps, 0.5) * 1e3,
-                                         "what": "interval between the completion events of consecutive steps"}
+                                         "what": "(completion of step i + depth) - (completion of step i), / depth"}
         res["forward_latency_ms"] = {"median": q(lat, 0.5), "p10": q(lat, 0.1), "p90": q(lat, 0.9)}
     if rank == 0 and world == 1 and not args.dry_run:
         if amp and not args.no_fp32 and graphed is None:

@@ -42,5 +42,19 @@ w = (torch.randn(3072, 768, device=dev) / 768 ** 0.5).bfloat16()
 bias = torch.randn(3072, device=dev)
 for _ in range(3):
     ops.linear_bf16_hip(a, w, bias, True)
+# the other three ViT linears on the same kernel (qkv, proj, fc2)
+for (K, N) in ((768, 2304), (768, 768), (3072, 768)):
+    a2 = torch.randn(2 * B * 1374, K, device=dev).bfloat16()
+    w2 = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
+    b2 = torch.randn(N, device=dev)
+    for _ in range(3):
+        ops.linear_bf16_hip(a2, w2, b2)
+# fine-stage assignment without the similarity matrix (B pairs, 2049 x 2049, 256-wide features)
+f1 = torch.randn(B, 2049, 256, device=dev)
+f2 = torch.randn(B, 2049, 256, device=dev)
+sc = torch.rand(B, 4096, device=dev)
+with torch.autocast("cuda", dtype=torch.bfloat16):
+    for _ in range(3):
+        ops.fine_pose_from_features(f1, f2, 0.1, sc, x, x)
 torch.cuda.synchronize()
 print("done")

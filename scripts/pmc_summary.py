@@ -6,7 +6,10 @@ import re
 import sys
 
 SHORT = ["token_attn_kernel<true", "vit_attn_kernel", "group_points_lds_kernel", "pe_group_mlp_max_bf16x3_kernel",
-         "ball_query_kernel", "geo_embed_kernel", "geo_knn_kernel", "gemm_bf16_kernel"]
+         "ball_query_kernel", "geo_embed_kernel", "geo_knn_kernel", "gemm_bf16_kernel<1", "gemm_bf16_kernel<0, false",
+         "fine_assign_kernel<0>", "fine_assign_kernel<1>", "fine_assign_kernel<2>"]
+# gemm_bf16_kernel<1>: fc1 + GELU (M = 87936, 768 -> 3072); gemm_bf16_kernel<0, false>: MEAN over the qkv / proj / fc2 launches of
+# scripts/pmc_kernels.py (three shapes, three launches each)
 
 
 def load(path):

@@ -22,6 +22,8 @@
 // the swept side (the background token) is the first element of tile 0; index 0 of the owning side belongs to nobody: its
 // statistics are the per-workgroup partial sums the other direction's pass 0 leaves behind plus the corner x_00, summed in
 // a fixed order by whoever needs them (deterministic: no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace unopose {
@@ -45,6 +47,7 @@ struct FAParams {
   float *w[2];             // (B, n[d] - 1) labels
   const float *pts2;       // (B, n[1] - 1, 3)
   float *weight, *pred;    // (B, n[0] - 1), (B, n[0] - 1, 3)
+  int old_grid;            // A/B switch (UNOPOSE_FA_OLD_GRID=1): block index fastest, as first written
 };
 
 __device__ __forceinline__ float fa_half_sum(float v) { return v + __shfl_xor(v, 32); }
@@ -56,7 +59,9 @@ template <int MODE>
 __global__ __launch_bounds__(512) void fine_assign_kernel(const FAParams p) {
   extern __shared__ __attribute__((aligned(1024))) char fa_smem[];
   const int dir = MODE == 0 ? (int)blockIdx.z : (MODE == 1 ? 1 : 0);
-  const int blk = blockIdx.x, b = blockIdx.y;
+  // grid.x = pair, grid.y = block: workgroup ids of one pair are B apart, i.e. (B % 8 == 0) on ONE XCD -- the 8 owners of a pair
+  // re-read the same swept side (1 MB) and share it in that XCD's L2 instead of fetching it 8 times (PMC: 601 -> MB per launch)
+  const int blk = p.old_grid ? blockIdx.x : blockIdx.y, b = p.old_grid ? blockIdx.y : blockIdx.x;
   if (blk >= p.nblk[dir]) return;
   const int NO = p.n[dir], NS = p.n[1 - dir];
   const u16 *own = p.f[dir] + (size_t)b * NO * FA_D;
@@ -248,7 +253,7 @@ int unopose_fine_assign(const void *f1, const void *f2, int B, int R, int C, int
                         void *stream) {
   UNOPOSE_REQUIRE(f1 && f2 && score1 && score2 && pts2 && ws && w1 && w2 && weight && pred, "fine_assign: null pointer");
   UNOPOSE_REQUIRE(D == FA_D, "fine_assign: feature width must be %d, got %d", FA_D, D);
-  UNOPOSE_REQUIRE(B >= 0 && B <= 65535 && R >= 2 && C >= 2 && R <= (1 << 20) && C <= (1 << 20), "fine_assign: bad sizes");
+  UNOPOSE_REQUIRE(B >= 0 && R >= 2 && C >= 2 && R <= (1 << 20) && C <= (1 << 20), "fine_assign: bad sizes");
   UNOPOSE_REQUIRE(shift >= 0.f && shift <= 40.f, "fine_assign: shift (1/temp) must lie in [0, 40] for exp(2 (x - shift)) to stay in fp32 range");
   if (B == 0) return UNOPOSE_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -281,9 +286,17 @@ int unopose_fine_assign(const void *f1, const void *f2, int B, int R, int C, int
     attr_set = true;
   }
   const int nb = p.nblk[0] > p.nblk[1] ? p.nblk[0] : p.nblk[1];
-  hipLaunchKernelGGL(fine_assign_kernel<0>, dim3(nb, B, 2), dim3(512), lds0, s, p);
-  hipLaunchKernelGGL(fine_assign_kernel<1>, dim3(p.nblk[1], B), dim3(512), lds1, s, p);
-  hipLaunchKernelGGL(fine_assign_kernel<2>, dim3(p.nblk[0], B), dim3(512), lds2, s, p);
+  static const int old_grid = getenv("UNOPOSE_FA_OLD_GRID") ? atoi(getenv("UNOPOSE_FA_OLD_GRID")) : 0;
+  p.old_grid = old_grid;
+  if (old_grid) {
+    hipLaunchKernelGGL(fine_assign_kernel<0>, dim3(nb, B, 2), dim3(512), lds0, s, p);
+    hipLaunchKernelGGL(fine_assign_kernel<1>, dim3(p.nblk[1], B), dim3(512), lds1, s, p);
+    hipLaunchKernelGGL(fine_assign_kernel<2>, dim3(p.nblk[0], B), dim3(512), lds2, s, p);
+    return check_launch("fine_assign");
+  }
+  hipLaunchKernelGGL(fine_assign_kernel<0>, dim3(B, nb, 2), dim3(512), lds0, s, p);
+  hipLaunchKernelGGL(fine_assign_kernel<1>, dim3(B, p.nblk[1]), dim3(512), lds1, s, p);
+  hipLaunchKernelGGL(fine_assign_kernel<2>, dim3(B, p.nblk[0]), dim3(512), lds2, s, p);
   return check_launch("fine_assign");
 }
 
