@@ -5,12 +5,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 NAMES = {10: "full (K rotation)", 12: "no MFMA", 13: "no fragment reads", 15: "DMA only, vmcnt(0) per tile... see 16",
          16: "placeholder"}
-NAMES = {410: "full", 416: "DMA only", 2410: "full, skew 2", 2416: "DMA only, skew 2", 4410: "full, skew 4", 4416: "DMA only, skew 4", 8410: "full, skew 8", 8416: "DMA only, skew 8"}
+NAMES = {4410: "full", 14410: "full, A tiles nt", 24410: "full, W tiles nt", 34410: "full, A and W nt"}
 def so(v): return os.path.join(HERE, f"_gemm_abl{v}.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     for v in NAMES:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-honor-nans",
-                               f"-DGEMM_ABL={v % 10}", f"-DGEMM_ROT={(v // 10) % 10}", f"-DGEMM_GM={max(1, (v // 100) % 10)}", f"-DGEMM_SKEW={v // 1000}", os.path.join(ROOT, "unopose_amd/csrc/gemm.hip"), os.path.join(ROOT, "unopose_amd/csrc/abi.hip"), "-o", so(v)])
+                               f"-DGEMM_ABL={v % 10}", f"-DGEMM_ROT={(v // 10) % 10}", f"-DGEMM_GM={max(1, (v // 100) % 10)}", f"-DGEMM_SKEW={(v // 1000) % 10}", f"-DGEMM_NT={v // 10000}", os.path.join(ROOT, "unopose_amd/csrc/gemm.hip"), os.path.join(ROOT, "unopose_amd/csrc/abi.hip"), "-o", so(v)])
     sys.exit(0)
 import torch
 torch.set_grad_enabled(False)
@@ -23,7 +23,7 @@ def timeit(f, n=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
 libs = {v: ctypes.CDLL(so(v)) for v in NAMES}
-for K, N in ((768, 2304), (3072, 768), (3072, 4096)):
+for K, N in ((768, 2304), (768, 768), (768, 3072), (3072, 768)):
     a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
     b = torch.randn(N, device="cuda"); out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -145,19 +145,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   // the LDS reads (it would otherwise drain the queue before every fragment read and every epilogue access); the waits
   // on DMA data are the explicit vmcnt + barrier pairs below.
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
-  auto dma16 = [&](uint32_t lds_byte, uint32_t vo, __amdgpu_buffer_rsrc_t rs, int so) {
+#ifndef GEMM_NT
+#define GEMM_NT 0  // experiment (scripts/ubench/gemm_abl.py): 1 = activation tiles loaded non-temporal, 2 = weight tiles, 3 = both
+#endif
+#define GEMM_DMA_ASM(MOD) "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen" MOD " lds\n\ts_mov_b32 m0, %0"
+  auto dma16 = [&](uint32_t lds_byte, uint32_t vo, __amdgpu_buffer_rsrc_t rs, int so, bool is_a) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(lds_byte), "v"(vo), "s"(rs), "s"(so)
-                 : "memory");
+    if ((GEMM_NT & 1) && is_a)
+      asm volatile(GEMM_DMA_ASM(" nt") : "=&s"(keep) : "s"(lds_byte), "v"(vo), "s"(rs), "s"(so) : "memory");
+    else if ((GEMM_NT & 2) && !is_a)
+      asm volatile(GEMM_DMA_ASM(" nt") : "=&s"(keep) : "s"(lds_byte), "v"(vo), "s"(rs), "s"(so) : "memory");
+    else
+      asm volatile(GEMM_DMA_ASM("") : "=&s"(keep) : "s"(lds_byte), "v"(vo), "s"(rs), "s"(so) : "memory");
   };
   auto stage_p = [&](const TileP &p, int buf, int kt, int i) {  // pieces i of A and W of K-tile kt (i = 0..3)
     kt += p.rot;
     if (kt >= nk_) kt -= nk_;
     const uint32_t la = lds0 + (uint32_t)(buf * GEMM_BUFBYTES + wave * 4096 + i * 1024);
-    dma16(la, p.a_off[i], a_rs, kt * (GEMM_BK * 2));
-    dma16(la + GEMM_OPBYTES, p.w_off[i], w_rs, kt * (GEMM_BK * 2));
+    dma16(la, p.a_off[i], a_rs, kt * (GEMM_BK * 2), true);
+    dma16(la + GEMM_OPBYTES, p.w_off[i], w_rs, kt * (GEMM_BK * 2), false);
   };
   // Cross-tile prefetch: the first K-tile of the NEXT tile is put in flight (into buffer 0) right after the last K-tile
   // of this one, so its DMA latency runs under the epilogue (bias / GELU / stores), which stages C through buffer 1 only.
