@@ -42,6 +42,9 @@ def parse(argv=None):
                          "round-robin over this many HIP streams; a step is still one forward over one batch, and the "
                          "latency-bound matcher of one batch runs underneath the ViT of the next.  1 = one stream.  The "
                          "fp32 path always runs one at a time")
+    ap.add_argument("--stages", default="auto", choices=["auto", "0", "1"],
+                    help="PipelinedForward(stages=...): 1 = ViT half and matcher half of every forward on two streams, 0 = whole "
+                         "forwards side by side, auto = by ViT size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the extra fp32 (reference default precision) leg")
@@ -326,7 +329,8 @@ def main():
     if not args.dry_run and graphed is None:
         from unopose_amd.pipeline import PipelinedForward
 
-        pipe = PipelinedForward(model, depth=args.inflight if amp else 1, autocast_dtype=torch.bfloat16 if amp else None, timing=True)
+        pipe = PipelinedForward(model, depth=args.inflight if amp else 1, autocast_dtype=torch.bfloat16 if amp else None, timing=True,
+                                stages="auto" if args.stages == "auto" else bool(int(args.stages)))
         args.inflight = pipe.depth
 
     def step(use_amp=amp):
@@ -393,6 +397,7 @@ def main():
                    "sharding": f"dp{world} (independent pairs, weights broadcast, poses gathered)"},
         "launch": "hipGraph replay" if graphed is not None else "eager",
         "forwards_in_flight": args.inflight,
+        "pipeline": None if pipe is None or pipe.depth == 1 else ("ViT half of step i+1 beside the matcher half of step i (two streams)" if pipe.stages is True else "two whole forwards side by side (two streams)"),
         "sanity": {"median_rot_err_vs_gt": rot_err.median().item(),
                    "frac_pairs_solved(<0.05)": (rot_err < 0.05).float().mean().item()},
     }

@@ -32,13 +32,15 @@ def batches(n, B=3):
 
 
 @torch.no_grad()
-def test_two_in_flight_equals_one_at_a_time(model):
+@pytest.mark.parametrize("stages", [False, True])
+def test_two_in_flight_equals_one_at_a_time(model, stages):
+    """stages=False: two whole forwards side by side; stages=True: ViT half and matcher half on two streams."""
     from unopose_amd.pipeline import PipelinedForward
 
     eps = batches(6)
     seq = PipelinedForward(model, depth=1)
     ref = [{k: seq.submit(dict(ep)).wait()[k].clone() for k in KEYS} for ep in eps]
-    pipe = PipelinedForward(model, depth=2, timing=True)
+    pipe = PipelinedForward(model, depth=2, timing=True, stages=stages)
     assert pipe.depth == 2 and len(pipe.streams) == 2
     tickets = [pipe.submit(dict(ep)) for ep in eps]
     for i in (3, 0, 5, 1, 4, 2):  # results may be collected in any order
@@ -47,6 +49,7 @@ def test_two_in_flight_equals_one_at_a_time(model):
             assert torch.equal(out[k], ref[i][k]), (i, k)
     pipe.drain()
     torch.cuda.synchronize()
+    assert pipe.stages is stages
     assert len(pipe.history) == 6 and all(a.elapsed_time(b) > 0 for a, b in pipe.history)
 
 

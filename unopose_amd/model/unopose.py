@@ -383,7 +383,16 @@ class UNOPose(nn.Module):
         if self.training:
             with ops.differentiable():
                 return self.forward_train(end_points)
-        dense_pm, dense_fm, dense_po, dense_fo, radius, pre = self._features(end_points)
+        return self.forward_matching(end_points, self.forward_features(end_points))
+
+    def forward_features(self, end_points):
+        """First half of the eval forward: the ViT over both crops, the 5000 -> 2048 FPS and the pixel features (a9, a10, a21).
+        `pipeline.PipelinedForward` runs the two halves of consecutive batches on different HIP streams."""
+        return self._features(end_points)
+
+    def forward_matching(self, end_points, feats):
+        """Second half: coarse + fine matching on what `forward_features` returned."""
+        dense_pm, dense_fm, dense_po, dense_fo, radius, pre = feats
         if pre is not None:
             return self._forward_from(pre, end_points, dense_pm, dense_fm, dense_po, dense_fo, radius)
         dense_pm_lrf = ops.lrf_global(end_points["pts"], self.use_ref_rad)

@@ -53,7 +53,7 @@ class PipelinedForward:
     --inflight 3 measures the same rate).  autocast_dtype: torch.bfloat16 (the pipelined path) or None (fp32: one batch
     at a time, whatever `depth` says)."""
 
-    def __init__(self, model, depth=2, autocast_dtype=torch.bfloat16, run_ahead=1, timing=False):
+    def __init__(self, model, depth=2, autocast_dtype=torch.bfloat16, run_ahead=1, timing=False, stages="auto"):
         if depth not in (1, 2, 3, 4):
             raise ValueError("depth must be 1..4")
         self.model, self.autocast_dtype = model, autocast_dtype
@@ -71,6 +71,13 @@ class PipelinedForward:
         self._n = 0
         self._pending = collections.deque()
         self._limit = self.depth + max(0, int(run_ahead))  # forwards the host may have enqueued and not yet seen finish
+        # stages: every forward is cut in two -- `forward_features` (the ViT) on one stream, `forward_matching` on a second,
+        # high-priority one -- so that ViTs never overlap each other and the latency-bound matcher of batch i always runs
+        # beside the ViT of batch i + 1, instead of two whole forwards advancing side by side.  Measured (same box, pairs/s):
+        # 518 x 518 crops 861 vs 832, 224 x 224 crops 1988 vs 2086 (there the matcher outlasts the ViT) -> "auto" cuts the
+        # forward when the ViT sees >= 1024 tokens.  The in-forward side-stream overlaps stay on in this mode (+1.5 %).
+        self.stages = stages if self.depth > 1 and hasattr(model, "forward_features") else False
+        self._stage_streams = None
         self.timing = bool(timing)
         self.history = []  # timing=True: (start event, end event) of every forward, on the stream it ran on (bench.py)
 
@@ -87,7 +94,16 @@ class PipelinedForward:
             self._pending.popleft().wait()
         s = self.streams[self._n % len(self.streams)]
         self._n += 1
-        if s is None:
+        if self.stages == "auto":
+            rgb = end_points.get("rgb")
+            self.stages = bool(torch.is_tensor(rgb) and (rgb.shape[-1] // 14) * (rgb.shape[-2] // 14) + 5 >= 1024)
+        if self.stages:
+            if self._stage_streams is None:
+                self._stage_streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device, priority=-1)]
+                if hasattr(self.model, "internal_overlap"):
+                    self.model.internal_overlap = True
+            t, start, done = self._submit_stages(end_points)
+        elif s is None:
             start = torch.cuda.Event(enable_timing=True) if self.timing else None
             if start is not None:
                 start.record()
@@ -115,10 +131,38 @@ class PipelinedForward:
                 ops.SERIALIZE_BIG_GEMMS = prev
             t = Ticket(out, done, s)
         self._pending.append(t)
-        if self.timing:
+        if self.timing and start is not None:
             self.history.append((start, done))
             del self.history[:-4096]
         return t
+
+    def _submit_stages(self, end_points):
+        sv, st = self._stage_streams
+        cur = torch.cuda.current_stream(self.device)
+        sv.wait_stream(cur)
+        for v in end_points.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(sv)
+                v.record_stream(st)
+        ac = (lambda: torch.autocast("cuda", dtype=self.autocast_dtype))
+        with torch.no_grad():
+            with torch.cuda.stream(sv), ac():
+                start = torch.cuda.Event(enable_timing=True) if self.timing else None
+                if start is not None:
+                    start.record(sv)
+                feats = self.model.forward_features(end_points)
+                ready = torch.cuda.Event()
+                ready.record(sv)
+            flat = list(feats[:5]) + (list(feats[5].values()) if isinstance(feats[5], dict) else [])
+            for v in flat:
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(st)
+            with torch.cuda.stream(st), ac():
+                st.wait_event(ready)
+                out = self.model.forward_matching(end_points, feats)
+                done = torch.cuda.Event(enable_timing=self.timing)
+                done.record(st)
+        return Ticket(out, done, st), start, done
 
     def drain(self):
         """Host-wait for everything submitted so far."""
