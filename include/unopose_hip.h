@@ -326,15 +326,6 @@ int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C
                         int epilogue, unopose_stream_t stream);
 int unopose_gemm_bf16_tile(void);
 
-/* Fused tail of a post-LN transformer layer (core/unopose/model/transformer.py:151-193, d_model 256):
- *   r = LN1(h Wl^T + bl + x);  out = LN2(r + relu(r We^T + be) Ws^T + bs)
- * h (attention core output), x (layer input), out: (rows,256) bfloat16; Wl (256,256), We (512,256),
- * Ws (256,512) bfloat16 row-major [out][in]; biases and LayerNorm parameters float32. */
-int unopose_transformer_tail(const void *h, const void *x, long rows, const void *Wl, const float *bl,
-                             const float *ln1w, const float *ln1b, const void *We, const float *be,
-                             const void *Ws, const float *bs, const float *ln2w, const float *ln2b,
-                             float eps, void *out, unopose_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

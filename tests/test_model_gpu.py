@@ -392,24 +392,6 @@ def test_fused_linear_attention_kernel(model):
     assert e.mean().item() / scale < 2e-2 and e.max().item() / scale < 0.5, (e.mean().item(), e.max().item(), scale)
 
 
-@torch.no_grad()
-@pytest.mark.parametrize("rows", [197 * 3, 2048 * 2 + 5])
-def test_fused_transformer_tail_kernel(model, rows):
-    """Fused linear+residual+LN+FFN+residual+LN (bf16 MFMA) vs the fp32 module math."""
-    from unopose_amd import ops
-
-    g = torch.Generator().manual_seed(rows)
-    layer = model.coarse_point_matching.transformers[1].layers[1]
-    h = torch.randn(1, rows, 256, generator=g).cuda()
-    x = torch.randn(1, rows, 256, generator=g).cuda()
-    hb, xb = h.bfloat16().float(), x.bfloat16().float()
-    a = layer.attention
-    r = a.norm(a.linear(hb) + xb)
-    ref = layer.output(r)
-    out = ops.transformer_tail(h, x, layer)
-    assert out.dtype == torch.bfloat16 and out.shape == ref.shape
-    e = (out.float() - ref).abs()
-    assert e.max().item() < 6e-2 and e.mean().item() < 6e-3, (e.max().item(), e.mean().item())
 
 
 @torch.no_grad()

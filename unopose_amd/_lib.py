@@ -57,7 +57,6 @@ SIGNATURES = {
     "unopose_linear_attention_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "unopose_linear_bf16": [_P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P],
     "unopose_gemm_bf16_tile": [],
-    "unopose_transformer_tail": [_P, _P, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P],
     "unopose_pe_image_bytes": [],
     "unopose_pe_pack_weights": [_P, _P, _P, _P, _P, _P, _P, _P],
     "unopose_pe_group_mlp_max_packed": [_P, _I, _I, _F, _I, _P, _P, _P],

@@ -305,8 +305,6 @@ class TransformerLayer(nn.Module):
             mem = x
         h = ops.token_attention(x, mem, a.attention, self.heads, embed)
         if x.is_cuda and not ops.is_differentiable():
-            if ops.USE_FUSED_TAIL and torch.is_autocast_enabled() and x.shape[-1] == 256:
-                return ops.transformer_tail(h, x, self)
             x = ops.add_layernorm(ops.linear(h, a.linear), x, a.norm)
         else:
             x = a.norm(a.linear(h) + x)
@@ -385,8 +383,6 @@ class LinearTransformerLayer(nn.Module):
         a = self.attention
         h = ops.focused_linear_attention(x, mem, a.attention, self.heads, self.focusing_factor)
         if x.is_cuda and not ops.is_differentiable():
-            if ops.USE_FUSED_TAIL and torch.is_autocast_enabled() and x.shape[-1] == 256:
-                return ops.transformer_tail(h, x, self)
             x = ops.add_layernorm(ops.linear(h, a.linear), x, a.norm)
         else:
             x = a.norm(a.linear(h) + x)

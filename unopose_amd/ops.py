@@ -1029,41 +1029,6 @@ def scale_residual_(x, y, gamma):
     return x
 
 
-# The single-kernel transformer tail (csrc/tail.hip) is correct and 1.2-2.2x faster than the GEMM-library
-# path when timed alone (host-launch-bound), but at B=32 the GPU is the bottleneck and its GPU time is
-# higher (68 us vs ~41 us of kernels for 6304 rows: 50 workgroups cannot fill 256 CUs and each walks a
-# 20-step weight-chunk chain), so it is opt-in (measured: 1129 vs 1150 pairs/s).  See DESIGN.md section 8.
-USE_FUSED_TAIL = os.environ.get("UNOPOSE_FUSED_TAIL", "0") == "1"
-
-
-def transformer_tail(h, x, layer):
-    """Everything after the attention core of a (RPE/cross/linear) transformer layer in ONE HIP kernel
-    (csrc/tail.hip): out = LN2(r + FFN(r)), r = LN1(linear(h) + x).  `layer` has .attention.linear,
-    .attention.norm, .output.{expand,squeeze,norm} (transformer.py:151-193).  bf16 in / out."""
-    bf = torch.bfloat16
-    a, o = layer.attention, layer.output
-    key = (a.linear.weight._version, o.expand.weight._version, o.squeeze.weight._version, a.linear.weight.data_ptr())
-    cache = getattr(layer, "_tail_cache", None)
-    if cache is None or cache[0] != key:
-        with torch.no_grad():
-            f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
-            cache = (key, a.linear.weight.detach().to(bf).contiguous(), f32(a.linear.bias), f32(a.norm.weight),
-                     f32(a.norm.bias), o.expand.weight.detach().to(bf).contiguous(), f32(o.expand.bias),
-                     o.squeeze.weight.detach().to(bf).contiguous(), f32(o.squeeze.bias), f32(o.norm.weight),
-                     f32(o.norm.bias))
-        layer._tail_cache = cache
-    _, wl, bl, l1w, l1b, we, be, ws, bs, l2w, l2b = cache
-    assert wl.shape == (256, 256) and we.shape == (512, 256) and ws.shape == (256, 512)
-    h = _c(h.to(bf))
-    x = _c(x.to(bf))
-    rows = h.numel() // 256
-    out = torch.empty_like(h)
-    with torch.cuda.device(h.device):
-        call("unopose_transformer_tail", ptr(h), ptr(x), rows, ptr(wl), ptr(bl), ptr(l1w), ptr(l1b), ptr(we), ptr(be),
-             ptr(ws), ptr(bs), ptr(l2w), ptr(l2b), float(a.norm.eps), ptr(out), stream_ptr())
-    return out
-
-
 def scale_residual_layernorm_(x, y, gamma, norm):
     """x (fp32) += gamma * y (bf16) in place; returns LayerNorm(x) in bf16 -- one pass over the residual stream."""
     assert x.dtype == torch.float32 and x.is_contiguous() and y.dtype == torch.bfloat16
