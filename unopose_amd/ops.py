@@ -87,7 +87,6 @@ def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
 # hypotheses) is moved into hand-written HIP kernels one by one -- each function
 # below names its current implementation.
 # =============================================================================
-import math
 
 import torch.nn.functional as F
 

@@ -25,7 +25,6 @@ Third-party pieces the reference calls that this image lacks are restated here:
   * imageio -> Pillow.
 """
 import json
-import os
 import os.path as osp
 
 import numpy as np
