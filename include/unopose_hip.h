@@ -197,6 +197,13 @@ int unopose_fine_correspondences(const float *atten, int B, int R, int C, const 
 int unopose_upproj_plan(const long long *choose, int B2, int Np, int H, int W, int side, int tok_offset, int tok_stride,
                         int cap_rows, int *ws, int *row_list, int *cellmap, int *tile_info, unopose_stream_t stream);
 
+/* C = LayerNorm(A W^T + bias + resid) * ln_w + ln_b for 256-wide layers (N = 256 = one tile: a row's statistics stay inside the
+ * workgroup): the output projection / FFN squeeze of the matcher's transformer layers with the residual add and the post-LN
+ * (core/unopose/model/transformer.py:151-193) in the GEMM epilogue, on the fp32 accumulators.  A (M,K), W (256,K), resid and C
+ * (M,256) bfloat16; bias, ln_w, ln_b float32 (256). */
+int unopose_linear_add_layernorm_bf16(const void *A, const void *W, const float *bias, const void *resid, const float *ln_w,
+                                      const float *ln_b, float eps, void *C, long M, int K, unopose_stream_t stream);
+
 /* Row-gathered grouped form of linear_bf16: C[r] = A[row_list[r]] . W[g(r)*256 .. +255]^T + bias, g(r) = the group of r's tile
  * (tile_info as written by upproj_plan; N / 256 groups).  A (M,K), W (N,K), C (max_tiles * 256, 256) bf16; bias fp32 (N).
  * The tile count is read on the device. */

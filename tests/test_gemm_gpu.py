@@ -56,3 +56,33 @@ def test_vit_mlp_fused_gelu_path_is_taken_and_matches():
     ref = F.gelu(x.bfloat16().float() @ lin.weight.bfloat16().float().t() + lin.bias.float())
     err = (y.float() - ref).abs()
     assert y.dtype == torch.bfloat16 and (err <= ref.abs() * 2.0 ** -8 + 1e-3).all()
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("M,K", [(197 * 64, 256), (131136, 512), (300, 256), (1, 64)])
+def test_linear_add_layernorm_epilogue(M, K):
+    """LayerNorm(lin(h) + x) in the GEMM epilogue (256-wide) vs an fp32 reference of the op and vs the two-launch form."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(M + K)
+    lin = torch.nn.Linear(K, 256).cuda()
+    ln = torch.nn.LayerNorm(256).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(256, generator=g) + 0.5)
+        ln.bias.copy_(torch.randn(256, generator=g))
+    h = (torch.randn(M, K, generator=g) * 2).bfloat16().cuda()
+    x = (torch.randn(M, 256, generator=g) * 3).bfloat16().cuda()
+    ref = F.layer_norm(h.float() @ lin.weight.bfloat16().float().t() + lin.bias.float() + x.float(), (256,), ln.weight, ln.bias, ln.eps)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = ops.linear_add_layernorm(h, lin, x, ln)
+        ops.USE_FUSED_LINEAR_LN = False
+        try:
+            two = ops.linear_add_layernorm(h, lin, x, ln)
+        finally:
+            ops.USE_FUSED_LINEAR_LN = True
+    assert out.dtype == torch.bfloat16 and out.shape == (M, 256)
+    e = (out.float() - ref).abs()
+    assert (e <= ref.abs() * 2.0 ** -8 + 2e-3).all(), e.max().item()
+    # the two-launch form rounds lin(h) to bf16 before the add: it is the less accurate of the two
+    assert (two.float() - ref).abs().max().item() >= e.max().item() * 0.5
+    assert (out.float() - two.float()).abs().max().item() < 0.1

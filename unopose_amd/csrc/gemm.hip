@@ -63,15 +63,25 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // GATHER (grouped, row-gathered form; unopose_linear_bf16_gather): output row r of tile t is A row row_list[256 t + r]
 // times the 256-row weight block of the group tile t belongs to (tile_info[1 + g] = first tile of group g, g = 0..N/256;
 // tile_info[0] = number of tiles, read on the device: the host never learns it); C is (tiles * 256, 256).
-template <int EPI, bool GATHER = false>  // EPI 0: bias; 1: bias + exact GELU; 2: bias + ReLU
+// EPI 3 (N == 256 only: a row is one tile wide): C = LayerNorm(A W^T + bias + resid) * ln_w + ln_b, the post-LN glue of the
+// matcher's transformer layers (transformer.py:151-193) -- the residual add and the LayerNorm run on the fp32 accumulators.
+template <int EPI, bool GATHER = false>  // EPI 0: bias; 1: bias + exact GELU; 2: bias + ReLU; 3: bias + residual + LayerNorm
 __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict__ A, const u16 *__restrict__ W,
                                                            const float *__restrict__ bias, u16 *__restrict__ C, int M,
                                                            int N, int K, int tiles_n, int tiles_arg,
                                                            const int *__restrict__ row_list = nullptr,
-                                                           const int *__restrict__ tile_info = nullptr) {
+                                                           const int *__restrict__ tile_info = nullptr,
+                                                           const u16 *__restrict__ resid = nullptr, const float *__restrict__ ln_w = nullptr,
+                                                           const float *__restrict__ ln_b = nullptr, float ln_eps = 0.f) {
   const int tiles = GATHER ? __builtin_amdgcn_readfirstlane(tile_info[0]) : tiles_arg;
   __shared__ __attribute__((aligned(1024))) char smem[2 * GEMM_BUFBYTES];
   __shared__ __attribute__((aligned(16))) float bias_lds[GEMM_BN];  // this tile's bias slice (LDS reads: no vmcnt traffic in the epilogue)
+  __shared__ __attribute__((aligned(16))) float lnw_lds[EPI == 3 ? GEMM_BN : 4], lnb_lds[EPI == 3 ? GEMM_BN : 4];
+  __shared__ float2 ln_part[EPI == 3 ? 2 * 4 * 32 * 4 : 1];  // [wm][mb][row][wn]: (sum, sum of squares) of 64 columns
+  if (EPI == 3 && threadIdx.x < GEMM_BN) {  // visible after the first barrier of the tile loop
+    lnw_lds[threadIdx.x] = ln_w[threadIdx.x];
+    lnb_lds[threadIdx.x] = ln_b[threadIdx.x];
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
 #undef GEMM_STEP
 
   // ---- next tile's first K-tile in flight under this tile's epilogue
-  const bool more = can_prefetch && ti + nslots < chunk_len;
+  const bool more = EPI != 3 && can_prefetch && ti + nslots < chunk_len;  // (EPI 3: the LayerNorm epilogue needs the registers)
   TileP nxt;
   float4 nxt_bv;
   if (more) {
@@ -258,6 +268,55 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
     nxt_bv = *reinterpret_cast<const float4 *>(bias + nxt.n0 + lane * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) stage_p(nxt, 0, 0, i);
+  }
+  if (EPI == 3) {
+    // v = acc + bias + residual; row statistics across the 4 column waves through LDS; normalise in place
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int m = min(m0 + wm * 128 + mb * 32 + l31, M - 1);
+      const u16 *rp = resid + (size_t)m * GEMM_BN + wn * 64 + 4 * hi;
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = nb * 32 + 8 * g + 4 * hi;
+          const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + wn * 64 + nl);
+          const uint2 r = *reinterpret_cast<const uint2 *>(rp + nb * 32 + 8 * g);
+          const float v0 = acc[nb][mb][4 * g + 0] + bv.x + __uint_as_float(r.x << 16);
+          const float v1 = acc[nb][mb][4 * g + 1] + bv.y + __uint_as_float(r.x & 0xffff0000u);
+          const float v2 = acc[nb][mb][4 * g + 2] + bv.z + __uint_as_float(r.y << 16);
+          const float v3 = acc[nb][mb][4 * g + 3] + bv.w + __uint_as_float(r.y & 0xffff0000u);
+          acc[nb][mb][4 * g + 0] = v0;
+          acc[nb][mb][4 * g + 1] = v1;
+          acc[nb][mb][4 * g + 2] = v2;
+          acc[nb][mb][4 * g + 3] = v3;
+          a1 += (v0 + v1) + (v2 + v3);
+          a2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+        }
+      a1 += __shfl_xor(a1, 32);  // lanes l31 and l31 + 32 hold complementary columns of the same row
+      a2 += __shfl_xor(a2, 32);
+      if (hi == 0) ln_part[((wm * 4 + mb) * 32 + l31) * 4 + wn] = make_float2(a1, a2);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const float2 *pp = ln_part + ((wm * 4 + mb) * 32 + l31) * 4;
+      const float t1 = (pp[0].x + pp[1].x) + (pp[2].x + pp[3].x), t2 = (pp[0].y + pp[1].y) + (pp[2].y + pp[3].y);
+      const float mean = t1 * (1.f / GEMM_BN);
+      const float rstd = rsqrtf(fmaxf(t2 * (1.f / GEMM_BN) - mean * mean, 0.f) + ln_eps);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = wn * 64 + nb * 32 + 8 * g + 4 * hi;
+          const float4 gw = *reinterpret_cast<const float4 *>(lnw_lds + nl), gb = *reinterpret_cast<const float4 *>(lnb_lds + nl);
+          acc[nb][mb][4 * g + 0] = (acc[nb][mb][4 * g + 0] - mean) * rstd * gw.x + gb.x;
+          acc[nb][mb][4 * g + 1] = (acc[nb][mb][4 * g + 1] - mean) * rstd * gw.y + gb.y;
+          acc[nb][mb][4 * g + 2] = (acc[nb][mb][4 * g + 2] - mean) * rstd * gw.z + gb.z;
+          acc[nb][mb][4 * g + 3] = (acc[nb][mb][4 * g + 3] - mean) * rstd * gw.w + gb.w;
+        }
+    }
   }
   // ---- epilogue: acc[nb][mb][4g + e] = C[m = wm*128 + mb*32 + l31][n = wn*64 + nb*32 + 8g + 4hi + e]
   //      two passes of 64 rows per wave through buffer 1 (8 KiB per wave, 16-byte slots XOR-swizzled by row)
@@ -270,7 +329,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int nl = nb * 32 + 8 * g + 4 * hi;  // local column of the 4 values
-        const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + wn * 64 + nl);
+        const float4 bv = EPI == 3 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(bias_lds + wn * 64 + nl);
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
           const int mb = ps * 2 + mh;
@@ -353,6 +412,25 @@ int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C
     hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
                        K, tiles_n, tiles);
   return check_launch("linear_bf16");
+}
+
+int unopose_linear_add_layernorm_bf16(const void *A, const void *W, const float *bias, const void *resid, const float *ln_w,
+                                      const float *ln_b, float eps, void *C, long M, int K, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(A && W && bias && resid && ln_w && ln_b && C, "linear_add_layernorm_bf16: null pointer");
+  UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && K >= GEMM_BK && K % GEMM_BK == 0, "linear_add_layernorm_bf16: needs K %% 64 == 0 (got M=%ld K=%d)", M, K);
+  UNOPOSE_REQUIRE((size_t)M * K * 2 < (1UL << 32), "linear_add_layernorm_bf16: operand larger than 4 GiB");
+  const int tiles = cdiv(M, GEMM_BM);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8)
+      cu = 256;
+    n_cu = cu & ~7;
+  }
+  const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
+  hipLaunchKernelGGL((gemm_bf16_kernel<3, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, (const u16 *)A, (const u16 *)W, bias,
+                     (u16 *)C, (int)M, GEMM_BN, K, 1, tiles, (const int *)nullptr, (const int *)nullptr, (const u16 *)resid, ln_w, ln_b, eps);
+  return check_launch("linear_add_layernorm_bf16");
 }
 
 int unopose_linear_bf16_gather(const void *A, long M, int K, const void *W, int N, const float *bias, const int *row_list,

@@ -284,10 +284,9 @@ class _AttentionOutput(nn.Module):
         self.norm = nn.LayerNorm(d)
 
     def forward(self, x):
-        y = ops.linear(ops.linear(x, self.expand, relu=True), self.squeeze)
-        if x.is_cuda and not ops.is_differentiable():
-            return ops.add_layernorm(x, y, self.norm)  # one pass (csrc/fused.hip); bf16 out under autocast
-        return self.norm(x + y)
+        if x.is_cuda and not ops.is_differentiable():  # squeeze + residual + LayerNorm: one launch under autocast
+            return ops.linear_add_layernorm(ops.linear(x, self.expand, relu=True), self.squeeze, x, self.norm)
+        return self.norm(x + self.squeeze(F.relu(self.expand(x))))
 
 
 class TransformerLayer(nn.Module):
@@ -305,7 +304,7 @@ class TransformerLayer(nn.Module):
             mem = x
         h = ops.token_attention(x, mem, a.attention, self.heads, embed)
         if x.is_cuda and not ops.is_differentiable():
-            x = ops.add_layernorm(ops.linear(h, a.linear), x, a.norm)
+            x = ops.linear_add_layernorm(h, a.linear, x, a.norm)
         else:
             x = a.norm(a.linear(h) + x)
         return self.output(x)
@@ -383,7 +382,7 @@ class LinearTransformerLayer(nn.Module):
         a = self.attention
         h = ops.focused_linear_attention(x, mem, a.attention, self.heads, self.focusing_factor)
         if x.is_cuda and not ops.is_differentiable():
-            x = ops.add_layernorm(ops.linear(h, a.linear), x, a.norm)
+            x = ops.linear_add_layernorm(h, a.linear, x, a.norm)
         else:
             x = a.norm(a.linear(h) + x)
         return self.output(x)

@@ -214,6 +214,29 @@ def linear(x, lin, relu=False, gelu=False):
         return F.relu(y) if relu else (F.gelu(y) if gelu else y)
 
 
+USE_FUSED_LINEAR_LN = os.environ.get("UNOPOSE_FUSED_LINEAR_LN", "1") == "1"  # A/B switch
+
+
+def linear_add_layernorm(h, lin, x, norm):
+    """LayerNorm(lin(h) + x): the post-LN glue after an attention output projection / FFN squeeze (transformer.py:151-193).
+    256-wide layers under autocast run as ONE launch -- residual add and LayerNorm in the epilogue of csrc/gemm.hip, on the
+    fp32 accumulators (the unfused form rounds lin(h) to bf16 first); everything else: add_layernorm(linear(h), x)."""
+    N, K = lin.weight.shape
+    rows = h.numel() // K
+    if (USE_FUSED_LINEAR_LN and not _DIFF and h.is_cuda and torch.is_autocast_enabled() and HIP_GEMM_ALL and N == 256
+            and own_gemm_ok(rows, N, K) and tuple(norm.normalized_shape) == (256,) and norm.weight is not None and lin.bias is not None):
+        cache = _bf16_weights(lin)
+        with torch.autocast("cuda", enabled=False):
+            hb = _c(h if h.dtype == torch.bfloat16 else h.to(torch.bfloat16)).reshape(rows, K)
+            xb = _c(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)).reshape(rows, N)
+            out = torch.empty(rows, N, dtype=torch.bfloat16, device=h.device)
+            with torch.cuda.device(h.device):
+                call("unopose_linear_add_layernorm_bf16", ptr(hb), ptr(cache[1]), ptr(cache[3]), ptr(xb), ptr(norm.weight.detach()),
+                     ptr(norm.bias.detach()), float(norm.eps), ptr(out), rows, K, stream_ptr())
+        return out.reshape(*h.shape[:-1], N)
+    return add_layernorm(linear(h, lin), x, norm)
+
+
 def patch_embed(patches, conv):
     """The ViT's 14x14/14 patch convolution as a GEMM over unfolded patches (B,P,3*14*14) fp32 -> (B,P,D).  On the
     autocast path with `HIP_GEMM_ALL` it runs on csrc/gemm.hip like every other ViT linear: K = 588 is zero-padded to 640
