@@ -138,3 +138,61 @@ def test_runner_with_pipelined_chunks_writes_the_same_lines(model, tmp_path):
     b = inference_and_save(Amp(model), images, str(tmp_path / "b.csv"), instance_batch_size=2, pipeline=PipelinedForward(model, depth=2))
     strip = lambda lines: [",".join(l.split(",")[:-1]) for l in lines]  # noqa: E731  (the last field is the wall-clock time)
     assert strip(a) == strip(b) and len(a) == 10
+
+
+@torch.no_grad()
+def test_no_library_bf16_gemm_on_the_autocast_path(model):
+    """Regression guard for DESIGN.md section 7 (library bf16 GEMM kernels corrupt registers of kernels running beside them):
+    during an eval forward under autocast no torch matmul-class op may run on bf16 data -- i.e. be called with autocast
+    enabled (which casts fp32 operands to bf16) or with bf16 operands.  fp32 contractions inside autocast-disabled regions
+    are allowed (PE mlp3, coarse similarity, the linear attention's k^T v)."""
+    import torch.nn.functional as F
+
+    offenders = []
+    patched = []
+
+    def guard(owner, name):
+        orig = getattr(owner, name)
+
+        def wrapper(*a, **k):
+            ts = [t for t in a if torch.is_tensor(t)]
+            if ts and ts[0].is_cuda and ts[0].is_floating_point() and min(t.dim() for t in ts[:2]) >= 1:
+                if torch.is_autocast_enabled() or any(t.dtype == torch.bfloat16 for t in ts[:2]):
+                    offenders.append((name, [tuple(t.shape) for t in ts[:2]], [str(t.dtype) for t in ts[:2]], torch.is_autocast_enabled()))
+            return orig(*a, **k)
+
+        setattr(owner, name, wrapper)
+        patched.append((owner, name, orig))
+
+    for owner, name in ((torch, "matmul"), (torch, "bmm"), (torch, "mm"), (torch, "addmm"), (torch, "baddbmm"), (torch, "einsum"),
+                        (torch, "_addmm_activation"), (F, "linear"), (torch.Tensor, "__matmul__"), (torch.Tensor, "matmul")):
+        guard(owner, name)
+    lin_forward = torch.nn.Linear.forward
+
+    def linear_forward(self, x):
+        if x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16):
+            offenders.append(("nn.Linear.forward", tuple(x.shape), str(x.dtype), torch.is_autocast_enabled()))
+        return lin_forward(self, x)
+
+    torch.nn.Linear.forward = linear_forward
+    from unopose_amd import ops
+
+    try:
+        ep = batches(1, B=2)[0]
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            model(dict(ep))
+        clean = list(offenders)
+        del offenders[:]
+        ops.HIP_GEMM_ALL = False  # the guard itself: with the library path switched back on it must fire
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                model(dict(ep))
+        finally:
+            ops.HIP_GEMM_ALL = True
+        fired = len(offenders)
+    finally:
+        torch.nn.Linear.forward = lin_forward
+        for owner, name, orig in patched:
+            setattr(owner, name, orig)
+    assert not clean, clean[:5]
+    assert fired > 20
