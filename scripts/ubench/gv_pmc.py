@@ -1,0 +1,15 @@
+"""Run ONE gemm_var.py build (argv[1] = name, argv[2] = shape name) a few times: target of rocprofv3 --pmc passes."""
+import ctypes, os, sys
+import torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+SH = {"qkv": (768, 2304, 0), "proj": (768, 768, 0), "fc1": (768, 3072, 1), "fc2": (3072, 768, 0)}
+K, N, epi = SH[sys.argv[2]]
+L = ctypes.CDLL(os.path.join(HERE, f"_gv_{sys.argv[1]}.so"))
+M = 64 * 1374
+a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
+b = torch.randn(N, device="cuda"); out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+fn = L.unopose_linear_bf16
+fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+for _ in range(4):
+    fn(a.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, epi, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+torch.cuda.synchronize()

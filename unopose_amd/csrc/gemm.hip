@@ -39,6 +39,49 @@ typedef unsigned short u16;
 #define GEMM_SKEW 4  // tiles sharing a panel start 0..SKEW-1 K-tiles apart
 #endif
 #endif
+#ifndef GEMM_EABL
+#define GEMM_EABL 0  // epilogue ablations: 1 = no global stores, 2 = no epilogue at all (accumulators kept live)
+#endif
+#ifndef GEMM_CNT
+#define GEMM_CNT 0  // 1 = non-temporal C stores
+#endif
+#ifndef GEMM_PHASE
+#define GEMM_PHASE 1  // phase groups per XCD (workgroups of group g start g * GEMM_PHASE_TICKS x 10 ns late)
+#endif
+#ifndef GEMM_PHASE_TICKS
+#define GEMM_PHASE_TICKS 1400
+#endif
+#ifndef GEMM_SAME
+#define GEMM_SAME 0  // probe: every tile streams the operands of tile (0, 0) -- an all-hit L2 stream under the full K loop
+#endif
+#ifndef GEMM_STAMP
+#define GEMM_STAMP 0
+#endif
+#ifndef GEMM_STAMP_BLOCK
+#define GEMM_STAMP_BLOCK 16
+#endif
+#if GEMM_STAMP
+__device__ unsigned long long g_stamps[8 * 64 * 4];
+extern "C" int unopose_gemm_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
+#endif
+#ifndef GEMM_PACE
+#define GEMM_PACE 0
+#endif
+#ifndef GEMM_YPOS
+#define GEMM_YPOS 0  // waves 4-7 issue their DMA burst after MFMA group 1 / 2 instead of group 0 (complementary phases on a SIMD)
+#endif
+#ifndef GEMM_SPEC
+#define GEMM_SPEC 0  // 1: waves 4-7 (the later-dispatched wave of every SIMD) issue ALL the LDS-DMA, waves 0-3 none
+#endif
+#ifndef GEMM_ROTATE
+#define GEMM_ROTATE 0
+#endif
+#ifndef GEMM_PRIO
+#define GEMM_PRIO 0  // 1: static s_setprio 1 for waves 4-7 (the later-dispatched half)
+#endif
+#ifndef GEMM_BURST
+#define GEMM_BURST 0  // 1: all 8 DMA pieces of the next K-tile right after the barrier; 2: in the first two MFMA groups
+#endif
 #define GEMM_BM 256
 #define GEMM_BN 256
 #define GEMM_BK 64
@@ -68,7 +111,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 template <int EPI, bool GATHER = false>  // EPI 0: bias; 1: bias + exact GELU; 2: bias + ReLU; 3: bias + residual + LayerNorm
 __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict__ A, const u16 *__restrict__ W,
                                                            const float *__restrict__ bias, u16 *__restrict__ C, int M,
-                                                           int N, int K, int tiles_n, int tiles_arg,
+                                                           int N, int K, int tiles_n, int tiles_arg, int cgn,
                                                            const int *__restrict__ row_list = nullptr,
                                                            const int *__restrict__ tile_info = nullptr,
                                                            const u16 *__restrict__ resid = nullptr, const float *__restrict__ ln_w = nullptr,
@@ -84,6 +127,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  if (GEMM_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   const int l31 = lane & 31, hi = lane >> 5;
   // ---- persistent, lock-stepped tile walk.  The grid is ONE workgroup per CU (gridDim.x <= 256, a multiple of 8;
   // 128 KiB of LDS admits one per CU).  Workgroup b sits on XCD b % 8 (observed dispatch rule: a SPEED assumption
@@ -93,10 +137,26 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   // output that shares GEMM_GM A panels and 32/GEMM_GM W panels K-slice by K-slice in that XCD's L2.  (With one
   // workgroup per tile in dispatch order the resident tiles drift apart in K and the L2 -> LDS stream runs at half
   // the rate: scripts/ubench/gemm_abl.py)
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, nslots0 = gridDim.x >> 3;
+  const bool phased = GEMM_PHASE > 1 && EPI != 3 && !GATHER && nslots0 % GEMM_PHASE == 0 && tiles >= 2 * (int)gridDim.x;
+  const int nph = phased ? GEMM_PHASE : 1;
+  const int pg = slot0 % nph, slot = slot0 / nph, nslots = nslots0 / nph;
+  if (phased && pg > 0) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)(pg * GEMM_PHASE_TICKS)) __builtin_amdgcn_s_sleep(64);
+  }
   const int cq = tiles >> 3, cr = tiles & 7;
-  const int chunk_base = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, chunk_len = cq + (xcd < cr ? 1 : 0);
   const int tiles_m = tiles / tiles_n, per_group = GEMM_GM * tiles_n;
+  // cgn > 0: "resident W" schedule.  XCD x owns a contiguous range of ROW panels and sweeps it once per column group
+  // (cgn groups of <= ceil(tiles_n / cgn) column tiles whose W panels together fit the XCD's L2 with room to spare); inside
+  // a sweep the tiles in flight form patches of gme row panels x the group's columns, and every row panel of a patch walks
+  // K from a different rotation: a W line is then touched gme times per round (reuse distance = W_sub + A_round / gme < L2)
+  // and stays resident under LRU, while an A line is used by the row's column tiles within a few K-tiles and dies.
+  const int rq = tiles_m >> 3, rr8 = tiles_m & 7;
+  const int row_lo = xcd < rr8 ? xcd * (rq + 1) : rr8 * (rq + 1) + (xcd - rr8) * rq, nrows = rq + (xcd < rr8 ? 1 : 0);
+  const bool resident = !GATHER && cgn > 0;
+  const int chunk_base = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+  const int chunk_len = resident ? nrows * tiles_n : cq + (xcd < cr ? 1 : 0);
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, (int)((size_t)M * K * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, (int)((size_t)N * K * 2), 0x00020000);
   const int nk_ = K / GEMM_BK;
@@ -117,13 +177,29 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   };
   auto tile_params = [&](int ti, int step, TileP &p) {
     const int t = chunk_base + ti;
-    int tn, tm;
+    int tn, tm, rot_res = 0;
     if (GATHER) {
       tm = t;
       tn = 0;
       const int ng = N / GEMM_BN;
       for (int g = 1; g < ng; ++g) tn += t >= tile_info[1 + g] ? 1 : 0;  // the group of tile t (uniform scalar loads)
       tn = __builtin_amdgcn_readfirstlane(tn);
+    } else if (resident) {
+      const int cgq = tiles_n / cgn, cgr = tiles_n % cgn;
+      int rem = ti, c_lo = 0, ncol = 1;
+      for (int g = 0; g < cgn; ++g) {  // the column group of sequence position ti (cgn <= 4)
+        ncol = cgq + (g < cgr ? 1 : 0);
+        if (rem < nrows * ncol || g == cgn - 1) break;
+        rem -= nrows * ncol;
+        c_lo += ncol;
+      }
+      const int gme = max(1, (nslots0 + ncol / 2) / ncol);  // rows per patch: patch ~ the tiles the XCD has in flight
+      const int pgr = gme * ncol, mg = rem / pgr, rr = rem - mg * pgr;
+      const int gm = min(gme, nrows - mg * gme);
+      const int tcol = rr / gm, trow = rr - tcol * gm;
+      tn = c_lo + tcol;
+      tm = row_lo + mg * gme + trow;
+      rot_res = (xcd * 5 + (trow * nk_) / gm + tcol % (GEMM_SKEW > 1 ? GEMM_SKEW : 1)) % nk_;
     } else {
       // tile order: groups of GEMM_GM row panels, column tiles fastest across the group
       const int mg = t / per_group, rr = t - mg * per_group;
@@ -137,19 +213,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
     // VGPR, K-tile offset in an SGPR; rows past M (ragged last tile) fall outside the descriptor -> zeros
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = wave * 32 + i * 8 + (lane >> 3);
+      const int row = ((GEMM_SPEC && !GATHER) ? (wave & 3) : wave) * 32 + i * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((row >> 1) & 7);
-      int arow = (GEMM_ABL == 7 ? 0 : p.m0) + row;  // ABL 7: every tile streams tile (0, 0)
+      int arow = ((GEMM_ABL == 7 || GEMM_SAME) ? 0 : p.m0) + row;  // ABL 7: every tile streams tile (0, 0)
       if (GATHER) arow = max(row_list[p.m0 + row], 0);  // padding rows of a group (-1) compute on row 0; nobody reads them
       p.a_off[i] = (uint32_t)(((size_t)arow * K + c * 8) * 2);
-      p.w_off[i] = (uint32_t)(((size_t)((GEMM_ABL == 7 ? 0 : p.n0) + row) * K + c * 8) * 2);
+      p.w_off[i] = (uint32_t)(((size_t)(((GEMM_ABL == 7 || GEMM_SAME) ? 0 : p.n0) + row) * K + c * 8) * 2);
     }
     // K-tile rotation, uniform over the tiles an XCD runs together (they must stay on the same K-slice to share it) and
     // different between XCDs / steps: the chip as a whole touches different 128-byte columns at any instant.
     // GEMM_SKEW: tiles sharing a panel start 0..SKEW-1 K-tiles apart, so a K-slice one of them has fetched is RESIDENT in L2
     // when the others ask for it (requests for a line still in flight do not merge into one fetch)
     const int skew = ((tm & 3) + tn) % (GEMM_SKEW > 1 ? GEMM_SKEW : 1);
-    p.rot = __builtin_amdgcn_readfirstlane(GEMM_ROT ? (xcd * 5 + step * 3 + skew) % nk_ : 0);
+    p.rot = __builtin_amdgcn_readfirstlane(resident ? rot_res : GEMM_ROT ? (xcd * 5 + step * 3 + skew) % nk_ : 0);
   };
   // The DMA is issued from inline asm: the compiler does not see an LDS write and so keeps its own s_waitcnt vmcnt out of
   // the LDS reads (it would otherwise drain the queue before every fragment read and every epilogue access); the waits
@@ -171,9 +247,47 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   auto stage_p = [&](const TileP &p, int buf, int kt, int i) {  // pieces i of A and W of K-tile kt (i = 0..3)
     kt += p.rot;
     if (kt >= nk_) kt -= nk_;
+    if (GEMM_SPEC && !GATHER) {
+      // waves 4-7 stage the rows of waves w - 4 and w (128 rows apart: the second half through the scalar offset)
+      if (wave >= 4) {
+        const uint32_t la = lds0 + (uint32_t)(buf * GEMM_BUFBYTES + (wave & 3) * 4096 + i * 1024);
+        const int hs = 128 * K * 2;
+        dma16(la, p.a_off[i], a_rs, kt * (GEMM_BK * 2), true);
+        dma16(la + GEMM_OPBYTES, p.w_off[i], w_rs, kt * (GEMM_BK * 2), false);
+        dma16(la + 4 * 4096, p.a_off[i], a_rs, kt * (GEMM_BK * 2) + hs, true);
+        dma16(la + 4 * 4096 + GEMM_OPBYTES, p.w_off[i], w_rs, kt * (GEMM_BK * 2) + hs, false);
+      }
+      return;
+    }
     const uint32_t la = lds0 + (uint32_t)(buf * GEMM_BUFBYTES + wave * 4096 + i * 1024);
     dma16(la, p.a_off[i], a_rs, kt * (GEMM_BK * 2), true);
     dma16(la + GEMM_OPBYTES, p.w_off[i], w_rs, kt * (GEMM_BK * 2), false);
+  };
+  // four pieces (consecutive KiB of one operand's image) from ONE M0 setting: the instruction's 12-bit offset moves the LDS
+  // destination AND the source address, so the per-lane source offsets are taken relative to it (vo[i] - 1024 i >= 0: row >= 8 i)
+  auto dma4 = [&](uint32_t lds_byte, const uint32_t (&vo)[4], __amdgpu_buffer_rsrc_t rs, int so) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %6, %7 offen lds\n\t"
+                 "buffer_load_dwordx4 %3, %6, %7 offen offset:1024 lds\n\t"
+                 "buffer_load_dwordx4 %4, %6, %7 offen offset:2048 lds\n\t"
+                 "buffer_load_dwordx4 %5, %6, %7 offen offset:3072 lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(vo[0]), "v"(vo[1] - 1024u), "v"(vo[2] - 2048u), "v"(vo[3] - 3072u), "s"(rs), "s"(so) : "memory");
+  };
+  auto stage_all = [&](const TileP &p, int buf, int kt) {
+    kt += p.rot;
+    if (kt >= nk_) kt -= nk_;
+    const uint32_t la = lds0 + (uint32_t)(buf * GEMM_BUFBYTES + wave * 4096);
+    dma4(la, p.a_off, a_rs, kt * (GEMM_BK * 2));
+    dma4(la + GEMM_OPBYTES, p.w_off, w_rs, kt * (GEMM_BK * 2));
+  };
+  auto stage_piece = [&](const TileP &p, int buf, int kt, int pc) {  // piece pc of K-tile kt: 0..3 = A pieces, 4..7 = W pieces
+    kt += p.rot;
+    if (kt >= nk_) kt -= nk_;
+    const uint32_t la = lds0 + (uint32_t)(buf * GEMM_BUFBYTES + wave * 4096 + (pc & 3) * 1024);
+    if (pc < 4) dma16(la, p.a_off[pc & 3], a_rs, kt * (GEMM_BK * 2), true);
+    else dma16(la + GEMM_OPBYTES, p.w_off[pc & 3], w_rs, kt * (GEMM_BK * 2), false);
   };
   // Cross-tile prefetch: the first K-tile of the NEXT tile is put in flight (into buffer 0) right after the last K-tile
   // of this one, so its DMA latency runs under the epilogue (bias / GELU / stores), which stages C through buffer 1 only.
@@ -182,7 +296,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   TileP cur;
   float4 cur_bv;  // bias[n0 + 4 lane ..] of the tile (every wave loads it: no branch, no early wait; wave 0 publishes it)
   bool have = false;
-  for (int ti = slot, step = 0; ti < chunk_len; ti += nslots, ++step) {
+  for (int ti = pg * nslots + slot, step = 0; ti < chunk_len; ti += nph * nslots, ++step) {
   if (!have) {
     tile_params(ti, step, cur);
     cur_bv = *reinterpret_cast<const float4 *>(bias + cur.n0 + lane * 4);
@@ -223,7 +337,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
     if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[0], acc[0][0], 0, 0, 0);            \
     if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[1], acc[0][1], 0, 0, 0);            \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    if (MORE && GEMM_ABL != 1) stage1(buf ^ 1, kt + 1, (KS));                                          \
+    if (MORE && GEMM_ABL != 1 && GEMM_BURST == 0) stage1(buf ^ 1, kt + 1, (KS));                                          \
+    if (MORE && GEMM_BURST == 1 && (KS) == 0) { stage1(buf ^ 1, kt + 1, 0); stage1(buf ^ 1, kt + 1, 1); stage1(buf ^ 1, kt + 1, 2); stage1(buf ^ 1, kt + 1, 3); } \
+    if (MORE && GEMM_BURST == 2 && (KS) < 2) { stage1(buf ^ 1, kt + 1, 2 * (KS)); stage1(buf ^ 1, kt + 1, 2 * (KS) + 1); } \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[2], acc[0][2], 0, 0, 0);            \
     if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], AC[3], acc[0][3], 0, 0, 0);            \
@@ -232,6 +348,93 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
     if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[2], acc[1][2], 0, 0, 0);            \
     if (GEMM_ABL != 2 && GEMM_ABL < 5) acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], AC[3], acc[1][3], 0, 0, 0);            \
     __builtin_amdgcn_sched_barrier(0);
+#if GEMM_ROTATE
+  // Rotated software pipeline: the last MFMA group (k-substep 3) of K-tile t is issued AFTER the barrier that ends the tile,
+  // behind the fragment reads of K-tile t+1's substep 0 -- the matrix pipe restarts right at the barrier release while those
+  // reads are in flight.  (Every wave's reads of tile t are complete before the barrier: lgkmcnt(0) in front of it.)
+  // GEMM_PACE = E > 0: the wave's 8 LDS-DMA pieces of the next K-tile are issued ONE at a time, after every E-th MFMA, from
+  // a wave-dependent offset: the CU's texture-address path moves 64 B / clk (16 clk per 1-KiB piece, 64 pieces per K-tile),
+  // so a burst of pieces blocks the issuing waves -- in order, in front of their MFMAs -- for hundreds of cycles.
+#define GEMM_MF1(M, WC, AC, NB, MB)                                                                   \
+    acc[NB][MB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[NB], AC[MB], acc[NB][MB], 0, 0, 0);      \
+    if (GEMM_PACE > 0 && more_k && (M) % GEMM_PACE == 0 && (M) / GEMM_PACE < 8) {                      \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+      if (dma_off == 0) stage_piece(cur, buf ^ 1, kt + 1, (M) / GEMM_PACE);                           \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+    }                                                                                                \
+    if (GEMM_PACE > 1 && more_k && (M) % GEMM_PACE == 1 && (M) / GEMM_PACE < 8) {                      \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+      if (dma_off == 1) stage_piece(cur, buf ^ 1, kt + 1, (M) / GEMM_PACE);                           \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+    }                                                                                                \
+    if (GEMM_PACE > 2 && more_k && (M) % GEMM_PACE == 2 && (M) / GEMM_PACE < 8) {                      \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+      if (dma_off == 2) stage_piece(cur, buf ^ 1, kt + 1, (M) / GEMM_PACE);                           \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+    }                                                                                                \
+    if (GEMM_PACE > 3 && more_k && (M) % GEMM_PACE == 3 && (M) / GEMM_PACE < 8) {                      \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+      if (dma_off == 3) stage_piece(cur, buf ^ 1, kt + 1, (M) / GEMM_PACE);                           \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
+#define GEMM_MF8(M0, WC, AC)                                                                         \
+    GEMM_MF1((M0) + 0, WC, AC, 0, 0) GEMM_MF1((M0) + 1, WC, AC, 0, 1) GEMM_MF1((M0) + 2, WC, AC, 0, 2) GEMM_MF1((M0) + 3, WC, AC, 0, 3) \
+    GEMM_MF1((M0) + 4, WC, AC, 1, 0) GEMM_MF1((M0) + 5, WC, AC, 1, 1) GEMM_MF1((M0) + 6, WC, AC, 1, 2) GEMM_MF1((M0) + 7, WC, AC, 1, 3)
+  const int dma_off = GEMM_PACE > 0 ? __builtin_amdgcn_readfirstlane(((wave & 3) + (wave >> 2) * (GEMM_PACE / 2)) % GEMM_PACE) : 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const char *lb = smem + buf * GEMM_BUFBYTES;
+    const bool more_k = kt + 1 < nk;
+    // (entry: fragments of substep 0 of this tile are being read into set 0; set 1 holds substep 3 of the previous tile)
+    if (kt > 0) { GEMM_MF8(0, wf1, af1) }
+    else if (GEMM_PACE > 0 && more_k) {  // first K-tile of the tile: no pending group -- its share of the pieces goes out at once
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        if (m % GEMM_PACE == dma_off && m / GEMM_PACE < 8) stage_piece(cur, buf ^ 1, kt + 1, m / GEMM_PACE);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more_k && GEMM_PACE == 0 && (GEMM_YPOS == 0 || wave < 4)) {
+      if (GEMM_BURST == 3) stage_all(cur, buf ^ 1, kt + 1);
+      else if (GEMM_BURST == 1) { stage1(buf ^ 1, kt + 1, 0); stage1(buf ^ 1, kt + 1, 1); stage1(buf ^ 1, kt + 1, 2); stage1(buf ^ 1, kt + 1, 3); }
+      else { stage1(buf ^ 1, kt + 1, 0); stage1(buf ^ 1, kt + 1, 1); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(lb, 1, wf1, af1);
+    __builtin_amdgcn_sched_barrier(0);
+    GEMM_MF8(8, wf0, af0)
+    __builtin_amdgcn_sched_barrier(0);
+    if (more_k && GEMM_YPOS == 1 && wave >= 4) { stage1(buf ^ 1, kt + 1, 0); stage1(buf ^ 1, kt + 1, 1); stage1(buf ^ 1, kt + 1, 2); stage1(buf ^ 1, kt + 1, 3); }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more_k && GEMM_PACE == 0 && GEMM_BURST != 1 && GEMM_BURST != 3) { stage1(buf ^ 1, kt + 1, 2); stage1(buf ^ 1, kt + 1, 3); }
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(lb, 2, wf0, af0);
+    __builtin_amdgcn_sched_barrier(0);
+    GEMM_MF8(16, wf1, af1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (more_k && GEMM_YPOS == 2 && wave >= 4) { stage1(buf ^ 1, kt + 1, 0); stage1(buf ^ 1, kt + 1, 1); stage1(buf ^ 1, kt + 1, 2); stage1(buf ^ 1, kt + 1, 3); }
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(lb, 3, wf1, af1);
+    __builtin_amdgcn_sched_barrier(0);
+    GEMM_MF8(24, wf0, af0)
+    __builtin_amdgcn_sched_barrier(0);
+#if GEMM_STAMP
+    const bool st_on = blockIdx.x == GEMM_STAMP_BLOCK && step == 2;
+    unsigned long long tB = 0, tC = 0, tA = 0;
+    if (st_on) { tB = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (st_on) { tC = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_barrier();
+    if (st_on) { tA = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) { unsigned long long *sp = g_stamps + ((size_t)wave * 64 + kt) * 4; sp[0] = tB; sp[1] = tC; sp[2] = tA; } }
+#else
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if (more_k) read_frags(smem + (buf ^ 1) * GEMM_BUFBYTES, 0, wf0, af0);
+  }
+  // (the last tile's substep 3 is still pending: issued below, after the next tile's prefetch has been put in flight)
+#else
   for (int kt = 0; kt < nk - 1; ++kt) {
     const int buf = kt & 1;
     const char *lb = smem + buf * GEMM_BUFBYTES;
@@ -257,18 +460,29 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
     GEMM_STEP(false, 3, wf1, af1, wf0, af0)
     __syncthreads();  // every wave is done reading the K-loop buffers: the epilogue reuses them
   }
+#endif
 #undef GEMM_STEP
 
   // ---- next tile's first K-tile in flight under this tile's epilogue
-  const bool more = EPI != 3 && can_prefetch && ti + nslots < chunk_len;  // (EPI 3: the LayerNorm epilogue needs the registers)
+  const bool more = EPI != 3 && can_prefetch && ti + nph * nslots < chunk_len;  // (EPI 3: the LayerNorm epilogue needs the registers)
   TileP nxt;
   float4 nxt_bv;
   if (more) {
-    tile_params(ti + nslots, step + 1, nxt);
+    tile_params(ti + nph * nslots, step + 1, nxt);
     nxt_bv = *reinterpret_cast<const float4 *>(bias + nxt.n0 + lane * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) stage_p(nxt, 0, 0, i);
   }
+#if GEMM_ROTATE
+  {
+    const bool more_k = false;
+    const int kt = 0, buf = 0;
+    (void)kt; (void)buf;
+    GEMM_MF8(0, wf1, af1)
+  }
+#undef GEMM_MF8
+#undef GEMM_MF1
+#endif
   if (EPI == 3) {
     // v = acc + bias + residual; row statistics across the 4 column waves through LDS; normalise in place
 #pragma unroll
@@ -322,8 +536,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   //      two passes of 64 rows per wave through buffer 1 (8 KiB per wave, 16-byte slots XOR-swizzled by row)
   char *cw = smem + GEMM_BUFBYTES + wave * (64 * 128);
   char *Cb = reinterpret_cast<char *>(C);
+  if (GEMM_EABL == 2) {
 #pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) asm volatile("" ::"v"(acc[nb][mb]));
+  }
+#pragma unroll
+  for (int ps = 0; ps < (GEMM_EABL == 2 ? 0 : 2); ++ps) {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
@@ -361,8 +581,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
       const int row = it * 8 + (lane >> 3), q = lane & 7;
       const uint4 v = *reinterpret_cast<const uint4 *>(cw + row * 128 + ((q ^ (row & 7)) << 4));
       const int m = m0 + wm * 128 + ps * 64 + row;
-      if (GATHER) *reinterpret_cast<uint4 *>(Cb + ((size_t)m * GEMM_BN + wn * 64 + q * 8) * 2) = v;
-      else if (m < M) *reinterpret_cast<uint4 *>(Cb + ((size_t)m * N + n0 + wn * 64 + q * 8) * 2) = v;
+      if (GEMM_EABL == 1) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+      else if (GATHER) *reinterpret_cast<uint4 *>(Cb + ((size_t)m * GEMM_BN + wn * 64 + q * 8) * 2) = v;
+      else if (m < M) {
+        if (GEMM_CNT) {
+          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 vv = {v.x, v.y, v.z, v.w};
+          __builtin_nontemporal_store(vv, reinterpret_cast<u32x4 *>(Cb + ((size_t)m * N + n0 + wn * 64 + q * 8) * 2));
+        }
+        else *reinterpret_cast<uint4 *>(Cb + ((size_t)m * N + n0 + wn * 64 + q * 8) * 2) = v;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -380,6 +608,32 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
 }  // namespace unopose
 
 using namespace unopose;
+
+#ifndef GEMM_WSUB_KB
+#define GEMM_WSUB_KB 2400  // W panels of one column group: what may stay resident in a 4 MiB L2 beside the streaming A panels
+#endif
+#ifndef GEMM_CGN
+#define GEMM_CGN -1  // experiments: force the number of column groups (0 = the lock-step schedule)
+#endif
+// Number of column groups of the resident-W schedule, or 0 for the lock-step schedule: the choice that moves fewer bytes
+// over the L2 miss path.  resident: every XCD reads its rows of A once per column group (cgn x A in total) and W once;
+// lock-step: A once, W once per round of every XCD.
+static int resident_w_groups(int tiles_m, int tiles_n, int K, int grid) {
+  if (GEMM_CGN >= 0) return GEMM_CGN;
+  if (grid < 64 || tiles_m < 16) return 0;
+  const double panel = 256.0 * K * 2, a_bytes = panel * tiles_m, w_bytes = panel * tiles_n;
+  const double groups = tiles_m / 8.0 / GEMM_GM, rounds = tiles_m / 8.0 * tiles_n / (grid / 8);
+  const double lockstep = a_bytes + w_bytes * 8 * (groups < rounds ? groups : rounds);  // W once per patch of co-resident tiles
+  int best = 0;
+  double best_cost = lockstep;
+  for (int c = 1; c <= 4 && c <= tiles_n; ++c) {
+    const int ncol = (tiles_n + c - 1) / c;
+    if (ncol * panel > GEMM_WSUB_KB * 1024.0) continue;
+    const double cost = c * a_bytes + 8 * w_bytes;
+    if (cost < best_cost) best_cost = cost, best = c;
+  }
+  return best;
+}
 
 extern "C" {
 
@@ -402,15 +656,16 @@ int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C
     n_cu = cu & ~7;
   }
   const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
+  const int cgn = resident_w_groups(tiles_m, tiles_n, K, grid);
   if (epilogue == 1)
     hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
-                       K, tiles_n, tiles);
+                       K, tiles_n, tiles, cgn);
   else if (epilogue == 2)
     hipLaunchKernelGGL(gemm_bf16_kernel<2>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
-                       K, tiles_n, tiles);
+                       K, tiles_n, tiles, cgn);
   else
     hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
-                       K, tiles_n, tiles);
+                       K, tiles_n, tiles, cgn);
   return check_launch("linear_bf16");
 }
 
@@ -429,7 +684,7 @@ int unopose_linear_add_layernorm_bf16(const void *A, const void *W, const float 
   }
   const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
   hipLaunchKernelGGL((gemm_bf16_kernel<3, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, (const u16 *)A, (const u16 *)W, bias,
-                     (u16 *)C, (int)M, GEMM_BN, K, 1, tiles, (const int *)nullptr, (const int *)nullptr, (const u16 *)resid, ln_w, ln_b, eps);
+                     (u16 *)C, (int)M, GEMM_BN, K, 1, tiles, 0, (const int *)nullptr, (const int *)nullptr, (const u16 *)resid, ln_w, ln_b, eps);
   return check_launch("linear_add_layernorm_bf16");
 }
 
@@ -450,7 +705,7 @@ int unopose_linear_bf16_gather(const void *A, long M, int K, const void *W, int 
   }
   const int grid = max_tiles >= n_cu ? n_cu : ((max_tiles + 7) & ~7);
   hipLaunchKernelGGL((gemm_bf16_kernel<0, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, (const u16 *)A, (const u16 *)W, bias,
-                     (u16 *)C, (int)M, N, K, 1, 0, row_list, tile_info);
+                     (u16 *)C, (int)M, N, K, 1, 0, 0, row_list, tile_info);
   return check_launch("linear_bf16_gather");
 }
 
