@@ -327,11 +327,24 @@ int unopose_linear_attention_f32(const float *x, const float *inv_softplus_scale
 /* nn.Linear on bf16 data with a fused epilogue (timm ViT blocks: qkv / proj / fc1 + GELU / fc2, and the
  * up-projection of oneref_feature_extraction.py:221):
  *     C (M,N) bf16 = act( A (M,K) bf16 . W (N,K)^T bf16 + bias (N) fp32 ),  fp32 accumulation,
- * epilogue 0 = bias only, 1 = bias + exact (erf) GELU evaluated on the fp32 accumulators.
+ * epilogue 0 = bias only, 1 = bias + GELU (erf form to 2.5e-5 absolute, far inside the bf16 result's resolution) evaluated
+ * on the fp32 accumulators, 2 = bias + ReLU.
  * Requires N % 256 == 0 and K % 64 == 0 (unopose_gemm_bf16_tile() reports the 256); any M >= 1. */
 int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C, long M, int N, int K,
                         int epilogue, unopose_stream_t stream);
 int unopose_gemm_bf16_tile(void);
+
+/* nn.Linear on float32 data (the reference's default precision, configs/main_cfg.py:87-89) with fp32-class accuracy on the
+ * bf16 matrix cores: every operand is split into hi + lo bf16 parts and a product is three MFMAs (ah wh + ah wl + al wh,
+ * fp32 accumulation; relative error ~2^-17 per product).  Operands come in the SPLIT layout -- row r, k-block j (32 k) is
+ * one 128-byte line [hi (32 x bf16) | lo (32 x bf16)], rows K * 4 bytes apart, i.e. the size of the fp32 matrix --
+ * written by unopose_split_bf16x2 (X (M,K) float32, K % 32 == 0) or by the GEMM itself:
+ *     C (M,N) float32 and / or Cs (M,N) split = act( As (M,K) . Ws (N,K)^T + bias (N) float32 )
+ * epilogue 0 = bias, 1 = bias + exact (erf) GELU, 2 = bias + ReLU; either of C / Cs may be NULL.
+ * Requires N % 256 == 0, K % 32 == 0. */
+int unopose_split_bf16x2(const float *X, long M, int K, void *Xs, unopose_stream_t stream);
+int unopose_linear_f32x3(const void *As, const void *Ws, const float *bias, float *C, void *Cs, long M, int N, int K,
+                         int epilogue, unopose_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -9,8 +9,13 @@ def so(n): return os.path.join(HERE, f"_gv_{n}.so")
 if sys.argv[1] == "build":
     def one(spec):
         name, _, flags = spec.partition("=")
+        flags = [f for f in flags.split(",") if f]
+        src = os.path.join(ROOT, "unopose_amd/csrc/gemm.hip")  # a flag "@path" names another source file (e.g. last round's kernel)
+        for f in flags:
+            if f.startswith("@"): src = os.path.join(ROOT, f[1:])
+        flags = [f for f in flags if not f.startswith("@")]
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-honor-nans", "-ffp-contract=off",
-               *[f for f in flags.split(",") if f], os.path.join(ROOT, "unopose_amd/csrc/gemm.hip"), os.path.join(ROOT, "unopose_amd/csrc/abi.hip"), "-o", so(name)]
+               "-I", os.path.join(ROOT, "unopose_amd/csrc"), *flags, src, os.path.join(ROOT, "unopose_amd/csrc/abi.hip"), "-o", so(name)]
         subprocess.check_call(cmd)
         return name
     with ThreadPoolExecutor(6) as ex:

@@ -26,8 +26,8 @@ def test_linear_bf16_vs_fp32_reference(M, K, N, gelu):
     err = (out.float() - ref).abs()
     tol = ref.abs() * 2.0 ** -8 + 1e-3
     assert (err <= tol).all(), (err.max().item(), int((err > tol).sum()))
-    # the fused GELU is the erf form, not the tanh approximation: its error before rounding is far below the
-    # 4.7e-4 gap between the two (checked where bf16 resolves it: |y| < 0.06 -> ulp < 2.5e-4)
+    # the fused GELU is erf-class (a 2.5e-5 fit of the erf form), not the tanh approximation: its error before rounding is far
+    # below the 4.7e-4 gap between the two (checked where bf16 resolves it: |y| < 0.06 -> ulp < 2.5e-4)
     if gelu:
         small = ref.abs() < 0.06
         assert (err[small] < 2.5e-4).all()
@@ -86,3 +86,68 @@ def test_linear_add_layernorm_epilogue(M, K):
     # the two-launch form rounds lin(h) to bf16 before the add: it is the less accurate of the two
     assert (two.float() - ref).abs().max().item() >= e.max().item() * 0.5
     assert (out.float() - two.float()).abs().max().item() < 0.1
+
+
+# ---- fp32-class GEMM (csrc/gemm_f32.hip): hi / lo-split bf16 operands, three MFMAs per product ---------------------------
+@torch.no_grad()
+def test_split_layout_roundtrip():
+    """unopose_split_bf16x2: per row and 32-k block one 128-byte line [hi | lo]; hi + lo = x to 2^-16 relative."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(37, 96, generator=g) * torch.logspace(-3, 3, 96)).cuda()
+    s = ops.split_f32(x)
+    assert s.shape == (37, 192) and s.dtype == torch.bfloat16
+    blk = s.reshape(37, 3, 2, 32).float()
+    hi, lo = blk[:, :, 0].reshape(37, 96), blk[:, :, 1].reshape(37, 96)
+    assert torch.equal(hi, x.bfloat16().float())
+    assert ((hi + lo - x).abs() <= x.abs() * 2.0 ** -16).all()
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("M,K,N,epi", [(1, 32, 256, 0), (300, 256, 256, 2), (4173, 768, 768, 1), (5000, 3072, 768, 0),
+                                       (2049 * 3, 256, 512, 2), (64 * 261, 768, 2304, 0)])
+def test_linear_f32x3_vs_fp64_reference(M, K, N, epi):
+    """C = act(A W^T + b) on fp32 data: error budget 3 x 2^-17 of sum |a| |w| (the split's representation error and the
+    dropped lo x lo term) -- fp32-class, 400 x tighter than a bf16 GEMM."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(M + K + N)
+    a = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    out, outs = ops.linear_f32x3(ops.split_f32(a), ops.split_f32(w), b, M, N, K, gelu=epi == 1, relu=epi == 2, out="both")
+    rows = slice(0, M) if M <= 4200 else torch.randperm(M, generator=g)[:2048].cuda()
+    ref = a[rows].double() @ w.double().t() + b.double()
+    mag = a[rows].abs().double() @ w.abs().double().t() + b.abs().double()
+    ref = F.gelu(ref) if epi == 1 else (F.relu(ref) if epi == 2 else ref)
+    err = (out[rows].double() - ref).abs()
+    assert (err <= mag * 3 * 2.0 ** -17 + 1e-6).all(), (err / mag).max().item()
+    # the split-layout output is the same numbers, split
+    blk = outs[rows].reshape(ref.shape[0], N // 32, 2, 32).float()
+    rec = (blk[:, :, 0] + blk[:, :, 1]).reshape(ref.shape[0], N)
+    assert ((rec - out[rows]).abs() <= out[rows].abs() * 2.0 ** -16 + 1e-30).all()
+
+
+@torch.no_grad()
+def test_fp32_linears_take_the_f32x3_path_and_match_torch():
+    """ops.linear / ops.mlp outside autocast: csrc/gemm_f32.hip; result = the fp32 torch composite at 1e-5 of the operand scale."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(1)
+    fc1, fc2 = torch.nn.Linear(768, 3072).cuda(), torch.nn.Linear(3072, 768).cuda()
+    x = torch.randn(2, 1374, 768, generator=g).cuda()
+    y = ops.mlp(x, fc1, fc2)
+    ref = F.gelu(x.double() @ fc1.weight.double().t() + fc1.bias.double()) @ fc2.weight.double().t() + fc2.bias.double()
+    assert y.dtype == torch.float32 and (y.double() - ref).abs().max().item() < 2e-5
+    ops.USE_F32X3 = False
+    try:
+        lib = ops.mlp(x, fc1, fc2)
+    finally:
+        ops.USE_F32X3 = True
+    assert (lib.double() - ref).abs().max().item() < 2e-5 and (y - lib).abs().max().item() < 2e-5
+    lin = torch.nn.Linear(256, 512).cuda()
+    h = torch.randn(3, 197, 256, generator=g).cuda()
+    z = ops.linear(h, lin, relu=True)
+    mag = h.abs().double() @ lin.weight.abs().double().t() + lin.bias.abs().double()
+    assert ((z.double() - F.relu(h.double() @ lin.weight.double().t() + lin.bias.double())).abs() <= mag * 3 * 2.0 ** -17).all()

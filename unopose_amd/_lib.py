@@ -58,6 +58,8 @@ SIGNATURES = {
     "unopose_linear_attention_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "unopose_linear_bf16": [_P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P],
     "unopose_gemm_bf16_tile": [],
+    "unopose_split_bf16x2": [_P, ctypes.c_long, _I, _P, _P],
+    "unopose_linear_f32x3": [_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P],
     "unopose_pe_image_bytes": [],
     "unopose_pe_pack_weights": [_P, _P, _P, _P, _P, _P, _P, _P],
     "unopose_pe_group_mlp_max_packed": [_P, _I, _I, _F, _I, _P, _P, _P],

@@ -43,7 +43,7 @@ class _Mlp(nn.Module):
         self.fc2 = nn.Linear(ratio * dim, dim)
 
     def forward(self, x):
-        return ops.linear(ops.linear(x, self.fc1, gelu=True), self.fc2)
+        return ops.mlp(x, self.fc1, self.fc2)
 
 
 class _Block(nn.Module):

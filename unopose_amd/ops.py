@@ -181,6 +181,64 @@ def bf16_linear_2d(x2, w, bias_f32, bias_bf16=None, relu=False):
     return F.relu(y) if relu else y
 
 
+# fp32 linears (the reference's default precision) on csrc/gemm_f32.hip: hi / lo-split bf16 operands, 3 MFMAs per product
+# (fp32-class accuracy); UNOPOSE_F32X3=0 routes them back to the library SGEMM (A/B switch).
+USE_F32X3 = os.environ.get("UNOPOSE_F32X3", "1") == "1"
+
+
+def f32x3_ok(rows, N, K):
+    return USE_F32X3 and N % 256 == 0 and K % 32 == 0 and rows >= 1 and rows * K * 4 < 2 ** 32 and N * K * 4 < 2 ** 32
+
+
+def split_f32(x2):
+    """(M,K) fp32 -> the split layout of csrc/gemm_f32.hip (per row and 32-k block one 128-byte line [hi | lo] of bf16):
+    returned as an (M, 2K) bf16 tensor (same bytes as the fp32 matrix)."""
+    M, K = x2.shape
+    out = torch.empty(M, 2 * K, dtype=torch.bfloat16, device=x2.device)
+    with torch.cuda.device(x2.device):
+        call("unopose_split_bf16x2", ptr(x2), M, K, ptr(out), stream_ptr())
+    return out
+
+
+def _f32x3_weights(lin):
+    key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.device, None if lin.bias is None else lin.bias._version)
+    cache = getattr(lin, "_f32x3_cache", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            w = lin.weight.detach().float().contiguous()
+            b32 = torch.zeros(w.shape[0], device=w.device) if lin.bias is None else lin.bias.detach().float().contiguous()
+            cache = (key, split_f32(w), b32)
+        lin._f32x3_cache = cache
+    return cache
+
+
+def linear_f32x3(xs, ws, bias_f32, M, N, K, gelu=False, relu=False, out="f32"):
+    """C-ABI unopose_linear_f32x3 on split operands; `out`: "f32" -> (M,N) fp32, "split" -> (M,2N) split layout, "both"."""
+    C = torch.empty(M, N, dtype=torch.float32, device=xs.device) if out in ("f32", "both") else None
+    Cs = torch.empty(M, 2 * N, dtype=torch.bfloat16, device=xs.device) if out in ("split", "both") else None
+    with torch.cuda.device(xs.device):
+        call("unopose_linear_f32x3", ptr(xs), ptr(ws), ptr(bias_f32), None if C is None else ptr(C), None if Cs is None else ptr(Cs),
+             M, N, K, 1 if gelu else (2 if relu else 0), stream_ptr())
+    return C if out == "f32" else (Cs if out == "split" else (C, Cs))
+
+
+def _f32_path(x):
+    return x.is_cuda and x.dtype == torch.float32 and not _DIFF and not torch.is_autocast_enabled()
+
+
+def mlp(x, fc1, fc2):
+    """timm Mlp (fc1 -> exact GELU -> fc2).  fp32: both linears on csrc/gemm_f32.hip, the hidden activation handed over in the
+    split layout fc2 reads (never materialised in fp32); autocast: two fused bf16 GEMMs."""
+    N1, K1 = fc1.weight.shape
+    N2, K2 = fc2.weight.shape
+    rows = x.numel() // K1
+    if _f32_path(x) and f32x3_ok(rows, N1, K1) and f32x3_ok(rows, N2, K2):
+        c1, c2 = _f32x3_weights(fc1), _f32x3_weights(fc2)
+        hs = linear_f32x3(split_f32(_c(x).reshape(rows, K1)), c1[1], c1[2], rows, N1, K1, gelu=True, out="split")
+        return linear_f32x3(hs, c2[1], c2[2], rows, N2, K2).reshape(*x.shape[:-1], N2)
+    return linear(linear(x, fc1, gelu=True), fc2)
+
+
 def linear(x, lin, relu=False, gelu=False):
     """nn.Linear under autocast without the per-call weight cast: bf16 copies of (weight, bias) are cached
     on the module (keyed by the parameter version) and the GEMM is issued directly in bf16.  Outside
@@ -188,6 +246,12 @@ def linear(x, lin, relu=False, gelu=False):
     the up-projection) run on the hand-written GEMM of csrc/gemm.hip with the bias -- and, for `gelu=True`, timm
     Mlp's exact-erf GELU -- fused into its epilogue; the rest goes to hipBLASLt, where `relu=True` rides in the
     library epilogue (RELU_BIAS through torch._addmm_activation)."""
+    if _f32_path(x):
+        N, K = lin.weight.shape
+        rows = x.numel() // K
+        if f32x3_ok(rows, N, K):
+            c = _f32x3_weights(lin)
+            return linear_f32x3(split_f32(_c(x).reshape(rows, K)), c[1], c[2], rows, N, K, gelu, relu).reshape(*x.shape[:-1], N)
     if _DIFF or not (torch.is_autocast_enabled() and x.is_cuda):
         y = lin(x)
         return F.relu(y) if relu else (F.gelu(y) if gelu else y)
