@@ -144,6 +144,13 @@ int unopose_pe_group_mlp_max_packed_cand(const float *xyz, int B, int N, float r
                                          const void *image, const int *cand_in, const int *cand_cnt_in,
                                          int cand_stride, int *cand_out, int *cand_cnt_out, float *out,
                                          unopose_stream_t stream);
+/* The same launch with the output placed by the caller: row stride out_ld (in 4-byte units, >= 128; the row of centre (b, j) starts
+ * at out + (b N + j) out_ld * 4 bytes) and out_split = 1 writing the 128 channels in the split layout of unopose_linear_f32x3
+ * (4 blocks of [hi | lo] bf16) instead of float32 -- both scales of the positional encoding then land side by side in the
+ * (B, N, 256)-wide operand of its Conv1d (oneref_predator_fine_point_matching.py:174) without a concatenation or a split pass. */
+int unopose_pe_group_mlp_max_packed_out(const float *xyz, int B, int N, float radius, int nsample, const void *image,
+                                        const int *cand_in, const int *cand_cnt_in, int cand_stride, int *cand_out,
+                                        int *cand_cnt_out, void *out, int out_ld, int out_split, unopose_stream_t stream);
 
 /* GeometricStructureEmbedding.forward (core/unopose/model/transformer.py:303-350):
  * points (B,n,3) -> out (B,n,n,256), float32 or bfloat16 (out_bf16).  hidden_dim = 256,
@@ -324,6 +331,23 @@ int unopose_linear_attention_f32(const float *x, const float *inv_softplus_scale
                                  const float *ksum, int B, int N, int focus, int mode, float *out,
                                  unopose_stream_t stream);
 
+/* ---- data-movement glue of the forward as single-pass kernels (csrc/glue.hip) ---------------------------------------------
+ * patchify: the ViT's 14 x 14 / 14 patch unfolding (timm PatchEmbed, oneref_feature_extraction.py:24-27) of two image batches
+ * (na + nb crops of (3,S,S) float32; rgb_b may be NULL with nb = 0) into the bf16 matrix ((na + nb) (S/14)^2, Kp) the
+ * patch-embedding GEMM reads: column = c * 196 + py * 14 + px, columns 588 .. Kp-1 zero. */
+int unopose_patchify_bf16(const float *rgb_a, int na, const float *rgb_b, int nb, int S, int Kp, void *out,
+                          unopose_stream_t stream);
+/* tokens of timm's _pos_embed (no_embed_class) + the first block's LayerNorm in one pass: x (nimg, npre + P, 768) float32 =
+ * [prefix (npre,768) | patch (nimg,P,768) bf16 + pos (P,768)], n1 = LayerNorm(x) * ln_w + ln_b as bf16. */
+int unopose_vit_tokens_layernorm(const void *patch, const float *pos, const float *prefix, int npre, int P, int nimg, int C,
+                                 const float *ln_w, const float *ln_b, float eps, float *x, void *n1, unopose_stream_t stream);
+/* out[r] = x[r,:] . w + b for 256-wide rows: the overlap-score heads nn.Linear(256, 1)
+ * (oneref_predator_coarse_point_matching.py:66, ..._fine_point_matching.py:89). */
+int unopose_row_dot(const void *x, int x_bf16, const float *w, float b, long rows, int C, void *out, int out_bf16,
+                    unopose_stream_t stream);
+/* out (B, N+1, row) = [first (B,1,row) | rest (B,N,row)]: the background token in front of the dense features (Fi:75-83). */
+int unopose_prepend_row(const void *first, const void *rest, long B, long N, int row_bytes, void *out, unopose_stream_t stream);
+
 /* nn.Linear on bf16 data with a fused epilogue (timm ViT blocks: qkv / proj / fc1 + GELU / fc2, and the
  * up-projection of oneref_feature_extraction.py:221):
  *     C (M,N) bf16 = act( A (M,K) bf16 . W (N,K)^T bf16 + bias (N) fp32 ),  fp32 accumulation,
@@ -341,10 +365,15 @@ int unopose_gemm_bf16_tile(void);
  * written by unopose_split_bf16x2 (X (M,K) float32, K % 32 == 0) or by the GEMM itself:
  *     C (M,N) float32 and / or Cs (M,N) split = act( As (M,K) . Ws (N,K)^T + bias (N) float32 )
  * epilogue 0 = bias, 1 = bias + exact (erf) GELU, 2 = bias + ReLU; either of C / Cs may be NULL.
- * Requires N % 256 == 0, K % 32 == 0. */
+ * Requires N % 256 == 0, K % 32 == 0.
+ * unopose_linear_f32x3_bf16: the same product rounded to bfloat16, optionally added to a bfloat16 residual (result rounded again):
+ * Cb = bf16( resid + bf16(As Ws^T + bias) ) -- the fp32 island `d + PE(p).to(bf16)` of the fine matcher under autocast
+ * (oneref_predator_fine_point_matching.py:163-165, 77-80). */
 int unopose_split_bf16x2(const float *X, long M, int K, void *Xs, unopose_stream_t stream);
 int unopose_linear_f32x3(const void *As, const void *Ws, const float *bias, float *C, void *Cs, long M, int N, int K,
                          int epilogue, unopose_stream_t stream);
+int unopose_linear_f32x3_bf16(const void *As, const void *Ws, const float *bias, const void *resid, void *Cb, long M, int N, int K,
+                              unopose_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -58,12 +58,18 @@ SIGNATURES = {
     "unopose_linear_attention_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "unopose_linear_bf16": [_P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P],
     "unopose_gemm_bf16_tile": [],
+    "unopose_patchify_bf16": [_P, _I, _P, _I, _I, _I, _P, _P],
+    "unopose_vit_tokens_layernorm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P],
+    "unopose_row_dot": [_P, _I, _P, _F, ctypes.c_long, _I, _P, _I, _P],
+    "unopose_prepend_row": [_P, _P, ctypes.c_long, ctypes.c_long, _I, _P, _P],
     "unopose_split_bf16x2": [_P, ctypes.c_long, _I, _P, _P],
     "unopose_linear_f32x3": [_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P],
     "unopose_pe_image_bytes": [],
     "unopose_pe_pack_weights": [_P, _P, _P, _P, _P, _P, _P, _P],
     "unopose_pe_group_mlp_max_packed": [_P, _I, _I, _F, _I, _P, _P, _P],
     "unopose_pe_group_mlp_max_packed_cand": [_P, _I, _I, _F, _I, _P, _P, _P, _I, _P, _P, _P, _P],
+    "unopose_pe_group_mlp_max_packed_out": [_P, _I, _I, _F, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P],
+    "unopose_linear_f32x3_bf16": [_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _P],
     "unopose_pe_group_mlp_max": [_P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "unopose_geo_embedding": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P, _P, _P],
 }

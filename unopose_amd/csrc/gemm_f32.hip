@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void split_bf16x2_kernel(const float *__restri
 }
 
 // EPI 0: bias; 1: bias + exact-erf GELU; 2: bias + ReLU.  C (fp32, row-major) and / or Cs (split layout) are written.
+// EPI 3: bias, result rounded to bf16 and added to the bf16 residual `Cs` (may be NULL), written to `C` as bf16 (M,N).
 template <int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_f32x3_kernel(const char *__restrict__ A, const char *__restrict__ W,
                                                             const float *__restrict__ bias, float *__restrict__ C, char *__restrict__ Cs,
@@ -188,6 +189,42 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_kernel(const char *__restri
           }
         }
       const int m_base = m0 + wm * 128 + mb * 32;
+      if (EPI == 3) {
+        // bf16 image: row = 128 B = 8 slots of 16 B (8 columns), slot nb * 4 + g, XOR-swizzled by the row
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<uint2 *>(cw + l31 * 128 + (((nb * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) =
+                make_uint2(cvt_pk_bf16_f32(v[nb][g][0], v[nb][g][1]), cvt_pk_bf16_f32(v[nb][g][2], v[nb][g][3]));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 8 + (lane >> 3), q = lane & 7;
+          uint4 o = *reinterpret_cast<const uint4 *>(cw + row * 128 + ((q ^ (row & 7)) << 4));
+          const int m = m_base + row;
+          if (m < M) {
+            const size_t off = ((size_t)m * N + n0 + wn * 64 + q * 8) * 2;
+            if (Cs) {
+              const uint4 r = *reinterpret_cast<const uint4 *>(Cs + off);
+              const uint32_t ov[4] = {o.x, o.y, o.z, o.w}, rv[4] = {r.x, r.y, r.z, r.w};
+              uint32_t sv[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                sv[e] = cvt_pk_bf16_f32(__uint_as_float(ov[e] << 16) + __uint_as_float(rv[e] << 16),
+                                        __uint_as_float(ov[e] & 0xffff0000u) + __uint_as_float(rv[e] & 0xffff0000u));
+              o = make_uint4(sv[0], sv[1], sv[2], sv[3]);
+            }
+            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(C) + off) = o;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        continue;
+      }
       if (C) {
         // fp32 image: row = 256 B = 16 slots of 16 B, slot s = nb * 8 + 2 g + hi, XOR-swizzled by the row
 #pragma unroll
@@ -293,6 +330,20 @@ int unopose_linear_f32x3(const void *As, const void *Ws, const float *bias, floa
   else UNOPOSE_LAUNCH_F32X3(0);
 #undef UNOPOSE_LAUNCH_F32X3
   return check_launch("linear_f32x3");
+}
+
+int unopose_linear_f32x3_bf16(const void *As, const void *Ws, const float *bias, const void *resid, void *Cb, long M, int N, int K,
+                              unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(As && Ws && bias && Cb, "linear_f32x3_bf16: null pointer");
+  UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && K >= GEMMF_BK && K % GEMMF_BK == 0,
+                  "linear_f32x3_bf16: needs N %% 256 == 0 and K %% 32 == 0 (got M=%ld N=%d K=%d)", M, N, K);
+  UNOPOSE_REQUIRE((size_t)M * K * 4 < (1UL << 32) && (size_t)N * K * 4 < (1UL << 32), "linear_f32x3_bf16: operand larger than 4 GiB");
+  const int tiles_m = cdiv(M, GEMM_BM), tiles_n = N / GEMM_BN, tiles = tiles_m * tiles_n;
+  const int n_cu = gemm_cu_count();
+  const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
+  hipLaunchKernelGGL(gemm_f32x3_kernel<3>, dim3(grid), dim3(512), 0, (hipStream_t)stream, (const char *)As, (const char *)Ws, bias,
+                     (float *)Cb, (char *)const_cast<void *>(resid), (int)M, N, K, tiles_n, tiles, 0);
+  return check_launch("linear_f32x3_bf16");
 }
 
 }  // extern "C"

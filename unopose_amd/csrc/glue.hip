@@ -1,0 +1,177 @@
+// Data-movement glue of the forward as single-pass HIP kernels (C ABI part 2c).  Each replaces a chain of torch
+// element-wise / cat / cast launches that rocprof showed as ~6 ms of a 37 ms step (280 launches):
+//   * patchify_bf16:        both crops -> the zero-padded bf16 patch matrix of the ViT's patch-embedding GEMM
+//                           (timm PatchEmbed, driven at oneref_feature_extraction.py:24-27; was cat + unfold copy + zeros + cast copy)
+//   * vit_tokens_layernorm: patch GEMM output + pos_embed, class / register tokens in front (timm _pos_embed, no_embed_class)
+//                           and the first block's LayerNorm in the same pass (was add + cat + LayerNorm)
+//   * row_dot:              the overlap-score heads nn.Linear(256, 1) (C:66, Fi:89) as a row dot product
+//   * prepend_row:          [bg | dense] (B, N + 1, C) assembly (Fi:75-83) in one pass
+#include <algorithm>
+
+#include "common.h"
+
+namespace unopose {
+
+typedef unsigned short u16;
+
+// ---- (B,3,S,S) fp32 x 2 -> (2 B P, Kp) bf16, P = (S/14)^2, column = c * 196 + py * 14 + px, columns >= 588 zero.
+// One workgroup per (crop, patch row gy): the 3 x 14 x S strip is read with coalesced rows and written patch-major.
+__global__ __launch_bounds__(256) void patchify_bf16_kernel(const float *__restrict__ a, int na, const float *__restrict__ b, int S,
+                                                            int Kp, u16 *__restrict__ out) {
+  const int g = S / 14;
+  const int crop = blockIdx.x / g, gy = blockIdx.x - crop * g;
+  const float *src = (crop < na ? a + (size_t)crop * 3 * S * S : b + (size_t)(crop - na) * 3 * S * S);
+  u16 *dst = out + ((size_t)crop * g * g + (size_t)gy * g) * Kp;
+  // element e of the strip: patch gx, column k (k < Kp); consecutive threads take consecutive (gx, k) pairs of the OUTPUT
+  // (2-byte coalesced stores); the reads of one patch row segment (14 floats) stay inside a 56-byte window: L1-served
+  const int total = g * (Kp / 2);
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int gx = e / (Kp / 2), k2 = (e - gx * (Kp / 2)) * 2;
+    float v[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k2 + j;
+      if (k < 588) {
+        const int c = k / 196, r = k - c * 196, py = r / 14, px = r - py * 14;
+        v[j] = src[((size_t)c * S + gy * 14 + py) * S + gx * 14 + px];
+      } else {
+        v[j] = 0.f;
+      }
+    }
+    *reinterpret_cast<uint32_t *>(dst + (size_t)gx * Kp + k2) = cvt_pk_bf16_f32(v[0], v[1]);
+  }
+}
+
+// ---- tokens + first LayerNorm.  One wavefront per token row; C = 768 = 64 lanes x 12 (three float4 per lane).
+// x[r] (fp32, the residual stream) = prefix token (cls, reg0..) for t < npre, else patch[b, t - npre] (bf16) + pos[t - npre];
+// n1[r] (bf16) = LayerNorm(x[r]) * w + bias.
+__global__ __launch_bounds__(256) void vit_tokens_layernorm_kernel(const u16 *__restrict__ patch, const float *__restrict__ pos,
+                                                                   const float *__restrict__ prefix, int npre, int P, long rows,
+                                                                   const float *__restrict__ w, const float *__restrict__ bias, float eps,
+                                                                   float *__restrict__ x, u16 *__restrict__ n1) {
+  constexpr int C = 768;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int T = npre + P;
+  const long bimg = r / T;
+  const int t = (int)(r - bimg * T);
+  float v[12];
+  if (t < npre) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float4 q = *reinterpret_cast<const float4 *>(prefix + (size_t)t * C + i * 256 + lane * 4);
+      v[4 * i] = q.x, v[4 * i + 1] = q.y, v[4 * i + 2] = q.z, v[4 * i + 3] = q.w;
+    }
+  } else {
+    const u16 *pr = patch + ((size_t)bimg * P + (t - npre)) * C;
+    const float *ps = pos + (size_t)(t - npre) * C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const uint2 h = *reinterpret_cast<const uint2 *>(pr + i * 256 + lane * 4);
+      const float4 q = *reinterpret_cast<const float4 *>(ps + i * 256 + lane * 4);
+      v[4 * i] = __uint_as_float(h.x << 16) + q.x;
+      v[4 * i + 1] = __uint_as_float(h.x & 0xffff0000u) + q.y;
+      v[4 * i + 2] = __uint_as_float(h.y << 16) + q.z;
+      v[4 * i + 3] = __uint_as_float(h.y & 0xffff0000u) + q.w;
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s += v[i];
+  const float mean = wave_sum_f32(s) * (1.f / C);
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) q2 += (v[i] - mean) * (v[i] - mean);
+  const float rstd = rsqrtf(wave_sum_f32(q2) * (1.f / C) + eps);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    *reinterpret_cast<float4 *>(x + (size_t)r * C + c) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    const float4 ww = *reinterpret_cast<const float4 *>(w + c), bb = *reinterpret_cast<const float4 *>(bias + c);
+    const float y0 = (v[4 * i] - mean) * rstd * ww.x + bb.x, y1 = (v[4 * i + 1] - mean) * rstd * ww.y + bb.y;
+    const float y2 = (v[4 * i + 2] - mean) * rstd * ww.z + bb.z, y3 = (v[4 * i + 3] - mean) * rstd * ww.w + bb.w;
+    *reinterpret_cast<uint2 *>(n1 + (size_t)r * C + c) = make_uint2(cvt_pk_bf16_f32(y0, y1), cvt_pk_bf16_f32(y2, y3));
+  }
+}
+
+// ---- out[r] = sum_c x[r, c] * w[c] + b   (x bf16 or fp32, C = 256: one wavefront per row, 4 channels per lane)
+template <bool X_BF16, bool OUT_BF16>
+__global__ __launch_bounds__(256) void row_dot_kernel(const void *__restrict__ x, const float *__restrict__ w, float b, long rows,
+                                                      void *__restrict__ out) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float4 ww = *reinterpret_cast<const float4 *>(w + lane * 4);
+  float4 v;
+  if (X_BF16) {
+    const uint2 h = *reinterpret_cast<const uint2 *>(reinterpret_cast<const u16 *>(x) + (size_t)r * 256 + lane * 4);
+    v = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+  } else {
+    v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(x) + (size_t)r * 256 + lane * 4);
+  }
+  const float s = wave_sum_f32((v.x * ww.x + v.y * ww.y) + (v.z * ww.z + v.w * ww.w)) + b;
+  if (lane == 0) {
+    if (OUT_BF16) reinterpret_cast<u16 *>(out)[r] = (u16)(cvt_pk_bf16_f32(s, 0.f) & 0xffffu);
+    else reinterpret_cast<float *>(out)[r] = s;
+  }
+}
+
+// ---- out (B, N + 1, C) = [first (B, 1, C) | rest (B, N, C)], 16-byte units (C * elem_size % 16 == 0)
+__global__ __launch_bounds__(256) void prepend_row_kernel(const uint4 *__restrict__ first, const uint4 *__restrict__ rest, long B, long N,
+                                                          int row16, uint4 *__restrict__ out) {
+  const long total = B * (N + 1) * row16;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / row16;
+    const int c = (int)(i - row * row16);
+    const long b = row / (N + 1), t = row - b * (N + 1);
+    out[i] = t == 0 ? first[b * row16 + c] : rest[(b * N + t - 1) * row16 + c];
+  }
+}
+
+}  // namespace unopose
+
+using namespace unopose;
+
+extern "C" {
+
+int unopose_patchify_bf16(const float *rgb_a, int na, const float *rgb_b, int nb, int S, int Kp, void *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(rgb_a && out && (rgb_b || nb == 0), "patchify_bf16: null pointer");
+  UNOPOSE_REQUIRE(na >= 1 && nb >= 0 && S >= 14 && S % 14 == 0 && Kp >= 588 && Kp % 2 == 0, "patchify_bf16: needs S %% 14 == 0 and an even Kp >= 588 (got S=%d Kp=%d)", S, Kp);
+  hipLaunchKernelGGL(patchify_bf16_kernel, dim3((na + nb) * (S / 14)), dim3(256), 0, (hipStream_t)stream, rgb_a, na, rgb_b, S, Kp, (u16 *)out);
+  return check_launch("patchify_bf16");
+}
+
+int unopose_vit_tokens_layernorm(const void *patch, const float *pos, const float *prefix, int npre, int P, int nimg, int C,
+                                 const float *ln_w, const float *ln_b, float eps, float *x, void *n1, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(patch && pos && prefix && ln_w && ln_b && x && n1, "vit_tokens_layernorm: null pointer");
+  UNOPOSE_REQUIRE(C == 768 && npre >= 0 && P >= 1 && nimg >= 1, "vit_tokens_layernorm: built for C = 768 (got %d)", C);
+  const long rows = (long)nimg * (npre + P);
+  hipLaunchKernelGGL(vit_tokens_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const u16 *)patch, pos,
+                     prefix, npre, P, rows, ln_w, ln_b, eps, x, (u16 *)n1);
+  return check_launch("vit_tokens_layernorm");
+}
+
+int unopose_row_dot(const void *x, int x_bf16, const float *w, float b, long rows, int C, void *out, int out_bf16, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(x && w && out, "row_dot: null pointer");
+  UNOPOSE_REQUIRE(C == 256 && rows >= 1, "row_dot: built for C = 256 (got %d)", C);
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (x_bf16 && out_bf16) hipLaunchKernelGGL((row_dot_kernel<true, true>), grid, block, 0, s, x, w, b, rows, out);
+  else if (x_bf16) hipLaunchKernelGGL((row_dot_kernel<true, false>), grid, block, 0, s, x, w, b, rows, out);
+  else if (out_bf16) hipLaunchKernelGGL((row_dot_kernel<false, true>), grid, block, 0, s, x, w, b, rows, out);
+  else hipLaunchKernelGGL((row_dot_kernel<false, false>), grid, block, 0, s, x, w, b, rows, out);
+  return check_launch("row_dot");
+}
+
+int unopose_prepend_row(const void *first, const void *rest, long B, long N, int row_bytes, void *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(first && rest && out, "prepend_row: null pointer");
+  UNOPOSE_REQUIRE(B >= 1 && N >= 0 && row_bytes >= 16 && row_bytes % 16 == 0, "prepend_row: row bytes must be a multiple of 16 (got %d)", row_bytes);
+  const long total = B * (N + 1) * (row_bytes / 16);
+  const int grid = (int)std::min<long>((total + 255) / 256, 256 * 8);
+  hipLaunchKernelGGL(prepend_row_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4 *)first, (const uint4 *)rest, B, N,
+                     row_bytes / 16, (uint4 *)out);
+  return check_launch("prepend_row");
+}
+
+}  // extern "C"

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void pe_pack_weights_kernel(const float *__res
 __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
     const float *__restrict__ xyz, int N, float radius, int S, int cpw, const uint4 *__restrict__ image,
     const int *__restrict__ cand_in, const int *__restrict__ cand_cnt_in, int cand_stride, int *__restrict__ cand_out,
-    int *__restrict__ cand_cnt_out, float *__restrict__ out) {
+    int *__restrict__ cand_cnt_out, float *__restrict__ out, int out_ld, int out_split) {
   extern __shared__ float4 smem4[];
   PeLdsB *L = reinterpret_cast<PeLdsB *>(smem4);
   float *sx = reinterpret_cast<float *>(L + 1);
@@ -451,9 +451,22 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float *O = out + ((size_t)b * N + j) * 128;
-    O[lane] = stage[lane];
-    O[lane + 64] = stage[lane + 64];
+    float *O = out + ((size_t)b * N + j) * out_ld;
+    if (!out_split) {
+      O[lane] = stage[lane];
+      O[lane + 64] = stage[lane + 64];
+    } else {
+      // split layout of csrc/gemm_f32.hip: 32-channel blocks of 128 bytes [hi (32 x bf16) | lo (32 x bf16)]; this scale's 128
+      // channels are 4 blocks = 128 dwords, two per lane
+      uint32_t *O32 = reinterpret_cast<uint32_t *>(O);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int d = lane + 64 * q, blk = d >> 5, w = d & 31, k = blk * 32 + (w & 15) * 2;
+        const float v0 = stage[k], v1 = stage[k + 1];
+        const uint32_t h = cvt_pk_bf16_f32(v0, v1);
+        O32[d] = (w & 16) ? cvt_pk_bf16_f32(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u)) : h;
+      }
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -484,7 +497,15 @@ int unopose_pe_group_mlp_max_packed(const float *xyz, int B, int N, float radius
 int unopose_pe_group_mlp_max_packed_cand(const float *xyz, int B, int N, float radius, int nsample, const void *image,
                                          const int *cand_in, const int *cand_cnt_in, int cand_stride, int *cand_out,
                                          int *cand_cnt_out, float *out, unopose_stream_t stream) {
+  return unopose_pe_group_mlp_max_packed_out(xyz, B, N, radius, nsample, image, cand_in, cand_cnt_in, cand_stride, cand_out,
+                                             cand_cnt_out, out, 128, 0, stream);
+}
+
+int unopose_pe_group_mlp_max_packed_out(const float *xyz, int B, int N, float radius, int nsample, const void *image,
+                                        const int *cand_in, const int *cand_cnt_in, int cand_stride, int *cand_out,
+                                        int *cand_cnt_out, void *out, int out_ld, int out_split, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(xyz && image && out, "pe_group_mlp_max_packed: null pointer");
+  UNOPOSE_REQUIRE(out_ld >= 128 && (out_split == 0 || out_split == 1), "pe_group_mlp_max_packed: bad output stride / mode");
   UNOPOSE_REQUIRE((cand_in == nullptr) == (cand_cnt_in == nullptr) && (cand_out == nullptr) == (cand_cnt_out == nullptr) &&
                       (!cand_in || cand_stride >= 1),
                   "pe_group_mlp_max_packed: candidate list and its counts go together");
@@ -503,7 +524,7 @@ int unopose_pe_group_mlp_max_packed_cand(const float *xyz, int B, int N, float r
   const int cpw = centres >= 65536 ? 16 : centres >= 32768 ? 8 : centres >= 8192 ? 4 : centres >= 2048 ? 2 : 1;
   dim3 grid(cdiv(N, 4 * cpw), B);
   hipLaunchKernelGGL(pe_group_mlp_max_bf16x3_kernel, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius, nsample,
-                     cpw, (const uint4 *)image, cand_in, cand_cnt_in, cand_stride, cand_out, cand_cnt_out, out);
+                     cpw, (const uint4 *)image, cand_in, cand_cnt_in, cand_stride, cand_out, cand_cnt_out, (float *)out, out_ld, out_split);
   return check_launch("pe_group_mlp_max_packed");
 }
 

@@ -107,7 +107,13 @@ class ViT(nn.Module):
     def forward(self, x, taps_side_by_side=False):
         """-> the four tapped LayerNorm outputs (F:24-42).  With `taps_side_by_side` on the fused autocast path
         they are returned as ONE (B, T, 4*D) tensor (tap k in columns [k*D, (k+1)*D)), written in place by the
-        four LayerNorm launches instead of being concatenated afterwards."""
+        four LayerNorm launches instead of being concatenated afterwards.  `x` may be a PAIR of image batches
+        (query crops, reference crops): they run as one batch without being concatenated first."""
+        xa, xb = x if isinstance(x, (tuple, list)) else (x, None)
+        if ops.vit_prologue_ok(xa, self) and (xb is None or xb.shape[1:] == xa.shape[1:]):
+            x, n1 = ops.vit_prologue(xa, xb, self, self.blocks[0].norm1)
+            return self._fused_blocks(x, n1, taps_side_by_side)
+        x = xa if xb is None else torch.cat([xa, xb], 0)
         B = x.shape[0]
         p = self.patch_size
         # patch conv 14x14/14 as one GEMM: (B, P, 3*14*14) @ W^T
@@ -123,23 +129,33 @@ class ViT(nn.Module):
                 and not ops.is_differentiable():
             # fused glue: each block's LayerScale residual also produces the next LayerNorm (csrc/fused.hip)
             x = x.contiguous()
-            n1 = ops.add_layernorm(x, None, self.blocks[0].norm1, torch.bfloat16)
-            D = x.shape[-1]
-            wide = torch.empty(B, x.shape[1], len(taps) * D, dtype=torch.bfloat16, device=x.device) \
-                if taps_side_by_side else None
-            for i, blk in enumerate(self.blocks):
-                nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None
-                x, n1 = blk.forward_fused(x, n1, nxt)
-                if i in taps:
-                    k = len(outs)
-                    outs.append(ops.add_layernorm(x, None, self.norm, out=None if wide is None else wide[:, :, k * D:(k + 1) * D]))
-            return outs if wide is None else wide
+            return self._fused_blocks(x, ops.add_layernorm(x, None, self.blocks[0].norm1, torch.bfloat16), taps_side_by_side)
         for i, blk in enumerate(self.blocks):
             x = blk(x)
             if i in taps:
                 outs.append(ops.add_layernorm(x, None, self.norm)
                             if x.is_cuda and torch.is_autocast_enabled() and not ops.is_differentiable() else self.norm(x))
         return outs
+
+
+def _vit_fused_blocks(self, x, n1, taps_side_by_side):
+    """The 12 blocks on the fused autocast path: x = fp32 residual stream (updated in place), n1 = norm1(x) of block 0 as bf16;
+    each block's LayerScale residual also produces the next LayerNorm (csrc/fused.hip)."""
+    n = self.depth // 4
+    taps = {self.depth - 1, self.depth - n - 1, self.depth - 2 * n - 1, self.depth - 3 * n - 1}
+    outs = []
+    B, _, D = x.shape
+    wide = torch.empty(B, x.shape[1], len(taps) * D, dtype=torch.bfloat16, device=x.device) if taps_side_by_side else None
+    for i, blk in enumerate(self.blocks):
+        nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None
+        x, n1 = blk.forward_fused(x, n1, nxt)
+        if i in taps:
+            k = len(outs)
+            outs.append(ops.add_layernorm(x, None, self.norm, out=None if wide is None else wide[:, :, k * D:(k + 1) * D]))
+    return outs if wide is None else wide
+
+
+ViT._fused_blocks = _vit_fused_blocks
 
 
 def interpolate_pos_embed(pos_embed_ckpt, new_side):
@@ -500,6 +516,34 @@ class PositionalEncoding(nn.Module):
             f1 = ops.pe_group_mlp_max(pts, self.r1, self.ns1, self.mlp1)  # (B,N,128)
             f2 = ops.pe_group_mlp_max(pts, self.r2, self.ns2, self.mlp2)
         return torch.cat([f1, f2], dim=2).float()
+
+    def split_ok(self, pts):
+        """Can the two scales be written straight into the split-layout operand of mlp3 (csrc/pe.hip -> csrc/gemm_f32.hip)?"""
+        return (pts.is_cuda and torch.is_autocast_enabled() and not ops.is_differentiable() and ops.USE_F32X3 and self.r2 >= self.r1
+                and self.ns1 % 32 == 0 and self.ns2 % 32 == 0 and self.mlp3.conv.weight.shape[0] % 256 == 0)
+
+    def groups_split(self, pts, buf, b0):
+        """`groups` of the clouds `pts` written into rows b0.. of `buf` ((Btot,N,512) bf16 = split layout of the (Btot,N,256) fp32
+        features): no concatenation of the scales, no fp32 round trip; two launches, no library kernel (side-stream safe)."""
+        pts = pts.float()
+        _, cand = ops.pe_group_mlp_max(pts, self.r2, self.ns2, self.mlp2, want_cand=True, out_split=(buf, b0, 128))
+        ops.pe_group_mlp_max(pts, self.r1, self.ns1, self.mlp1, cand_in=cand, out_split=(buf, b0, 0))
+        return buf
+
+    def project_add(self, buf, d):
+        """bf16( d + bf16(mlp3(groups)) ): the fp32-forced PE (Fi:163-165) added to the bf16 features (Fi:77-80), as the
+        epilogue of the fp32-class GEMM."""
+        conv = self.mlp3.conv
+        key = (conv.weight._version, conv.weight.data_ptr(), conv.bias._version)
+        cache = getattr(conv, "_f32x3_cache", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                cache = (key, ops.split_f32(conv.weight.detach().float().reshape(conv.weight.shape[0], -1).contiguous()),
+                         conv.bias.detach().float().contiguous())
+            conv._f32x3_cache = cache
+        rows = buf.shape[0] * buf.shape[1]
+        N, K = conv.weight.shape[0], buf.shape[2] // 2
+        return ops.linear_f32x3_bf16(buf, cache[1], cache[2], rows, N, K, resid=d.contiguous()).reshape(buf.shape[0], buf.shape[1], N)
 
     def project(self, feat):
         """mlp3 (Conv1d 256 -> out_dim, bias) on the concatenated scales; a library GEMM -> main stream only."""

@@ -157,10 +157,19 @@ class FinePointMatchingOneRef(nn.Module):
             # rides beside the dense features and is put in front only once, at the end
             # pe2_groups: the reference cloud's grouped features (PE before mlp3) when UNOPose.forward already
             # computed them under the coarse stage; mlp3 then runs HERE, on the main stream, as one 2B GEMM
-            pe = self.PE(torch.cat([p1_, p2], 0)) if pe2_groups is None else \
-                self.PE.project(torch.cat([self.PE.groups(p1_), pe2_groups], 0))
             d = ops.linear(f_all if f_all is not None else torch.cat([f1, f2], 0), self.in_proj)
-            d = d + pe.to(d.dtype)
+            if self.PE.split_ok(p1_) and d.dtype == torch.bfloat16 and (pe2_groups is None or isinstance(pe2_groups, tuple)):
+                # both scales of both clouds land in ONE split-layout buffer (the reference cloud's half possibly filled earlier, under
+                # the coarse stage); mlp3 runs on csrc/gemm_f32.hip with "+ d" in its epilogue
+                if pe2_groups is None:
+                    buf = self.PE.groups_split(torch.cat([p1_, p2], 0), torch.empty(2 * B, p2.shape[1], 512, dtype=torch.bfloat16, device=p2.device), 0)
+                else:
+                    buf = self.PE.groups_split(p1_, pe2_groups[1], 0)
+                d = self.PE.project_add(buf, d)
+            else:
+                pe = self.PE(torch.cat([p1_, p2], 0)) if pe2_groups is None else \
+                    self.PE.project(torch.cat([self.PE.groups(p1_), pe2_groups], 0))
+                d = d + pe.to(d.dtype)
             bg = self.bg_token.expand(2 * B, -1, -1).to(d.dtype)
             idx_all = torch.cat([fps_idx1, fps_idx2], 0).long()
             for blk in self.transformers:
@@ -288,14 +297,14 @@ class UNOPose(nn.Module):
         # both crops through the ViT as ONE batch of 2B images
         B = rgb.shape[0]
         if plan is not None:
-            acts = net.vit(torch.cat([rgb, tem_rgb], 0), taps_side_by_side=True)
+            acts = net.vit((rgb, tem_rgb), taps_side_by_side=True)
             if torch.is_tensor(acts) and acts.shape[1] == plan["tok_stride"]:
                 main.wait_stream(side)
                 both = ops.sparse_pixel_features(acts, net.output_upscaling, plan)  # query | reference, stacked
                 return dense_pm, both[:B], dense_po, both[B:], radius, pre
             z, (H, W), off = net.upproject(acts, rgb.shape[-2], rgb.shape[-1])
         else:
-            z, (H, W), off = net.upprojected_tokens(torch.cat([rgb, tem_rgb], 0))
+            z, (H, W), off = net.upproject(net.vit((rgb, tem_rgb), taps_side_by_side=True), rgb.shape[-2], rgb.shape[-1])
         # query | reference features land in ONE (2B,N,256) buffer: the fine matcher takes them stacked
         both = torch.empty(2 * B, choose.shape[1], 256, dtype=torch.float32, device=z.device) \
             if sel_choose.shape == choose.shape else None
@@ -452,8 +461,14 @@ class UNOPose(nn.Module):
             side = self._side_stream(dense_po.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                pe2 = self.fine_point_matching.PE.groups(dense_po)
-                pe2.record_stream(main)
+                PE = self.fine_point_matching.PE
+                if PE.split_ok(dense_po) and STACKED_FINE:
+                    buf = torch.empty(2 * B, dense_po.shape[1], 512, dtype=torch.bfloat16, device=dense_po.device)
+                    pe2 = ("split", PE.groups_split(dense_po, buf, B))
+                    buf.record_stream(main)
+                else:
+                    pe2 = PE.groups(dense_po)
+                    pe2.record_stream(main)
         end_points = self.coarse_point_matching(sparse_pm, sparse_fm, geo_m, sparse_po, sparse_fo, geo_o, radius,
                                                 end_points)
         if pe2 is not None:

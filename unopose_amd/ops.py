@@ -3,6 +3,7 @@
 Each function cites the reference Python it replaces.  Inputs must be CUDA
 float32 tensors; there is no CPU path (RuntimeError).
 """
+import ctypes
 import os
 
 import torch
@@ -222,6 +223,14 @@ def linear_f32x3(xs, ws, bias_f32, M, N, K, gelu=False, relu=False, out="f32"):
     return C if out == "f32" else (Cs if out == "split" else (C, Cs))
 
 
+def linear_f32x3_bf16(xs, ws, bias_f32, M, N, K, resid=None):
+    """C-ABI unopose_linear_f32x3_bf16: bf16( resid + bf16(X W^T + b) ) with X, W in the split layout."""
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=xs.device)
+    with torch.cuda.device(xs.device):
+        call("unopose_linear_f32x3_bf16", ptr(xs), ptr(ws), ptr(bias_f32), None if resid is None else ptr(resid), ptr(out), M, N, K, stream_ptr())
+    return out
+
+
 def _f32_path(x):
     return x.is_cuda and x.dtype == torch.float32 and not _DIFF and not torch.is_autocast_enabled()
 
@@ -326,6 +335,48 @@ def patch_embed(patches, conv):
         return linear_bf16_hip(a, cache[1], cache[2]).reshape(*patches.shape[:-1], D)
 
 
+def vit_prologue_ok(xa, vit):
+    """The fused ViT prologue (csrc/glue.hip) runs under autocast on the hand-written GEMM, for ViT-B (768 wide)."""
+    return (not _DIFF and xa.is_cuda and torch.is_autocast_enabled() and HIP_GEMM_ALL and USE_HIP_GEMM and xa.dtype == torch.float32
+            and vit.pos_embed.shape[-1] == 768 and xa.shape[-1] == xa.shape[-2] and xa.shape[-1] % 14 == 0
+            and vit.pos_embed.shape[1] == (xa.shape[-1] // 14) ** 2)
+
+
+def vit_prologue(xa, xb, vit, norm1):
+    """Both image batches (xb may be None) -> (x fp32 (n,T,768) residual stream, n1 = norm1(x) bf16): patch unfolding straight into
+    the zero-padded bf16 patch matrix, the patch-embedding GEMM (csrc/gemm.hip), then pos_embed / class + register tokens / first
+    LayerNorm in ONE pass.  Replaces cat([rgb, tem_rgb]) + unfold copy + zeros + cast copy + add + cat + LayerNorm."""
+    conv = vit.patch_embed.proj
+    w = conv.weight.reshape(conv.weight.shape[0], -1)
+    D, K = w.shape
+    Kp = (K + 63) // 64 * 64
+    key = (conv.weight._version, conv.weight.data_ptr(), Kp, vit.cls_token._version, vit.reg_token._version)
+    cache = getattr(conv, "_prologue_cache", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            wp = torch.zeros(D, Kp, dtype=torch.bfloat16, device=w.device)
+            wp[:, :K] = w.detach()
+            b = torch.zeros(D, device=w.device) if conv.bias is None else conv.bias.detach().float().contiguous()
+            prefix = torch.cat([vit.cls_token.detach().float().reshape(-1, D), vit.reg_token.detach().float().reshape(-1, D)], 0).contiguous()
+        cache = (key, wp, b, prefix)
+        conv._prologue_cache = cache
+    _, wp, b, prefix = cache
+    na, nb = xa.shape[0], 0 if xb is None else xb.shape[0]
+    S = xa.shape[-1]
+    P = (S // 14) ** 2
+    npre = prefix.shape[0]
+    dev = xa.device
+    with torch.autocast("cuda", enabled=False), torch.cuda.device(dev):
+        a = torch.empty((na + nb) * P, Kp, dtype=torch.bfloat16, device=dev)
+        call("unopose_patchify_bf16", ptr(_c(xa)), na, None if xb is None else ptr(_c(xb)), nb, S, Kp, ptr(a), stream_ptr())
+        y = linear_bf16_hip(a, wp, b)
+        x = torch.empty(na + nb, npre + P, D, dtype=torch.float32, device=dev)
+        n1 = torch.empty(na + nb, npre + P, D, dtype=torch.bfloat16, device=dev)
+        call("unopose_vit_tokens_layernorm", ptr(y), ptr(vit.pos_embed.detach().float().contiguous()), ptr(prefix), npre, P, na + nb, D,
+             ptr(norm1.weight.detach()), ptr(norm1.bias.detach()), float(norm1.eps), ptr(x), ptr(n1), stream_ptr())
+    return x, n1
+
+
 def rigid_rows(p, t, R):
     """(p - t) @ R for row-vector points p (B,N,3), t (B,3), R (B,3,3) (Fi:69).  Under autocast the reference's `@` is a
     bf16 bmm (operands rounded to bf16, fp32 accumulation, bf16 result); here the same arithmetic as three broadcast
@@ -347,11 +398,20 @@ def score_head(x, lin):
     if _DIFF or not (HIP_GEMM_ALL and x.is_cuda and torch.is_autocast_enabled()):
         return lin(x)
     with torch.autocast("cuda", enabled=False):
-        w = lin.weight.detach().to(torch.bfloat16).float().reshape(-1)
-        y = (x.float() * w).sum(-1, keepdim=True)
-        if lin.bias is not None:
-            y = y + lin.bias.detach().float()
-        return y.to(torch.bfloat16)
+        key = (lin.weight._version, lin.weight.data_ptr(), None if lin.bias is None else lin.bias._version)
+        cache = getattr(lin, "_rowdot_cache", None)
+        if cache is None or cache[0] != key:
+            cache = (key, lin.weight.detach().to(torch.bfloat16).float().reshape(-1).contiguous(),
+                     0.0 if lin.bias is None else float(lin.bias.detach().float().item()))
+            lin._rowdot_cache = cache
+        if x.shape[-1] == 256 and x.dtype in (torch.bfloat16, torch.float32):
+            xc = _c(x)
+            out = torch.empty(*x.shape[:-1], 1, dtype=torch.bfloat16, device=x.device)
+            with torch.cuda.device(x.device):
+                call("unopose_row_dot", ptr(xc), int(x.dtype == torch.bfloat16), ptr(cache[1]), cache[2], xc.numel() // 256, 256, ptr(out), 1,
+                     stream_ptr())
+            return out
+        return ((x.float() * cache[1]).sum(-1, keepdim=True) + cache[2]).to(torch.bfloat16)
 
 
 def gather_rows(feats, idx):
@@ -818,14 +878,16 @@ def focused_linear_attention_torch(xq, xkv, att, heads, focusing):
     return x.reshape(B, i, C).to(dt)
 
 
-def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None, cand_in=None, want_cand=False):
+def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None, cand_in=None, want_cand=False, out_split=None):
     """QueryAndLRFGroup -> SharedMLP[6,32,64,128] -> max over neighbours (fine matcher PE, Fi:167-174)
     as ONE HIP kernel (csrc/pe.hip): neighbour lists, frames and all MLP activations stay on chip;
     (B,N,3) -> (B,N,128) fp32.  Matrix-core precision: exact fp32 MFMA by default; under autocast(bf16)
     (or bf16x3=True) bf16 MFMA with hi/lo-split operands (~2^-16 relative error, ~5x the fp32 MFMA rate).
     Neighbour-list hand-off (bf16x3 kernel only): `want_cand=True` also returns (lists (B,N,nsample) int32,
     counts (B,N) int32) of this pass; passing such a pair from a LARGER-radius pass over the same points as
-    `cand_in` lets this pass test those candidates instead of scanning the cloud (same result)."""
+    `cand_in` lets this pass test those candidates instead of scanning the cloud (same result).
+    `out_split` = (buf (Btot,N,2W) bf16 viewed as the split layout of a W-wide fp32 row, first cloud b0, first channel c0):
+    the 128 channels go straight into that operand of csrc/gemm_f32.hip (bf16x3 kernel only); returns buf."""
     if bf16x3 is None:
         bf16x3 = torch.is_autocast_enabled()
     if [tuple(l.conv.weight.shape[:2]) for l in mlp.layers()] != [(32, 6), (64, 32), (128, 64)] or nsample % 32:
@@ -850,8 +912,23 @@ def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None, cand_in=None, want_
         cache = (key, flat, image)
         mlp._hip_cache = cache
     w1, b1, w2, b2, w3, b3 = cache[1]
-    out = torch.empty(B, N, 128, dtype=torch.float32, device=pts.device)
     cand_out = None
+    if out_split is not None:
+        buf, b0, c0 = out_split
+        assert bf16x3 and buf.dtype == torch.bfloat16 and buf.is_contiguous() and buf.shape[1] == N and c0 % 32 == 0 and b0 + B <= buf.shape[0]
+        ld = buf.shape[2] // 2  # row width in 4-byte units
+        with torch.cuda.device(pts.device):
+            if want_cand:
+                cand_out = (torch.empty(B, N, int(nsample), dtype=torch.int32, device=pts.device),
+                            torch.empty(B, N, dtype=torch.int32, device=pts.device))
+            ci = cand_in if cand_in is not None else (None, None)
+            dst = ctypes.c_void_p(buf.data_ptr() + (b0 * N * ld + c0) * 4)
+            call("unopose_pe_group_mlp_max_packed_out", ptr(pts), B, N, float(radius), int(nsample), ptr(cache[2]),
+                 None if ci[0] is None else ptr(ci[0]), None if ci[0] is None else ptr(ci[1]),
+                 0 if ci[0] is None else int(ci[0].shape[2]), None if cand_out is None else ptr(cand_out[0]),
+                 None if cand_out is None else ptr(cand_out[1]), dst, ld, 1, stream_ptr())
+        return (buf, cand_out) if want_cand else buf
+    out = torch.empty(B, N, 128, dtype=torch.float32, device=pts.device)
     with torch.cuda.device(pts.device):
         if bf16x3:
             if want_cand:
