@@ -345,8 +345,12 @@ int unopose_vit_tokens_layernorm(const void *patch, const float *pos, const floa
  * (oneref_predator_coarse_point_matching.py:66, ..._fine_point_matching.py:89). */
 int unopose_row_dot(const void *x, int x_bf16, const float *w, float b, long rows, int C, void *out, int out_bf16,
                     unopose_stream_t stream);
-/* out (B, N+1, row) = [first (B,1,row) | rest (B,N,row)]: the background token in front of the dense features (Fi:75-83). */
-int unopose_prepend_row(const void *first, const void *rest, long B, long N, int row_bytes, void *out, unopose_stream_t stream);
+/* out[r,:] = bf16( x[r,:] / max(||x[r,:]||_2, 1e-12) / temp ) for 256-wide rows: the operands of compute_feature_similarity
+ * (core/unopose/utils/model_utils.py:260-282) as the fine assignment reads them. */
+int unopose_normalize_rows_bf16(const void *x, int x_bf16, long rows, int C, float temp, void *out, unopose_stream_t stream);
+/* vt (B, C, pad) bf16: vt[b,c,j] = v[b,j,c] (rows of v `ld` elements apart), zero for m <= j < pad: the value image of
+ * unopose_token_attention. */
+int unopose_transpose_pad_bf16(const void *v, long ld, int B, int m, int C, int pad, void *vt, unopose_stream_t stream);
 
 /* nn.Linear on bf16 data with a fused epilogue (timm ViT blocks: qkv / proj / fc1 + GELU / fc2, and the
  * up-projection of oneref_feature_extraction.py:221):

@@ -1,0 +1,116 @@
+"""GPU: the single-pass glue kernels of csrc/glue.hip (and the placed / split outputs of csrc/pe.hip, the bf16 + residual epilogue of
+csrc/gemm_f32.hip) against the torch op chains they replace -- bit-exact where the arithmetic is the same, else at the result's
+own resolution."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _vit(side=16):
+    from unopose_amd.model.modules import ViT
+
+    torch.manual_seed(0)
+    v = ViT(768, 12, 12, 14, 14 * side).cuda().eval()
+    with torch.no_grad():
+        for p in v.parameters():
+            p.normal_(0, 0.05)
+        for b in v.blocks:
+            b.norm1.weight.add_(1.0)
+            b.norm2.weight.add_(1.0)
+        v.norm.weight.add_(1.0)
+    return v
+
+
+@torch.no_grad()
+def test_vit_prologue_equals_the_torch_chain():
+    """patchify -> patch GEMM -> pos_embed / prefix tokens / first LayerNorm vs unfold + zero-pad + GEMM + add + cat + LayerNorm."""
+    from unopose_amd import ops
+
+    v = _vit()
+    g = torch.Generator().manual_seed(1)
+    xa, xb = torch.randn(3, 3, 224, 224, generator=g).cuda(), torch.randn(2, 3, 224, 224, generator=g).cuda()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert ops.vit_prologue_ok(xa, v)
+        x, n1 = ops.vit_prologue(xa, xb, v, v.blocks[0].norm1)
+        xx = torch.cat([xa, xb], 0)
+        patches = xx.reshape(5, 3, 16, 14, 16, 14).permute(0, 2, 4, 1, 3, 5).reshape(5, 256, 588)
+        y = ops.patch_embed(patches, v.patch_embed.proj) + v.pos_embed
+        y = torch.cat([v.cls_token.expand(5, -1, -1), v.reg_token.expand(5, -1, -1), y], 1)
+    assert x.dtype == torch.float32 and torch.equal(x, y)  # same GEMM, same sums
+    ref = F.layer_norm(y, (768,), v.blocks[0].norm1.weight, v.blocks[0].norm1.bias, 1e-6)
+    assert n1.dtype == torch.bfloat16 and ((n1.float() - ref).abs() <= ref.abs() * 2.0 ** -8 + 1e-3).all()
+    # one batch alone: the same kernels with nb = 0
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        x1, _ = ops.vit_prologue(xb, None, v, v.blocks[0].norm1)
+    assert (x1 - x[3:]).abs().max().item() < 0.05  # (another tile walk of the GEMM: bf16 rounding flips only)
+
+
+@torch.no_grad()
+def test_vit_forward_pair_equals_concatenated_batch():
+    from unopose_amd import ops
+
+    v = _vit()
+    g = torch.Generator().manual_seed(2)
+    xa, xb = torch.randn(2, 3, 224, 224, generator=g).cuda(), torch.randn(2, 3, 224, 224, generator=g).cuda()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        pair = v((xa, xb), taps_side_by_side=True)
+        cat = v(torch.cat([xa, xb], 0), taps_side_by_side=True)
+    assert torch.equal(pair, cat)
+
+
+@torch.no_grad()
+def test_row_dot_normalize_transpose_pad():
+    from unopose_amd import ops
+    from unopose_amd._lib import call, ptr, stream_ptr
+
+    g = torch.Generator().manual_seed(3)
+    f = torch.randn(7, 300, 256, generator=g).cuda()
+    lin = torch.nn.Linear(256, 1).cuda()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        for x in (f, f.bfloat16()):
+            s = ops.score_head(x, lin)
+            ref = (x.float() * lin.weight.detach().bfloat16().float().reshape(-1)).sum(-1, keepdim=True) + lin.bias.detach().float()
+            assert s.shape == (7, 300, 1) and s.dtype == torch.bfloat16
+            assert ((s.float() - ref).abs() <= ref.abs() * 2.0 ** -8 + 1e-5).all()
+    for x in (f, f.bfloat16()):
+        n = ops.normalize_rows_bf16(x, 0.1)
+        ref = F.normalize(x.float(), p=2, dim=2) / 0.1
+        assert n.dtype == torch.bfloat16 and ((n.float() - ref).abs() <= ref.abs() * 2.0 ** -8 + 1e-6).all()
+    assert torch.equal(ops.normalize_rows_bf16(torch.zeros(2, 3, 256, device="cuda"), 0.1), torch.zeros(2, 3, 256, device="cuda", dtype=torch.bfloat16))
+    y = torch.randn(5, 197, 768, generator=g).cuda().bfloat16()  # q | k | v side by side, v = the last 256 columns
+    vt = torch.full((5, 256, 256), 7.0, device="cuda", dtype=torch.bfloat16)
+    import ctypes
+    call("unopose_transpose_pad_bf16", ctypes.c_void_p(y.data_ptr() + 512 * 2), y.stride(1), 5, 197, 256, 256, ptr(vt), stream_ptr())
+    assert torch.equal(vt[:, :, :197], y[..., 512:].transpose(1, 2)) and (vt[:, :, 197:] == 0).all()
+
+
+@torch.no_grad()
+def test_pe_split_output_and_mlp3_epilogue():
+    """Both PE scales written straight into the split-layout operand = the fp32 outputs, split; mlp3 on the fp32-class GEMM with the bf16
+    residual add = the reference's  d + PE(p).to(bf16)  at bf16 resolution."""
+    from unopose_amd import ops
+    from unopose_amd.model import UNOPose, default_model_cfg
+    from unopose_amd.synthetic import trained_like_
+
+    torch.manual_seed(0)
+    model = trained_like_(UNOPose(default_model_cfg())).cuda().eval()
+    PE = model.fine_point_matching.PE
+    g = torch.Generator().manual_seed(5)
+    pts = (torch.randn(3, 512, 3, generator=g) * 0.2).cuda()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert PE.split_ok(pts)
+        ref_groups = PE.groups(pts)  # (3,512,256) fp32
+        buf = torch.zeros(4, 512, 512, dtype=torch.bfloat16, device="cuda")
+        PE.groups_split(pts, buf, 1)
+        assert (buf[0] == 0).all()
+        blk = buf[1:].reshape(3, 512, 8, 2, 32).float()
+        hi, lo = blk[:, :, :, 0].reshape(3, 512, 256), blk[:, :, :, 1].reshape(3, 512, 256)
+        assert torch.equal(hi, ref_groups.bfloat16().float()) and ((hi + lo - ref_groups).abs() <= ref_groups.abs() * 2.0 ** -16).all()
+        d = torch.randn(3, 512, 256, generator=g).cuda().bfloat16()
+        out = PE.project_add(buf[1:].contiguous(), d)
+        ref = d + PE.project(ref_groups).to(torch.bfloat16)
+    assert out.dtype == torch.bfloat16 and out.shape == ref.shape
+    assert ((out.float() - ref.float()).abs() <= ref.float().abs() * 2.0 ** -7 + 2e-3).all()
+    assert (out != ref).float().mean().item() < 0.02  # the same two roundings; a flip where the fp32-class sums differ in the last bits

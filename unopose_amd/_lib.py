@@ -61,7 +61,8 @@ SIGNATURES = {
     "unopose_patchify_bf16": [_P, _I, _P, _I, _I, _I, _P, _P],
     "unopose_vit_tokens_layernorm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P],
     "unopose_row_dot": [_P, _I, _P, _F, ctypes.c_long, _I, _P, _I, _P],
-    "unopose_prepend_row": [_P, _P, ctypes.c_long, ctypes.c_long, _I, _P, _P],
+    "unopose_normalize_rows_bf16": [_P, _I, ctypes.c_long, _I, _F, _P, _P],
+    "unopose_transpose_pad_bf16": [_P, ctypes.c_long, _I, _I, _I, _I, _P, _P],
     "unopose_split_bf16x2": [_P, ctypes.c_long, _I, _P, _P],
     "unopose_linear_f32x3": [_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P],
     "unopose_pe_image_bytes": [],

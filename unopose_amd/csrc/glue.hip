@@ -5,7 +5,8 @@
 //   * vit_tokens_layernorm: patch GEMM output + pos_embed, class / register tokens in front (timm _pos_embed, no_embed_class)
 //                           and the first block's LayerNorm in the same pass (was add + cat + LayerNorm)
 //   * row_dot:              the overlap-score heads nn.Linear(256, 1) (C:66, Fi:89) as a row dot product
-//   * prepend_row:          [bg | dense] (B, N + 1, C) assembly (Fi:75-83) in one pass
+//   * normalize_rows:       F.normalize(f) / temp -> bf16 operands of the fine assignment (model_utils.py:260-282)
+//   * transpose_pad:        the channel-major zero-padded V image the token attention reads (was zeros + strided copy)
 #include <algorithm>
 
 #include "common.h"
@@ -117,15 +118,40 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const void *__restrict__ x
   }
 }
 
-// ---- out (B, N + 1, C) = [first (B, 1, C) | rest (B, N, C)], 16-byte units (C * elem_size % 16 == 0)
-__global__ __launch_bounds__(256) void prepend_row_kernel(const uint4 *__restrict__ first, const uint4 *__restrict__ rest, long B, long N,
-                                                          int row16, uint4 *__restrict__ out) {
-  const long total = B * (N + 1) * row16;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long row = i / row16;
-    const int c = (int)(i - row * row16);
-    const long b = row / (N + 1), t = row - b * (N + 1);
-    out[i] = t == 0 ? first[b * row16 + c] : rest[(b * N + t - 1) * row16 + c];
+// ---- out[r, :] = bf16( x[r, :] / max(||x[r, :]||, 1e-12) / temp )   (F.normalize(f, p=2, dim=-1) / temp of
+//      compute_feature_similarity, model_utils.py:260-282), 256-wide rows, one wavefront per row
+template <bool X_BF16>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const void *__restrict__ x, long rows, float temp, u16 *__restrict__ out) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float4 v;
+  if (X_BF16) {
+    const uint2 h = *reinterpret_cast<const uint2 *>(reinterpret_cast<const u16 *>(x) + (size_t)r * 256 + lane * 4);
+    v = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+  } else {
+    v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(x) + (size_t)r * 256 + lane * 4);
+  }
+  const float nrm = fmaxf(sqrtf(wave_sum_f32((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w))), 1e-12f);
+  const float y0 = v.x / nrm / temp, y1 = v.y / nrm / temp, y2 = v.z / nrm / temp, y3 = v.w / nrm / temp;
+  *reinterpret_cast<uint2 *>(out + (size_t)r * 256 + lane * 4) = make_uint2(cvt_pk_bf16_f32(y0, y1), cvt_pk_bf16_f32(y2, y3));
+}
+
+// ---- vt[b, c, j] = v[b, j, c] for j < m, 0 for m <= j < pad   (the channel-major, zero-padded V image of csrc/attn.hip;
+//      v rows `ld` elements apart inside the k | v projection output).  One workgroup per (64 channels, cloud).
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const u16 *__restrict__ v, long ld, int m, int C, int pad, u16 *__restrict__ vt) {
+  extern __shared__ u16 tile[];  // [64][pad + 2]
+  const int b = blockIdx.y, c0 = blockIdx.x * 64, tp = pad + 2;
+  const u16 *src = v + (size_t)b * m * ld + c0;
+  for (int i = threadIdx.x; i < 64 * pad; i += 256) {
+    const int j = i >> 6, c = i & 63;
+    tile[c * tp + j] = j < m ? src[(size_t)j * ld + c] : (u16)0;
+  }
+  __syncthreads();
+  u16 *dst = vt + ((size_t)b * C + c0) * pad;
+  for (int i = threadIdx.x; i < 64 * (pad / 2); i += 256) {
+    const int c = i / (pad / 2), j2 = (i - c * (pad / 2)) * 2;
+    *reinterpret_cast<uint32_t *>(dst + (size_t)c * pad + j2) = (uint32_t)tile[c * tp + j2] | ((uint32_t)tile[c * tp + j2 + 1] << 16);
   }
 }
 
@@ -164,14 +190,21 @@ int unopose_row_dot(const void *x, int x_bf16, const float *w, float b, long row
   return check_launch("row_dot");
 }
 
-int unopose_prepend_row(const void *first, const void *rest, long B, long N, int row_bytes, void *out, unopose_stream_t stream) {
-  UNOPOSE_REQUIRE(first && rest && out, "prepend_row: null pointer");
-  UNOPOSE_REQUIRE(B >= 1 && N >= 0 && row_bytes >= 16 && row_bytes % 16 == 0, "prepend_row: row bytes must be a multiple of 16 (got %d)", row_bytes);
-  const long total = B * (N + 1) * (row_bytes / 16);
-  const int grid = (int)std::min<long>((total + 255) / 256, 256 * 8);
-  hipLaunchKernelGGL(prepend_row_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4 *)first, (const uint4 *)rest, B, N,
-                     row_bytes / 16, (uint4 *)out);
-  return check_launch("prepend_row");
+int unopose_normalize_rows_bf16(const void *x, int x_bf16, long rows, int C, float temp, void *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(x && out, "normalize_rows_bf16: null pointer");
+  UNOPOSE_REQUIRE(C == 256 && rows >= 1 && temp > 0.f, "normalize_rows_bf16: built for C = 256 (got %d)", C);
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (x_bf16) hipLaunchKernelGGL(normalize_rows_kernel<true>, grid, block, 0, (hipStream_t)stream, x, rows, temp, (u16 *)out);
+  else hipLaunchKernelGGL(normalize_rows_kernel<false>, grid, block, 0, (hipStream_t)stream, x, rows, temp, (u16 *)out);
+  return check_launch("normalize_rows_bf16");
+}
+
+int unopose_transpose_pad_bf16(const void *v, long ld, int B, int m, int C, int pad, void *vt, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(v && vt, "transpose_pad_bf16: null pointer");
+  UNOPOSE_REQUIRE(B >= 1 && m >= 1 && m <= pad && pad % 2 == 0 && pad <= 1024 && C % 64 == 0 && ld >= C, "transpose_pad_bf16: bad shape (m=%d pad=%d C=%d)", m, pad, C);
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3(C / 64, B), dim3(256), (size_t)64 * (pad + 2) * 2, (hipStream_t)stream, (const u16 *)v, ld, m, C,
+                     pad, (u16 *)vt);
+  return check_launch("transpose_pad_bf16");
 }
 
 }  // extern "C"

@@ -667,7 +667,6 @@ def token_attention(x, mem, att, heads, embed=None):
 def _token_attention_hip_f32(x, mem, att, embed):
     """fp32 path: same kernel scheme with hi/lo-split bf16 MFMAs (csrc/attn_f32.hip); projections in
     fp32 with the RPE fold baked into the weights (exact algebra, fp32 rounding)."""
-    import ctypes
 
     B, n, C = x.shape
     m = mem.shape[1]
@@ -747,14 +746,14 @@ def _token_attention_hip(x, mem, att, embed):
             yq = bf16_linear_2d(xb.reshape(B * n, C), w_q, bq32, b_q).reshape(B, n, -1)
             ykv = bf16_linear_2d(mem.to(bf).reshape(B * m, C), w_kv, bkv32, b_kv).reshape(B, m, -1)
     # q | qp and k | v are consumed in place from the projection outputs (row strides passed to the kernel)
-    vt = torch.zeros(B, C, _KEY_PAD, dtype=bf, device=x.device)
-    vt[:, :, :m] = ykv[..., C:].transpose(1, 2)
+    vt = torch.empty(B, C, _KEY_PAD, dtype=bf, device=x.device)
+    with torch.cuda.device(x.device):
+        call("unopose_transpose_pad_bf16", ctypes.c_void_p(ykv.data_ptr() + C * 2), ykv.stride(1), B, m, C, _KEY_PAD, ptr(vt), stream_ptr())
     E = _c(embed.to(bf)) if rpe else None
     out = torch.empty(B, n, C, dtype=bf, device=x.device)
     esz = 2
     q_ptr = yq.data_ptr()
     k_ptr = ykv.data_ptr()
-    import ctypes
     with torch.cuda.device(x.device):
         call("unopose_token_attention", ctypes.c_void_p(q_ptr), yq.stride(1), ctypes.c_void_p(k_ptr), ykv.stride(1),
              ptr(vt), ctypes.c_void_p(q_ptr + C * esz) if rpe else None, yq.stride(1),
@@ -1120,6 +1119,17 @@ def fine_pose_fused_ok(f1, f2):
             and f2.shape[-1] == 256)
 
 
+def normalize_rows_bf16(f, temp):
+    """bf16(F.normalize(f.float(), dim=-1) / temp) in one pass (csrc/glue.hip); f (...,256) bf16 or fp32."""
+    if f.shape[-1] != 256 or f.dtype not in (torch.bfloat16, torch.float32):
+        return _c((F.normalize(f.float(), p=2, dim=-1) / temp).to(torch.bfloat16))
+    fc = _c(f)
+    out = torch.empty(f.shape, dtype=torch.bfloat16, device=f.device)
+    with torch.cuda.device(f.device):
+        call("unopose_normalize_rows_bf16", ptr(fc), int(f.dtype == torch.bfloat16), fc.numel() // 256, 256, float(temp), ptr(out), stream_ptr())
+    return out
+
+
 def fine_pose_from_features(f1, f2, temp, score, pts1, pts2, dis_thres=0.15):
     """compute_feature_similarity (cosine, /temp; model_utils.py:260-282) + compute_fine_Rt_overlap (:527-566) with the
     similarity recomputed tile by tile inside the three reduction passes instead of stored: f1 (B,N1+1,256), f2
@@ -1128,8 +1138,7 @@ def fine_pose_from_features(f1, f2, temp, score, pts1, pts2, dis_thres=0.15):
     B, N1, _ = pts1.shape
     N2 = pts2.shape[1]
     assert f1.shape == (B, N1 + 1, 256) and f2.shape == (B, N2 + 1, 256)
-    a = _c((F.normalize(f1.float(), p=2, dim=2) / temp).to(torch.bfloat16))
-    b = _c(F.normalize(f2.float(), p=2, dim=2).to(torch.bfloat16))
+    a, b = normalize_rows_bf16(f1, temp), normalize_rows_bf16(f2, 1.0)
     pts1, pts2 = _c(pts1.float()), _c(pts2.float())
     score1, score2 = _c(score[:, :N1].float()), _c(score[:, N1:].float())
     dev = pts1.device
