@@ -362,6 +362,12 @@ int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C
                         int epilogue, unopose_stream_t stream);
 int unopose_gemm_bf16_tile(void);
 
+/* Small batched float32 contraction on the exact-fp32 matrix instruction (an fma chain, one rounding per product):
+ *     C[(bo,bi)][i][j] = alpha * sum_k A[bo sab + bi sah + i sai + k sak] * Bm[bo sbb + bi sbh + j sbj + k sbk],  C (bo*bi, n, m) row-major.
+ * The coarse feature similarity (model_utils.py:260-282), the focused linear attention's k^T v (transformer.py:560-566). */
+int unopose_bmm_f32(const float *A, long sab, long sah, long sai, long sak, const float *Bm, long sbb, long sbh, long sbj, long sbk,
+                    float *C, int bo, int bi, int n, int m, int K, float alpha, unopose_stream_t stream);
+
 /* nn.Linear on float32 data (the reference's default precision, configs/main_cfg.py:87-89) with fp32-class accuracy on the
  * bf16 matrix cores: every operand is split into hi + lo bf16 parts and a product is three MFMAs (ah wh + ah wl + al wh,
  * fp32 accumulation; relative error ~2^-17 per product).  Operands come in the SPLIT layout -- row r, k-block j (32 k) is

@@ -114,3 +114,22 @@ def test_pe_split_output_and_mlp3_epilogue():
     assert out.dtype == torch.bfloat16 and out.shape == ref.shape
     assert ((out.float() - ref.float()).abs() <= ref.float().abs() * 2.0 ** -7 + 2e-3).all()
     assert (out != ref).float().mean().item() < 0.02  # the same two roundings; a flip where the fp32-class sums differ in the last bits
+
+
+@torch.no_grad()
+def test_bmm_f32_strided_contractions():
+    """csrc/bmm_f32.hip vs float64 einsum: the coarse similarity shape (K-contiguous operands), the linear attention's k^T v
+    ((pair, head) batches read in place, contraction index strided) and a ragged shape."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    a, b = torch.randn(6, 197, 256, generator=g).cuda(), torch.randn(6, 197, 256, generator=g).cuda()
+    c = ops.bmm_nt_f32(a, b, 10.0)
+    ref = torch.einsum("bik,bjk->bij", a.double(), b.double()) * 10.0
+    assert c.shape == (6, 197, 197) and (c.double() - ref).abs().max().item() < 2e-4 * 10
+    v, k = torch.randn(3, 196, 256, generator=g).cuda(), torch.rand(3, 196, 256, generator=g).cuda()
+    kvt = ops.bmm_nt_f32(v.reshape(3, 196, 4, 64).permute(0, 2, 3, 1), k.reshape(3, 196, 4, 64).permute(0, 2, 3, 1))
+    ref = torch.einsum("bjhd,bjhc->bhdc", v.double().reshape(3, 196, 4, 64), k.double().reshape(3, 196, 4, 64))
+    assert kvt.shape == (3, 4, 64, 64) and kvt.is_contiguous() and (kvt.double() - ref).abs().max().item() < 1e-4
+    x, r = torch.randn(2, 33, 3, generator=g).cuda(), torch.randn(2, 3, 3, generator=g).cuda()
+    assert (ops.bmm_nt_f32(x, r.transpose(1, 2)) - x @ r).abs().max().item() < 1e-5

@@ -141,11 +141,14 @@ def test_runner_with_pipelined_chunks_writes_the_same_lines(model, tmp_path):
 
 
 @torch.no_grad()
-def test_no_library_bf16_gemm_on_the_autocast_path(model):
-    """Regression guard for DESIGN.md section 7 (library bf16 GEMM kernels corrupt registers of kernels running beside them):
-    during an eval forward under autocast no torch matmul-class op may run on bf16 data -- i.e. be called with autocast
-    enabled (which casts fp32 operands to bf16) or with bf16 operands.  fp32 contractions inside autocast-disabled regions
-    are allowed (PE mlp3, coarse similarity, the linear attention's k^T v)."""
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_no_library_gemm_on_the_eval_path(model, precision):
+    """Regression guard for DESIGN.md section 7 (library bf16 GEMM kernels corrupt registers of kernels running beside them; the
+    fp32 library SGEMM runs at a third of csrc/gemm_f32.hip): during an eval forward NO torch matmul-class op may run on GPU data,
+    in either precision -- every contraction is a hand-written kernel (csrc/gemm.hip, gemm_f32.hip, bmm_f32.hip, the attention /
+    embedding / PE kernels).  Self-checking: with the own GEMMs switched off the guard must fire."""
+    import contextlib
+
     import torch.nn.functional as F
 
     offenders = []
@@ -157,42 +160,44 @@ def test_no_library_bf16_gemm_on_the_autocast_path(model):
         def wrapper(*a, **k):
             ts = [t for t in a if torch.is_tensor(t)]
             if ts and ts[0].is_cuda and ts[0].is_floating_point() and min(t.dim() for t in ts[:2]) >= 1:
-                if torch.is_autocast_enabled() or any(t.dtype == torch.bfloat16 for t in ts[:2]):
-                    offenders.append((name, [tuple(t.shape) for t in ts[:2]], [str(t.dtype) for t in ts[:2]], torch.is_autocast_enabled()))
+                offenders.append((name, [tuple(t.shape) for t in ts[:2]], [str(t.dtype) for t in ts[:2]], torch.is_autocast_enabled()))
             return orig(*a, **k)
 
         setattr(owner, name, wrapper)
         patched.append((owner, name, orig))
 
+    from unopose_amd import ops
+
+    ep = batches(1, B=2)[0]
+    ctx = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if precision == "bf16" else contextlib.nullcontext
+    with ctx():
+        model(dict(ep))  # builds the per-module weight caches (their one-off einsum / cat run outside the guarded forward)
     for owner, name in ((torch, "matmul"), (torch, "bmm"), (torch, "mm"), (torch, "addmm"), (torch, "baddbmm"), (torch, "einsum"),
                         (torch, "_addmm_activation"), (F, "linear"), (torch.Tensor, "__matmul__"), (torch.Tensor, "matmul")):
         guard(owner, name)
     lin_forward = torch.nn.Linear.forward
 
     def linear_forward(self, x):
-        if x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16):
+        if x.is_cuda:
             offenders.append(("nn.Linear.forward", tuple(x.shape), str(x.dtype), torch.is_autocast_enabled()))
         return lin_forward(self, x)
 
     torch.nn.Linear.forward = linear_forward
-    from unopose_amd import ops
-
     try:
-        ep = batches(1, B=2)[0]
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with ctx():
             model(dict(ep))
         clean = list(offenders)
         del offenders[:]
-        ops.HIP_GEMM_ALL = False  # the guard itself: with the library path switched back on it must fire
+        ops.HIP_GEMM_ALL, ops.USE_F32X3 = False, False  # the guard itself: with the library paths switched back on it must fire
         try:
-            with torch.autocast("cuda", dtype=torch.bfloat16):
+            with ctx():
                 model(dict(ep))
         finally:
-            ops.HIP_GEMM_ALL = True
+            ops.HIP_GEMM_ALL, ops.USE_F32X3 = True, True
         fired = len(offenders)
     finally:
         torch.nn.Linear.forward = lin_forward
         for owner, name, orig in patched:
             setattr(owner, name, orig)
-    assert not clean, clean[:5]
+    assert not clean, clean[:8]
     assert fired > 20

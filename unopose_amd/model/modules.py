@@ -530,9 +530,7 @@ class PositionalEncoding(nn.Module):
         ops.pe_group_mlp_max(pts, self.r1, self.ns1, self.mlp1, cand_in=cand, out_split=(buf, b0, 0))
         return buf
 
-    def project_add(self, buf, d):
-        """bf16( d + bf16(mlp3(groups)) ): the fp32-forced PE (Fi:163-165) added to the bf16 features (Fi:77-80), as the
-        epilogue of the fp32-class GEMM."""
+    def _mlp3_split(self):
         conv = self.mlp3.conv
         key = (conv.weight._version, conv.weight.data_ptr(), conv.bias._version)
         cache = getattr(conv, "_f32x3_cache", None)
@@ -541,14 +539,25 @@ class PositionalEncoding(nn.Module):
                 cache = (key, ops.split_f32(conv.weight.detach().float().reshape(conv.weight.shape[0], -1).contiguous()),
                          conv.bias.detach().float().contiguous())
             conv._f32x3_cache = cache
+        return cache
+
+    def project_add(self, buf, d):
+        """bf16( d + bf16(mlp3(groups)) ): the fp32-forced PE (Fi:163-165) added to the bf16 features (Fi:77-80), as the
+        epilogue of the fp32-class GEMM."""
+        cache = self._mlp3_split()
         rows = buf.shape[0] * buf.shape[1]
-        N, K = conv.weight.shape[0], buf.shape[2] // 2
+        N, K = self.mlp3.conv.weight.shape[0], buf.shape[2] // 2
         return ops.linear_f32x3_bf16(buf, cache[1], cache[2], rows, N, K, resid=d.contiguous()).reshape(buf.shape[0], buf.shape[1], N)
 
     def project(self, feat):
         """mlp3 (Conv1d 256 -> out_dim, bias) on the concatenated scales; a library GEMM -> main stream only."""
         w = self.mlp3.conv.weight.reshape(self.mlp3.conv.weight.shape[0], -1)
+        N, K = w.shape
+        rows = feat.numel() // K
         with torch.autocast("cuda", enabled=False):  # Fi:163-165 forces fp32 for the whole PE
+            if feat.is_cuda and not ops.is_differentiable() and ops.f32x3_ok(rows, N, K):
+                cache = self._mlp3_split()
+                return ops.linear_f32x3(ops.split_f32(feat.float().reshape(rows, K).contiguous()), cache[1], cache[2], rows, N, K).reshape(*feat.shape[:-1], N)
             return F.linear(feat, w.float(), self.mlp3.conv.bias.float())
 
     def forward(self, pts):

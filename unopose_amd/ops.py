@@ -231,6 +231,23 @@ def linear_f32x3_bf16(xs, ws, bias_f32, M, N, K, resid=None):
     return out
 
 
+def linear_f32_raw(x, w, b, owner, tag):
+    """x (...,K) fp32 @ w (N,K)^T + b with cached split weights on `owner` (the fp32 token / linear attention projections, whose
+    fused weight matrices are built by their callers); csrc/gemm_f32.hip when the shape fits, else the library."""
+    N, K = w.shape
+    rows = x.numel() // K
+    if not (x.is_cuda and not _DIFF and f32x3_ok(rows, N, K)):
+        return F.linear(x, w, b)
+    key = (w.data_ptr(), w._version, tag)
+    caches = owner.__dict__.setdefault("_f32x3_raw", {})
+    c = caches.get(tag)
+    if c is None or c[0] != key:
+        with torch.no_grad():
+            c = (key, split_f32(w.detach().float().contiguous()), torch.zeros(N, device=w.device) if b is None else b.detach().float().contiguous())
+        caches[tag] = c
+    return linear_f32x3(split_f32(_c(x.float()).reshape(rows, K)), c[1], c[2], rows, N, K).reshape(*x.shape[:-1], N)
+
+
 def _f32_path(x):
     return x.is_cuda and x.dtype == torch.float32 and not _DIFF and not torch.is_autocast_enabled()
 
@@ -317,6 +334,21 @@ def patch_embed(patches, conv):
     w = conv.weight.reshape(conv.weight.shape[0], -1)
     D, K = w.shape
     rows = patches.numel() // K
+    if _f32_path(patches) and f32x3_ok(rows, D, 32):
+        # fp32: K = 588 zero-padded to 608 (a multiple of the 32-wide stage of csrc/gemm_f32.hip)
+        Kp = (K + 31) // 32 * 32
+        key = (conv.weight._version, conv.weight.data_ptr(), Kp, "f32")
+        cache = getattr(conv, "_f32x3_pad_cache", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                wp = torch.zeros(D, Kp, dtype=torch.float32, device=w.device)
+                wp[:, :K] = w.detach()
+                b = torch.zeros(D, device=w.device) if conv.bias is None else conv.bias.detach().float().contiguous()
+                cache = (key, split_f32(wp), b)
+            conv._f32x3_pad_cache = cache
+        a = torch.zeros(rows, Kp, dtype=torch.float32, device=patches.device)
+        a[:, :K] = patches.reshape(rows, K)
+        return linear_f32x3(split_f32(a), cache[1], cache[2], rows, D, Kp).reshape(*patches.shape[:-1], D)
     if _DIFF or not (HIP_GEMM_ALL and patches.is_cuda and torch.is_autocast_enabled() and own_gemm_ok(rows, D, 64)):
         return F.linear(patches, w, conv.bias)
     Kp = (K + 63) // 64 * 64
@@ -377,11 +409,34 @@ def vit_prologue(xa, xb, vit, norm1):
     return x, n1
 
 
+def bmm_nt_f32(a, b, alpha=1.0):
+    """C[..., i, j] = alpha * sum_k a[..., i, k] b[..., j, k] on csrc/bmm_f32.hip (exact-fp32 MFMA, any strides): a (Bo,[Bi,]n,K),
+    b (Bo,[Bi,]m,K) fp32 views -> contiguous (Bo,[Bi,]n,m) fp32."""
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == b.dim() and a.dim() in (3, 4)
+    if a.dim() == 3:
+        a4, b4 = a.unsqueeze(1), b.unsqueeze(1)
+    else:
+        a4, b4 = a, b
+    Bo, Bi, n, K = a4.shape
+    m = b4.shape[2]
+    out = torch.empty(Bo, Bi, n, m, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        call("unopose_bmm_f32", ptr(a4), a4.stride(0), a4.stride(1), a4.stride(2), a4.stride(3), ptr(b4), b4.stride(0), b4.stride(1),
+             b4.stride(2), b4.stride(3), ptr(out), Bo, Bi, n, m, K, float(alpha), stream_ptr())
+    return out if a.dim() == 4 else out[:, 0]
+
+
+def _own_f32(x):
+    return x.is_cuda and not _DIFF and USE_F32X3
+
+
 def rigid_rows(p, t, R):
     """(p - t) @ R for row-vector points p (B,N,3), t (B,3), R (B,3,3) (Fi:69).  Under autocast the reference's `@` is a
     bf16 bmm (operands rounded to bf16, fp32 accumulation, bf16 result); here the same arithmetic as three broadcast
     multiply-adds, so that no library bf16 GEMM kernel is on the path (`own_gemm_ok`)."""
     x = p - t.unsqueeze(1)
+    if _own_f32(p) and not torch.is_autocast_enabled() and x.dtype == torch.float32:
+        return bmm_nt_f32(x, R.float().transpose(1, 2))  # (x @ R)[n, j] = sum_k x[n, k] R[k, j]
     if _DIFF or not (HIP_GEMM_ALL and p.is_cuda and torch.is_autocast_enabled()):
         return x @ R
     with torch.autocast("cuda", enabled=False):
@@ -395,6 +450,17 @@ def score_head(x, lin):
     """The overlap-score head nn.Linear(d, 1) (C:66, Fi:89).  One output channel is no GEMM shape for csrc/gemm.hip, and no
     library bf16 GEMM may be on the autocast path (`own_gemm_ok`): evaluated as a multiply + row sum in fp32 on the
     bf16-rounded weights, rounded to the dtype the autocast Linear would return."""
+    if _f32_path(x) and USE_F32X3 and x.shape[-1] == 256:  # fp32: the same row dot on the unrounded weights
+        key = (lin.weight._version, lin.weight.data_ptr(), None if lin.bias is None else lin.bias._version, "f32")
+        cache = getattr(lin, "_rowdot_cache_f32", None)
+        if cache is None or cache[0] != key:
+            cache = (key, lin.weight.detach().float().reshape(-1).contiguous(), 0.0 if lin.bias is None else float(lin.bias.detach().float().item()))
+            lin._rowdot_cache_f32 = cache
+        xc = _c(x)
+        out = torch.empty(*x.shape[:-1], 1, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            call("unopose_row_dot", ptr(xc), 0, ptr(cache[1]), cache[2], xc.numel() // 256, 256, ptr(out), 0, stream_ptr())
+        return out
     if _DIFF or not (HIP_GEMM_ALL and x.is_cuda and torch.is_autocast_enabled()):
         return lin(x)
     with torch.autocast("cuda", enabled=False):
@@ -687,8 +753,8 @@ def _token_attention_hip_f32(x, mem, att, embed):
                      torch.cat([att.proj_k.bias.float(), att.proj_v.bias.float()], 0).contiguous())
         att._hip_cache_f32 = cache
     _, w_q, b_q, w_kv, b_kv = cache
-    yq = F.linear(x, w_q, b_q)
-    ykv = F.linear(mem, w_kv, b_kv)
+    yq = linear_f32_raw(x, w_q, b_q, att, "q")
+    ykv = linear_f32_raw(mem, w_kv, b_kv, att, "kv")
     vt = torch.zeros(B, C, _KEY_PAD, dtype=torch.float32, device=x.device)
     vt[:, :, :m] = ykv[..., C:].transpose(1, 2)
     E = _c(embed.float()) if rpe else None
@@ -802,15 +868,19 @@ def _focused_linear_attention_hip_f32(xq, xkv, att, focusing):
             cache = (key, (1.0 / F.softplus(att.scale.float())).reshape(-1).contiguous())
         att._hip_cache_f32 = cache
     inv_sp = cache[1]
-    q = _c(att.proj_q(xq))
-    kproj = _c(att.proj_k(xkv))
-    v = att.proj_v(xkv)
+    q = _c(linear(xq, att.proj_q))
+    kproj = _c(linear(xkv, att.proj_k))
+    v = linear(xkv, att.proj_v)
     kf = torch.empty(B, j, C, dtype=torch.float32, device=xq.device)
     out = torch.empty(B, N, C, dtype=torch.float32, device=xq.device)
     with torch.cuda.device(xq.device):
         call("unopose_linear_attention_f32", ptr(kproj), ptr(inv_sp), None, None, B, j, focusing, 1, ptr(kf), stream_ptr())
         ksum = _c(kf.sum(dim=1))
-        kvt = _c(torch.einsum("bjhd,bjhc->bhdc", v.reshape(B, j, 4, 64), kf.reshape(B, j, 4, 64)))
+        if _own_f32(v) and v.dtype == torch.float32:
+            # kv_h^T[d][c] = sum_j v[j,h,d] k[j,h,c]: (pair, head) batches, both operands read in place (j strided)
+            kvt = bmm_nt_f32(v.reshape(B, j, 4, 64).permute(0, 2, 3, 1), kf.reshape(B, j, 4, 64).permute(0, 2, 3, 1))
+        else:
+            kvt = _c(torch.einsum("bjhd,bjhc->bhdc", v.reshape(B, j, 4, 64), kf.reshape(B, j, 4, 64)))
         call("unopose_linear_attention_f32", ptr(q), ptr(inv_sp), ptr(kvt), ptr(ksum), B, N, focusing, 0, ptr(out),
              stream_ptr())
     return out
@@ -843,7 +913,10 @@ def _focused_linear_attention_hip(xq, xkv, att, focusing):
         ksum = _c(kf32.sum(dim=1))  # (B,256)
         # kv_h^T[d][c] = sum_j v[j,h,d] k[j,h,c]   (fp32 contraction: autocast would turn it into a library bf16 GEMM)
         with torch.autocast("cuda", enabled=False):
-            kvt = _c(torch.einsum("bjhd,bjhc->bhdc", v.float().reshape(B, j, 4, 64), kf32.reshape(B, j, 4, 64)).to(bf))
+            if _own_f32(v):
+                kvt = bmm_nt_f32(v.float().reshape(B, j, 4, 64).permute(0, 2, 3, 1), kf32.reshape(B, j, 4, 64).permute(0, 2, 3, 1)).to(bf)
+            else:
+                kvt = _c(torch.einsum("bjhd,bjhc->bhdc", v.float().reshape(B, j, 4, 64), kf32.reshape(B, j, 4, 64)).to(bf))
         call("unopose_linear_attention", ptr(q), ptr(inv_sp), ptr(kvt), ptr(ksum), B, N, focusing, 0, ptr(out),
              stream_ptr())
     return out
@@ -976,10 +1049,14 @@ def feature_similarity(f1, f2, temp):
         with torch.autocast("cuda", enabled=False):
             return torch.bmm((a / temp).to(torch.bfloat16), b.to(torch.bfloat16).transpose(1, 2), out_dtype=torch.float32)
     if f1.is_cuda and torch.is_autocast_enabled():
-        # no library bf16 GEMM on the path (own_gemm_ok): the same bf16-rounded operands, multiplied by the fp32 library
+        # no library bf16 GEMM on the path (own_gemm_ok): the same bf16-rounded operands, multiplied by the exact-fp32 MFMA
         # kernel (exact products, fp32 sums -- what the bf16 bmm with fp32 output computes up to summation order)
         with torch.autocast("cuda", enabled=False):
+            if _own_f32(f1):
+                return bmm_nt_f32(normalize_rows_bf16(f1, temp).float(), normalize_rows_bf16(f2, 1.0).float())
             return torch.bmm((a / temp).to(torch.bfloat16).float(), b.to(torch.bfloat16).float().transpose(1, 2))
+    if _own_f32(f1) and a.dtype == torch.float32:
+        return bmm_nt_f32(_c(a), _c(b)) / temp
     return (a @ b.transpose(1, 2)) / temp
 
 
