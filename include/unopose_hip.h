@@ -331,6 +331,13 @@ int unopose_linear_attention_f32(const float *x, const float *inv_softplus_scale
                                  const float *ksum, int B, int N, int focus, int mode, float *out,
                                  unopose_stream_t stream);
 
+/* Depth maps of a triangle mesh in P poses (BOP's VSD error renders the object in the estimated and the ground-truth pose:
+ * third_party/bop_toolkit/bop_toolkit_lib/pose_error.py:17-101, renderer.render_object(...)["depth"]).  verts (V,3) float32, faces (F,3)
+ * int32, Rt (P,12) = row-major R then t (model -> camera, camera looks along +z), K4 (P,4) = fx, fy, cx, cy; integer pixel coordinates
+ * are pixel centres (misc.py:142-162); depth (P,H,W) float32 = z of the nearest surface, 0 where nothing projects. */
+int unopose_render_depth(const float *verts, int V, const int *faces, int F, const float *Rt, const float *K4, int P, int H, int W,
+                         float *depth, unopose_stream_t stream);
+
 /* ---- data-movement glue of the forward as single-pass kernels (csrc/glue.hip) ---------------------------------------------
  * patchify: the ViT's 14 x 14 / 14 patch unfolding (timm PatchEmbed, oneref_feature_extraction.py:24-27) of two image batches
  * (na + nb crops of (3,S,S) float32; rgb_b may be NULL with nb = 0) into the bf16 matrix ((na + nb) (S/14)^2, Kp) the

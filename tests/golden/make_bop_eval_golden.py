@@ -50,8 +50,61 @@ def main():
         recalls[kind] = recs
     out.update(recalls_mssd=recalls["mssd"], recalls_mspd=recalls["mspd"], AR_MSSD=float(np.mean(recalls["mssd"])),
                AR_MSPD=float(np.mean(recalls["mspd"])))
+    out["vsd"] = vsd_case()
     json.dump(out, open(os.path.join(HERE, "bop_eval.json"), "w"), indent=0)
     print({k: v for k, v in out.items() if k.startswith("AR") or k.startswith("recalls")})
+    print({k: v for k, v in out["vsd"].items() if k.startswith("AR")})
+
+
+def vsd_case():
+    """The toolkit's own pose_error.vsd / mssd / mspd, matching and scoring on tests/bop_eval_case.make_vsd_case, with the numpy
+    rasteriser of tests/raster_np.py as the toolkit's `renderer`: VSD errors per (estimate, ground truth, tau), the 10 x 10 recalls,
+    AR_VSD / AR_MSSD / AR_MSPD and the BOP'19 AR = their mean (scripts/eval_bop19_pose.py:17-44, 218-222)."""
+    from bop_eval_case import make_vsd_case
+    from raster_np import NumpyRenderer
+
+    models, scene_gt, cameras, results, im_width, depth_images, (W, H) = make_vsd_case()
+    ren = NumpyRenderer(W, H)
+    for oid, m in models.items():
+        ren.add_object(oid, m["verts"], m["faces"])
+        m["symmetries_bop"] = [dict(R=s["R"], t=s["t"].reshape(3, 1)) for s in m["symmetries"]]
+    taus = list(np.arange(0.05, 0.51, 0.05))
+    n_top = 1
+    errs = {"vsd": [], "mssd": [], "mspd": []}
+    for r in results:
+        m = models[r["obj_id"]]
+        K = cameras[r["scene_id"]][r["im_id"]]
+        e = {"vsd": {}, "mssd": {}, "mspd": {}}
+        for gid, g in enumerate(scene_gt[r["scene_id"]][r["im_id"]]):
+            if g["obj_id"] != r["obj_id"]:
+                continue
+            a = (r["R"], r["t"].reshape(3, 1), g["R"], g["t"].reshape(3, 1))
+            e["vsd"][gid] = [float(x) for x in pose_error.vsd(*a, depth_images[r["scene_id"]][r["im_id"]], K, 15.0, taus, True, m["diameter"], ren,
+                                                              r["obj_id"], "step")]
+            e["mssd"][gid] = [float(pose_error.mssd(*a, m["pts"], m["symmetries_bop"]) / m["diameter"])]
+            e["mspd"][gid] = [float(pose_error.mspd(*a, K, m["pts"], m["symmetries_bop"]) * 640.0 / im_width)]
+        for k in errs:
+            errs[k].append(e[k])
+
+    def recalls(kind, idx, ths):
+        scene_errs = {sid: [] for sid in scene_gt}
+        for est_id, (r, e) in enumerate(zip(results, errs[kind])):
+            scene_errs[r["scene_id"]].append(dict(im_id=r["im_id"], obj_id=r["obj_id"], est_id=est_id, score=r["score"],
+                                                  errors={gid: [v[idx]] for gid, v in e.items()}))
+        recs = []
+        for th in ths:
+            matches = []
+            for sid in scene_gt:
+                gt_valid = {iid: [g["valid"] for g in gts] for iid, gts in scene_gt[sid].items()}
+                matches += pose_matching.match_poses_scene(sid, scene_gt[sid], gt_valid, scene_errs[sid], [th], n_top)
+            recs.append(score.calc_localization_scores(list(scene_gt), list(models), matches, n_top, do_print=False)["recall"])
+        return recs
+
+    rec_v = [recalls("vsd", ti, np.arange(0.05, 0.51, 0.05)) for ti in range(len(taus))]
+    rec_s, rec_p = recalls("mssd", 0, np.arange(0.05, 0.51, 0.05)), recalls("mspd", 0, np.arange(5, 51, 5))
+    ar = [float(np.mean(rec_v)), float(np.mean(rec_s)), float(np.mean(rec_p))]
+    return dict(errors_vsd=[[e[k] for k in sorted(e)] for e in errs["vsd"]], recalls_vsd=rec_v, recalls_mssd=rec_s, recalls_mspd=rec_p,
+                AR_VSD=ar[0], AR_MSSD=ar[1], AR_MSPD=ar[2], AR=float(np.mean(ar)))
 
 
 if __name__ == "__main__":
