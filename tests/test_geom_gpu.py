@@ -60,6 +60,34 @@ def _well_conditioned(ref, radius):
     return (gap > 2e-2) & ((vote.abs() - near) >= 1) & (acc / scale > 1e-2)
 
 
+def _frame_invariants(out, ref, radius):
+    """What must hold for EVERY point whose frame exists, however ill-conditioned its neighbourhood: channels
+    3-5 are F^T (p_k - c) / r for ONE orthonormal frame F = [x, y, z] per point with y = x x z (P:470-471) -- a LEFT-handed frame,
+    det F = -1 -- so (i) every neighbour keeps its length, (ii) an orthogonal map of determinant -1 takes the relative coordinates onto
+    them, (iii) the z-axis is orthogonal to the dominant direction of the neighbourhood whenever that direction is defined (z = +-v_min;
+    any unit vector of span(v_0, v_1) if the two smallest eigenvalues tie).  The frame does NOT exist where the x-axis accumulator
+    vanishes (rank-deficient neighbourhoods: duplicated / collinear / coplanar points): the reference then emits x = y = 0, and such points
+    are compared with the reference output directly.  float64 throughout.
+    Returns (frame-exists mask, worst length error, worst residual of the fitted det -1 map, worst |z . v_max|) over the points with a frame."""
+    rel = ref[:, :3].double().permute(0, 2, 1, 3)            # (B,N,3,S)
+    o = out[:, 3:].double().permute(0, 2, 1, 3) * radius       # (B,N,3,S) = F^T (p_k - c)
+
+    def fit(o):
+        U, _, Vh = torch.linalg.svd(o @ rel.transpose(-1, -2))  # sum_k o_k rel_k^T
+        d = torch.det(U @ Vh)
+        Ft = U @ torch.diag_embed(torch.stack([torch.ones_like(d), torch.ones_like(d), -d], -1)) @ Vh  # the closest det -1 orthogonal map
+        return Ft, (o - Ft @ rel).abs().amax(dim=(2, 3))
+
+    # the frame exists where the REFERENCE output is an orthogonal image of the relative coordinates
+    exists = fit(ref[:, 3:].double().permute(0, 2, 1, 3) * radius)[1] < 5e-5  # (fp32 outputs: an existing frame fits to ~1e-5, a missing one misses by O(0.1))
+    Ft, resid = fit(o)
+    len_err = (o.norm(dim=2) - rel.norm(dim=2)).abs().amax(-1)
+    lam, vec = torch.linalg.eigh(rel @ rel.transpose(-1, -2) / rel.shape[-1])
+    constrained = exists & ((lam[..., 2] - lam[..., 1]) / lam[..., 2].clamp(min=1e-30) > 2e-2)
+    zdot = (Ft[..., 2, :] * vec[..., 2]).sum(-1).abs()
+    return exists, len_err[exists].max().item(), resid[exists].max().item(), zdot[constrained].max().item()
+
+
 def _check_group(out, ref, radius, expect_well, tol=2e-3):
     """`expect_well`: the well-conditioned fraction per cloud, a property of the REFERENCE output measured once
     (clouds sampled with replacement are full of duplicated neighbourhoods and score low); asserted as measured
@@ -77,6 +105,27 @@ def _check_group(out, ref, radius, expect_well, tol=2e-3):
     assert all(f >= e - 0.01 for f, e in zip(frac.tolist(), expect_well)), (frac.tolist(), expect_well)
     bad = (err >= tol) & well
     assert not bad.any(), f"{int(bad.sum())} well-conditioned points differ, worst {err[well].max().item():.3e}"
+    # ALL points, ill-conditioned ones included: the output is a proper rotation of the relative coordinates whose z-axis avoids the
+    # neighbourhood's dominant direction -- for the kernel AND (as a sanity check of the invariants) for the reference output
+    for name, x in (("kernel", out), ("reference", ref)):
+        exists, len_err, resid, zdot = _frame_invariants(x, ref, radius)
+        print(f"{name}: frame exists on {exists.double().mean().item():.3f} of ALL points; there |len| {len_err:.1e}, det -1 residual {resid:.1e}, "
+              f"|z.v_max| {zdot:.1e}")
+        assert len_err < 2e-4 and resid < 2e-4 and zdot < 2e-2, (name, len_err, resid, zdot)
+    # Everywhere else the reference's own x-axis is  acc / (|acc| + 1e-10)  with |acc| <~ 1e-9 (P:466: smooth patches at a small radius,
+    # duplicated / coplanar neighbours), i.e. SHORTER than a unit vector or pure rounding noise: x and y shrink (to 0 in the limit), z stays
+    # a unit vector.  What still holds for every point of both outputs: no neighbour gets longer than it is.
+    rel_len = ref[:, :3].double().norm(dim=1) / radius
+    for name, x in (("kernel", out), ("reference", ref)):
+        grow = (x[:, 3:].double().norm(dim=1) - rel_len).max().item()
+        assert grow < 1e-4, (name, grow)
+    noframe = ~exists
+    if noframe.any():
+        dz = (out[:, 5] - ref[:, 5]).abs().amax(-1)[noframe]
+        print("points whose reference frame is not orthonormal (shrunk or missing x-axis): %d; worst z-channel deviation there %.2e"
+              % (int(noframe.sum()), dz.max().item()))
+    if (~well).any():
+        print("worst deviation on the ill-conditioned points (frame implementation-defined): %.2e" % err[~well].max().item())
     return frac
 
 
