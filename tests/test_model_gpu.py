@@ -395,6 +395,29 @@ def test_fused_linear_attention_kernel(model):
 
 
 @torch.no_grad()
+def test_forward_end_to_end_different_images(tamed):
+    """The reference's forward on a pair whose query and reference crops are DIFFERENT images (tests/golden/
+    make_forward_diffimg_golden.py): the matcher finds no true correspondences here, the pose is whatever its hypothesis search
+    settles on -- and the same inputs must settle on the same pose: FPS indices equal, R / t within 1e-4 of the reference."""
+    z = load("forward_diffimg")
+    model = tamed[1024]
+    ep = {k: z[k] for k in ("pts", "tem1_pts", "rgb", "tem1_rgb", "rgb_choose", "tem1_choose")}
+    assert (ep["rgb"] - ep["tem1_rgb"]).abs().mean().item() > 0.5
+    ep["coarse_rand"] = z["rand"]
+    model.taps = {}
+    try:
+        out = model(ep)
+        taps = model.taps
+    finally:
+        model.taps = None
+    assert torch.equal(taps["fps_idx_m"].cpu().int(), z["fps_idx_m"].int()) and torch.equal(taps["fps_idx_o"].cpu().int(), z["fps_idx_o"].int())
+    for k in ("init_R", "init_t", "pred_R", "pred_t"):
+        assert err(out[k], z[k]) < 1e-4, (k, err(out[k], z[k]))
+    assert err(out["pred_pose_score"], z["pred_pose_score"]) < 1e-3
+    assert err(out["pred_R"][0], z["R_gt"]) > 0.5  # (not a solvable pair: nothing ties the two images together)
+
+
+@torch.no_grad()
 def test_forward_autocast_bf16_vs_reference_golden(tamed):
     """The autocast(bf16) forward -- the configuration bench.py times, with every bf16 HIP kernel on the
     path (ViT flash attention, fused LN glue, bf16 embedding, RPE / cross token attention, linear

@@ -20,12 +20,12 @@ def model():
     return trained_like_(UNOPose(default_model_cfg())).cuda().eval()
 
 
-def batches(n, B=3):
+def batches(n, B=3, img=224):
     from unopose_amd.synthetic import make_batch
 
     out = []
     for i in range(n):
-        ep, _, _ = make_batch(B, S=224, seed=50 + i, device="cuda")
+        ep, _, _ = make_batch(B, S=img, seed=50 + i, device="cuda")
         ep["coarse_rand"] = torch.rand(B, 18000, generator=torch.Generator().manual_seed(i)).cuda()
         out.append(ep)
     return out
@@ -141,6 +141,58 @@ def test_runner_with_pipelined_chunks_writes_the_same_lines(model, tmp_path):
 
 
 @torch.no_grad()
+@torch.no_grad()
+def test_pipeline_cold_start_on_a_fresh_model():
+    """No warm-up: the FIRST forwards of a freshly constructed model go through the pipeline, so its weight caches are built by
+    forward 1 on one pipeline stream while forward 2 is already queued on another (the second stream must wait for
+    them).  Both pipeline modes; results = the same batches one at a time on a second, identically initialised model."""
+    from unopose_amd.model import UNOPose, default_model_cfg
+    from unopose_amd.pipeline import PipelinedForward
+    from unopose_amd.synthetic import trained_like_
+
+    eps = batches(4, B=3, img=224)
+
+    def make():  # (the constructor draws the default initialisation from the global generator)
+        torch.manual_seed(1234)
+        return trained_like_(UNOPose(default_model_cfg()), seed=3).cuda().eval()
+
+    ref_model = make()
+    for stages in (False, True):
+        ref_model.internal_overlap = stages  # the in-forward side-stream overlaps are on in stage mode only (pipeline.py)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            want = [ref_model(dict(e)) for e in eps]
+        fresh = make()
+        pf = PipelinedForward(fresh, depth=2, stages=stages)
+        tickets = [pf.submit(dict(e)) for e in eps]
+        for t, w in zip(tickets, want):
+            o = t.result()
+            for k in ("pred_R", "pred_t", "init_R", "pred_pose_score"):
+                assert torch.equal(o[k], w[k]), (stages, k)
+        pf.close()
+        assert fresh.internal_overlap is True  # restored
+
+
+@torch.no_grad()
+def test_stage_mode_at_bench_size_equals_one_at_a_time():
+    """The benched mode (stage pipeline, B = 32, 518 x 518 crops, bf16): three consecutive batches, bit-identical to running them
+    one at a time."""
+    from unopose_amd.model import UNOPose, default_model_cfg
+    from unopose_amd.pipeline import PipelinedForward
+    from unopose_amd.synthetic import trained_like_
+
+    model = trained_like_(UNOPose(default_model_cfg(feature_extraction=dict(img_size=518)))).cuda().eval()
+    eps = batches(3, B=32, img=518)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        want = [{k: model(dict(e))[k].clone() for k in ("pred_R", "pred_t", "pred_pose_score")} for e in eps]
+    pf = PipelinedForward(model, depth=2, stages="auto")
+    outs = [pf.submit(dict(e)) for e in eps]
+    for t, w in zip(outs, want):
+        o = t.result()
+        for k in w:
+            assert torch.equal(o[k], w[k]), k
+    pf.close()
+
+
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_no_library_gemm_on_the_eval_path(model, precision):
     """Regression guard for DESIGN.md section 7 (library bf16 GEMM kernels corrupt registers of kernels running beside them; the

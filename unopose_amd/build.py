@@ -63,6 +63,9 @@ def build(force=False, verbose=False):
         if verbose and r.stderr:
             print(r.stderr)
 
+    for f in os.listdir(OBJ):  # objects of sources that no longer exist must not travel with the tree
+        if f.endswith(".o") and os.path.join(OBJ, f) not in objs:
+            os.remove(os.path.join(OBJ, f))
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(SO):

@@ -33,6 +33,21 @@ inline int check_launch(const char *what) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Opt a kernel into more than 64 KiB of dynamic LDS, once per DEVICE (the attribute belongs to the function on the current device:
+// a process that drives several GPUs must set it on each).  `done`: a static bool[64] owned by the call site.
+inline int lds_optin(bool (&done)[64], const void *fn, size_t bytes, const char *what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!done[dev]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+      set_error("%s: cannot reserve %zu bytes of LDS", what, bytes);
+      return UNOPOSE_ELAUNCH;
+    }
+    done[dev] = true;
+  }
+  return UNOPOSE_OK;
+}
+
 // Packed RNE fp32 -> bf16 (low half = a, high half = b): lowers to ONE v_cvt_pk_bf16_f32 on gfx950.
 // Deliberately the compiler's own vector conversion, not inline asm: the hazard recogniser does not look
 // inside asm statements, and an asm VALU op next to an in-flight MFMA on overlapping registers silently

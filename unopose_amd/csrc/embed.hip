@@ -280,14 +280,10 @@ int unopose_geo_embedding(const float *points, int B, int n, const void *wd_hi, 
   hipLaunchKernelGGL((geo_embed_kernel<SP, OB>), grid, dim3(GE_THREADS), lds, s, points, knn_ws, dh, dl, ah, al, \
                      bias_sum, div_term, n, sigma_d, factor_a, reduce_mean, out)
   if (split) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void *)geo_embed_kernel<true, false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void *)geo_embed_kernel<true, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
+    static bool opt_a[64], opt_b[64];
+    if (lds_optin(opt_a, (const void *)geo_embed_kernel<true, false>, lds, "geo_embedding") != UNOPOSE_OK ||
+        lds_optin(opt_b, (const void *)geo_embed_kernel<true, true>, lds, "geo_embedding") != UNOPOSE_OK)
+      return UNOPOSE_ELAUNCH;
     if (out_bf16) UNOPOSE_GE_LAUNCH(true, true); else UNOPOSE_GE_LAUNCH(true, false);
   } else {
     if (out_bf16) UNOPOSE_GE_LAUNCH(false, true); else UNOPOSE_GE_LAUNCH(false, false);

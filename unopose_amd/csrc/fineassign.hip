@@ -279,12 +279,10 @@ int unopose_fine_assign(const void *f1, const void *f2, int B, int R, int C, int
   const int nsp[2] = {cdiv(R, 32) * 32, cdiv(C, 32) * 32};
   const size_t lds0 = 2 * FA_TILE, lds1 = 2 * FA_TILE + (size_t)2 * nsp[0] * 4, lds2 = 2 * FA_TILE + (size_t)6 * nsp[1] * 4;
   UNOPOSE_REQUIRE(lds1 <= 150 * 1024 && lds2 <= 150 * 1024, "fine_assign: %d x %d does not fit the LDS-resident per-index tables", R, C);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)fine_assign_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void *)fine_assign_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
-  }
+  static bool opt1[64], opt2[64];
+  if (lds_optin(opt1, (const void *)fine_assign_kernel<1>, 150 * 1024, "fine_assign") != UNOPOSE_OK ||
+      lds_optin(opt2, (const void *)fine_assign_kernel<2>, 150 * 1024, "fine_assign") != UNOPOSE_OK)
+    return UNOPOSE_ELAUNCH;
   const int nb = p.nblk[0] > p.nblk[1] ? p.nblk[0] : p.nblk[1];
   static const int old_grid = getenv("UNOPOSE_FA_OLD_GRID") ? atoi(getenv("UNOPOSE_FA_OLD_GRID")) : 0;
   p.old_grid = old_grid;

@@ -514,12 +514,8 @@ int unopose_pe_group_mlp_max_packed_out(const float *xyz, int B, int N, float ra
   if (B == 0) return UNOPOSE_OK;
   const size_t lds = sizeof(PeLdsB) + ((size_t)3 * N + 4 * (size_t)nsample + 4 * 128) * 4;
   UNOPOSE_REQUIRE(lds <= 160 * 1024, "pe_group_mlp_max_packed: N=%d nsample=%d exceed the LDS tile", N, nsample);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)pe_group_mlp_max_bf16x3_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static bool opt[64];
+  if (lds_optin(opt, (const void *)pe_group_mlp_max_bf16x3_kernel, 160 * 1024, "pe_group_mlp_max_packed") != UNOPOSE_OK) return UNOPOSE_ELAUNCH;
   const long centres = (long)B * N;
   const int cpw = centres >= 65536 ? 16 : centres >= 32768 ? 8 : centres >= 8192 ? 4 : centres >= 2048 ? 2 : 1;
   dim3 grid(cdiv(N, 4 * cpw), B);
@@ -537,12 +533,8 @@ int unopose_pe_group_mlp_max(const float *xyz, int B, int N, float radius, int n
   if (B == 0) return UNOPOSE_OK;
   const size_t lds = sizeof(PeLds) + ((size_t)3 * N + 4 * (size_t)nsample + 4 * 128) * 4;
   UNOPOSE_REQUIRE(lds <= 160 * 1024, "pe_group_mlp_max: N=%d nsample=%d exceed the LDS tile", N, nsample);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)pe_group_mlp_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr_set = true;
-  }
+  static bool opt[64];
+  if (lds_optin(opt, (const void *)pe_group_mlp_max_kernel, 160 * 1024, "pe_group_mlp_max") != UNOPOSE_OK) return UNOPOSE_ELAUNCH;
   const long centres = (long)B * N;
   const int cpw = centres >= 32768 ? 8 : centres >= 8192 ? 4 : centres >= 2048 ? 2 : 1;
   dim3 grid(cdiv(N, 4 * cpw), B);

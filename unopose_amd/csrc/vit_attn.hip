@@ -343,16 +343,9 @@ using namespace unopose;
 
 template <int QB, int NBUF, int NW, bool PIPE = false>
 static int launch_vit_attn(const void *qkv, int B, int T, int H, void *out, hipStream_t stream) {
-  static bool attr_set = false;  // > 64 KiB of LDS needs the opt-in (idempotent; benign if raced)
+  static bool opt[64];  // > 64 KiB of LDS needs the opt-in, per device (idempotent; benign if raced)
   const size_t lds = (size_t)NBUF * VA_BUF * sizeof(u16);
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&vit_attn_kernel<QB, NBUF, NW, PIPE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      set_error("vit_attention: cannot reserve %zu bytes of LDS", lds);
-      return UNOPOSE_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  if (lds_optin(opt, reinterpret_cast<const void *>(&vit_attn_kernel<QB, NBUF, NW, PIPE>), lds, "vit_attention") != UNOPOSE_OK) return UNOPOSE_ELAUNCH;
   const int BH = B * H, nq = cdiv(T, 32 * NW * QB);
   const float scale_log2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
   const long blocks = (long)cdiv(BH, 8) * nq * 8;

@@ -49,9 +49,11 @@ class Ticket:
 
 
 class PipelinedForward:
-    """model: an eval-mode UNOPose on a HIP device.  depth: forwards in flight (1 or 2; more brings nothing: bench.py
-    --inflight 3 measures the same rate).  autocast_dtype: torch.bfloat16 (the pipelined path) or None (fp32: one batch
-    at a time, whatever `depth` says)."""
+    """model: an eval-mode UNOPose on a HIP device.  depth: forwards in flight (1..4 accepted; 2 is the useful value: bench.py
+    --inflight 3 / 4 measure the same rate or less).  autocast_dtype: torch.bfloat16 (the pipelined path) or None (fp32: one batch
+    at a time, whatever `depth` says).  The model's weights must not change while forwards are in flight (the per-module weight
+    caches are rebuilt on whichever stream sees the new version first); after an update call `drain()` then `reset()`.
+    `close()` restores the model's `internal_overlap` switch."""
 
     def __init__(self, model, depth=2, autocast_dtype=torch.bfloat16, run_ahead=1, timing=False, stages="auto"):
         if depth not in (1, 2, 3, 4):
@@ -66,8 +68,14 @@ class PipelinedForward:
             raise RuntimeError("more than one forward in flight needs ops.HIP_GEMM_ALL (library stream-K GEMMs spin on partner "
                                "workgroups and can hang when forwards overlap)")
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.depth)] if self.depth > 1 else [None]
+        self._saved_overlap = getattr(model, "internal_overlap", None)
         if hasattr(model, "internal_overlap"):  # measured: with a second forward in flight the in-forward overlaps cost 1.6 %
             model.internal_overlap = self.depth == 1
+        # Derived-weight caches (bf16 / split weights, packed PE image, attention weight blocks ...) are built lazily by the FIRST
+        # forward, on the stream it runs on.  A forward on ANOTHER pipeline stream must not read them before those kernels have run:
+        # every pipeline stream waits once for the completion event of the first forward (pipeline.py:116).
+        self._warm = None
+        self._warm_seen = set()
         self._n = 0
         self._pending = collections.deque()
         self._limit = self.depth + max(0, int(run_ahead))  # forwards the host may have enqueued and not yet seen finish
@@ -94,14 +102,15 @@ class PipelinedForward:
             self._pending.popleft().wait()
         s = self.streams[self._n % len(self.streams)]
         self._n += 1
-        if self.stages == "auto":
+        use_stages = self.stages
+        if use_stages == "auto":  # decided per batch: a later batch of another resolution gets the mode that suits it
             rgb = end_points.get("rgb")
-            self.stages = bool(torch.is_tensor(rgb) and (rgb.shape[-1] // 14) * (rgb.shape[-2] // 14) + 5 >= 1024)
-        if self.stages:
+            use_stages = bool(torch.is_tensor(rgb) and (rgb.shape[-1] // 14) * (rgb.shape[-2] // 14) + 5 >= 1024)
+        if hasattr(self.model, "internal_overlap") and self.depth > 1:
+            self.model.internal_overlap = bool(use_stages)
+        if use_stages:
             if self._stage_streams is None:
                 self._stage_streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device, priority=-1)]
-                if hasattr(self.model, "internal_overlap"):
-                    self.model.internal_overlap = True
             t, start, done = self._submit_stages(end_points)
         elif s is None:
             start = torch.cuda.Event(enable_timing=True) if self.timing else None
@@ -114,6 +123,9 @@ class PipelinedForward:
         else:
             cur = torch.cuda.current_stream(self.device)
             s.wait_stream(cur)
+            if self._warm is not None and s.cuda_stream not in self._warm_seen:
+                s.wait_event(self._warm)  # the caches the first forward built on its stream
+                self._warm_seen.add(s.cuda_stream)
             for v in end_points.values():
                 if torch.is_tensor(v) and v.is_cuda:
                     v.record_stream(s)
@@ -130,6 +142,9 @@ class PipelinedForward:
             finally:
                 ops.SERIALIZE_BIG_GEMMS = prev
             t = Ticket(out, done, s)
+            if self._warm is None:
+                self._warm = done
+                self._warm_seen.add(s.cuda_stream)
         self._pending.append(t)
         if self.timing and start is not None:
             self.history.append((start, done))
@@ -168,3 +183,15 @@ class PipelinedForward:
         """Host-wait for everything submitted so far."""
         while self._pending:
             self._pending.popleft().wait()
+
+    def reset(self):
+        """Forget which streams have seen the weight caches (call after `drain()` when the model's weights changed)."""
+        self.drain()
+        self._warm = None
+        self._warm_seen.clear()
+
+    def close(self):
+        """Drain and give the model its `internal_overlap` switch back."""
+        self.drain()
+        if self._saved_overlap is not None:
+            self.model.internal_overlap = self._saved_overlap
