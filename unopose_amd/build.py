@@ -16,7 +16,7 @@ SO = os.path.join(HERE, "libunopose_hip.so")
 ARCH = "gfx950"
 # -ffp-contract=off: fp32 distance expressions must round exactly as written so
 # FPS / ball_query indices are bit-identical to oracle/ (DESIGN.md "fp-contract").
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall",
+FLAGS = [*os.environ.get("UNOPOSE_EXTRA_HIPCC_FLAGS", "").split(), "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall",
          "-Wno-unused-function"]
 # Dense-math kernels: `nnan` lets fmaxf lower to ONE v_max_f32 instead of canonicalise + max (the PE tile
 # loop had 288 v_max for 112 logical maxima).  Not applied to the index-producing files (pointnet2, geom,

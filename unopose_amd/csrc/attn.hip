@@ -23,9 +23,19 @@ __device__ __forceinline__ u16 f2bf_rn(float f) {
   return (u16)(u >> 16);
 }
 
+#ifndef TA_DPP_BUTTERFLY
+#define TA_DPP_BUTTERFLY 1  // 0: the butterfly through ds_swizzle (LDS crossbar); see DESIGN.md section 7
+#endif
 template <int XOR>
-__device__ __forceinline__ float swz_xor(float v) {  // butterfly inside 32 lanes, no LDS memory touched
+__device__ __forceinline__ float swz_xor(float v) {  // butterfly step inside a 16-lane row, no LDS memory touched
+#if TA_DPP_BUTTERFLY
+  // DPP: quad_perm [1,0,3,2] / [2,3,0,1] for xor 1 / 2; row_half_mirror / row_mirror for xor 4 / 8 -- applied in this order every
+  // lane's partner group holds the value the xor partner would (the groups are uniform by then), so sums and maxima are unchanged
+  constexpr int ctrl = XOR == 1 ? 0xB1 : XOR == 2 ? 0x4E : XOR == 4 ? 0x141 : 0x140;
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false));
+#else
   return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (XOR << 10) | 0x1F));
+#endif
 }
 __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, swz_xor<1>(v));

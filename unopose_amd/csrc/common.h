@@ -84,7 +84,13 @@ __device__ __forceinline__ BilinearTap bilinear_tap(long long pix, int H, int W,
   return t;
 }
 
-// ---- wave64 DPP reductions (gfx9 row_shr / row_bcast) ----------------------
+#ifndef UNOPOSE_SUM_SHFL
+#define UNOPOSE_SUM_SHFL 0
+#endif
+#ifndef UNOPOSE_ROW_BCAST
+#define UNOPOSE_ROW_BCAST 0  // 1: cross-row steps of the wave reductions through DPP row_bcast:15 / :31
+#endif
+// ---- wave64 DPP reductions (gfx9 row_shr within the 16-lane rows; the four row results combined through v_readlane) --------
 // dpp_ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v, uint32_t identity) {
@@ -114,21 +120,43 @@ __device__ __forceinline__ uint64_t row_max_u64(uint64_t v) {
 // max over all 64 lanes; wave-uniform result (read from lane 63).
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
   v = row_max_u64(v);
+#if UNOPOSE_ROW_BCAST
   v = umax64(v, dpp_u64<0x142, 0xA>(v));
   v = umax64(v, dpp_u64<0x143, 0xC>(v));
   uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, 63);
   uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
   return ((uint64_t)hi << 32) | lo;
+#else
+  uint64_t r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    r[i] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 16 * i + 15) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 16 * i + 15);
+  return umax64(umax64(r[0], r[1]), umax64(r[2], r[3]));
+#endif
 }
 
 __device__ __forceinline__ float wave_sum_f32(float v) {
+#if UNOPOSE_SUM_SHFL
+  // probe: no DPP at all -- the same pairing tree through ds_bpermute
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+#endif
   v += dpp_f32<0x111, 0xF>(v, 0.f);
   v += dpp_f32<0x112, 0xF>(v, 0.f);
   v += dpp_f32<0x114, 0xF>(v, 0.f);
   v += dpp_f32<0x118, 0xF>(v, 0.f);
+#if UNOPOSE_ROW_BCAST
   v += dpp_f32<0x142, 0xA>(v, 0.f);
   v += dpp_f32<0x143, 0xC>(v, 0.f);
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+#else
+  // the four row sums (lane 15 of every 16-lane row) combined in the order the row_bcast chain used: (r3 + r2) + (r1 + r0)
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  return (r3 + r2) + (r1 + r0);
+#endif
 }
 __device__ __forceinline__ float wave_max_f32(float v) {
   const float ninf = -__builtin_inff();
@@ -136,9 +164,15 @@ __device__ __forceinline__ float wave_max_f32(float v) {
   v = fmaxf(v, dpp_f32<0x112, 0xF>(v, ninf));
   v = fmaxf(v, dpp_f32<0x114, 0xF>(v, ninf));
   v = fmaxf(v, dpp_f32<0x118, 0xF>(v, ninf));
+#if UNOPOSE_ROW_BCAST
   v = fmaxf(v, dpp_f32<0x142, 0xA>(v, ninf));
   v = fmaxf(v, dpp_f32<0x143, 0xC>(v, ninf));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+#else
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+#endif
 }
 
 __device__ __forceinline__ int lane_id() {

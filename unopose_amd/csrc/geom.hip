@@ -7,6 +7,8 @@
 //   * unopose_weighted_procrustes -- weighted_procrustes (utils/model_utils.py:667-743)
 // All 3x3 eigen / singular problems are solved by Jacobi rotations in registers
 // (jacobi3.h) instead of torch.svd.
+#include <cstdlib>
+
 #include "common.h"
 #include "jacobi3.h"
 
@@ -103,6 +105,12 @@ __global__ __launch_bounds__(256) void lrf_global_kernel(const float *__restrict
   }
 }
 
+#ifndef UNOPOSE_LRF_DEBUG
+#define UNOPOSE_LRF_DEBUG 0  // probe build (scripts/ubench): per-centre intermediates of the frame into a debug buffer
+#endif
+#if UNOPOSE_LRF_DEBUG
+__device__ float *g_lrf_dbg;
+#endif
 // -------------------------------------- fused ball_query + group + LRF ------
 // One wavefront per centre.  LDS: SoA copy of the cloud + one neighbour list per wave.
 // out (B,6,N,S): channels 0-2 = p_k - c (un-normalised), 3-5 = R^T (p_k - c) / radius
@@ -203,6 +211,15 @@ __global__ __launch_bounds__(256) void query_lrf_group_kernel(const float *__res
     vz = wave_sum_f32(vz);
     Vec3 xp, yp;
     finish_frame(zp, v3(vx, vy, vz), xp, yp);
+#if UNOPOSE_LRF_DEBUG
+    if (lane == 0 && g_lrf_dbg) {
+      float *d = g_lrf_dbg + ((size_t)b * N + j) * 24;
+      d[0] = a00; d[1] = a01; d[2] = a02; d[3] = a11; d[4] = a12; d[5] = a22;
+      d[6] = z0.x; d[7] = z0.y; d[8] = z0.z; d[9] = (float)vote; d[10] = vx; d[11] = vy; d[12] = vz;
+      d[13] = xp.x; d[14] = xp.y; d[15] = xp.z; d[16] = l0; d[17] = l1; d[18] = l2; d[19] = (float)cnt;
+      d[20] = e0.x; d[21] = e1.x; d[22] = cx; d[23] = inv_s;
+    }
+#endif
 
     float *row = O + (size_t)j * S;
     for (int l = lane; l < S; l += 64) {
@@ -335,13 +352,23 @@ int unopose_lrf_global(const float *pts, int B, int N, int use_ref_rad, float *o
   return check_launch("lrf_global");
 }
 
+#if UNOPOSE_LRF_DEBUG
+extern "C" int unopose_lrf_debug_buffer(float *buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lrf_dbg), &buf, sizeof(buf)); }
+#endif
+
 int unopose_query_lrf_group(const float *xyz, int B, int N, float radius, int nsample, float *out,
                             unopose_stream_t stream) {
   UNOPOSE_REQUIRE(xyz && out, "query_lrf_group: null pointer");
   UNOPOSE_REQUIRE(B >= 0 && N >= 1 && nsample >= 1 && B <= 65535, "query_lrf_group: bad sizes");
   if (B == 0) return UNOPOSE_OK;
-  const size_t lds = ((size_t)3 * N + 4 * (size_t)nsample) * 4;
+  size_t lds = ((size_t)3 * N + 4 * (size_t)nsample) * 4;
   UNOPOSE_REQUIRE(lds <= 64 * 1024, "query_lrf_group: N=%d nsample=%d exceed the 64 KiB LDS tile", N, nsample);
+  static const long lds_probe = getenv("UNOPOSE_QLG_LDS_PROBE") ? atol(getenv("UNOPOSE_QLG_LDS_PROBE")) : 0;  // co-residency probe
+  if (lds_probe > (long)lds) {
+    static bool opt[64];
+    if (lds_optin(opt, (const void *)query_lrf_group_kernel, (size_t)lds_probe, "query_lrf_group") != UNOPOSE_OK) return UNOPOSE_ELAUNCH;
+    lds = (size_t)lds_probe;
+  }
   const long centres = (long)B * N;
   int cpw = centres >= 65536 ? 8 : centres >= 16384 ? 4 : centres >= 4096 ? 2 : 1;
   dim3 grid(cdiv(N, 4 * cpw), B);

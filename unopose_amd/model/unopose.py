@@ -18,7 +18,9 @@ from .modules import (GeometricStructureEmbedding, GeometricTransformer, Positio
 
 
 STACKED_FINE = os.environ.get("UNOPOSE_STACKED_FINE", "1") == "1"  # A/B switch for the 2B-stacked fine matcher
-PE_UNDER_COARSE = os.environ.get("UNOPOSE_PE_UNDER_COARSE", "1") == "1"  # A/B switch, see UNOPose.forward
+# Reference-cloud PE on a side stream under the coarse stage: OFF by default since round 3 -- the PE / frame kernels are not
+# reproducible when waves of the token attention kernel share their CU; "1" restores the round-2 overlap (+1.5 %).
+PE_UNDER_COARSE = os.environ.get("UNOPOSE_PE_UNDER_COARSE", "0") == "1"
 GEOM_UNDER_VIT = int(os.environ.get("UNOPOSE_GEOM_UNDER_VIT", "1"))  # 1: LRF / FPS-196 / gathers, 2: + embedding
 
 
@@ -280,15 +282,16 @@ class UNOPose(nn.Module):
                 # the other latency-bound, feature-independent steps ride along: both global LRFs, the two
                 # 2048->196 FPS chains and the gathers of points / frame coordinates (M:28-47)
                 pre = {}
-                pm_lrf = ops.lrf_global(end_points["pts"], self.use_ref_rad)
-                po_lrf = ops.lrf_global(tem_pts, self.use_ref_rad)  # NB App-E.1: full 5000-point cloud
                 pre["idx_m"] = ops.furthest_point_sample(dense_pm, self.coarse_npoint)
                 pre["idx_o"] = ops.furthest_point_sample(dense_po, self.coarse_npoint)
                 pre["sparse_pm"] = ops.gather_rows(dense_pm.float(), pre["idx_m"])
                 pre["sparse_po"] = ops.gather_rows(dense_po.float(), pre["idx_o"])
-                pre["sparse_pm_lrf"] = ops.gather_rows(pm_lrf, pre["idx_m"])
-                pre["sparse_po_lrf"] = ops.gather_rows(po_lrf, pre["idx_o"])
+                # (the two global frames are NOT computed here: the frame kernels change their results when waves of an MFMA kernel of
+                # another stream -- the previous batch's token attention in a pipelined runner -- share their CU: DESIGN.md section 7;
+                # `_forward_from` computes them on the matcher's own stream)
                 if GEOM_UNDER_VIT > 1:
+                    pre["sparse_pm_lrf"] = ops.gather_rows(ops.lrf_global(end_points["pts"], self.use_ref_rad), pre["idx_m"])
+                    pre["sparse_po_lrf"] = ops.gather_rows(ops.lrf_global(tem_pts, self.use_ref_rad), pre["idx_o"])  # NB App-E.1: full 5000-point cloud
                     bg_point = torch.ones(dense_pm.size(0), 1, 3, device=dense_pm.device)
                     pre["geo"] = self.geo_embedding(torch.cat([torch.cat([bg_point, pre["sparse_pm_lrf"]], dim=1),
                                                                torch.cat([bg_point, pre["sparse_po_lrf"]], dim=1)], dim=0))
@@ -430,6 +433,11 @@ class UNOPose(nn.Module):
         if self.taps is not None:  # test probe (the model never reads fps_idx_* from end_points)
             self.taps.update(fps_idx_m=fps_idx_m, fps_idx_o=fps_idx_o, dense_pm=dense_pm, dense_fm=dense_fm,
                              dense_po=dense_po, dense_fo=dense_fo, radius=radius)
+        if "sparse_pm_lrf" not in pre:  # frames on the matcher's stream (see `_features`)
+            po_lrf = end_points["ref_lrf"] if "ref_lrf" in end_points else ops.lrf_global(
+                end_points["tem1_pts"] if "tem1_pts" in end_points else end_points["dense_po"], self.use_ref_rad)
+            pre = dict(pre, sparse_pm_lrf=ops.gather_rows(ops.lrf_global(end_points["pts"], self.use_ref_rad), fps_idx_m),
+                       sparse_po_lrf=ops.gather_rows(po_lrf, fps_idx_o))
         sparse_pm, sparse_po, sparse_pm_lrf, sparse_po_lrf = (pre[k] for k in ("sparse_pm", "sparse_po", "sparse_pm_lrf",
                                                                                   "sparse_po_lrf"))
         sparse_fm = pre["sparse_fm"] if "sparse_fm" in pre else ops.gather_rows(dense_fm, fps_idx_m)
