@@ -107,10 +107,11 @@ def hip_event_time(fn, iters, stream):
 
 
 def roofline_leg(model, batch, img):
-    """Roofline of the dominant hand-written kernel of the step, timed live with HIP events on the stream
-    it runs on: the ViT patch attention at 518x518 crops (12 launches = the largest share of the step
-    after the GEMMs), the fused positional-encoding kernel (S=256 launch) at 224x224.  The other
-    rows BASELINE's north star prices follow in `roofline_other`.  Work models: DESIGN.md section 4."""
+    """Roofline of the dominant hand-written kernel of the step, timed live with HIP events on the stream it runs on:
+    `gemm_bf16_kernel` (csrc/gemm.hip), the linear layers of the ViT -- 48 launches per step, the largest share of
+    the step's GPU time.  `roofline` prices the four shapes of one ViT-B block (qkv, proj, fc1 + bias + GELU, fc2) at
+    the step's row count M = 2B x T flop-weighted: achieved = (sum of their flops) / (sum of their launch times).
+    The other rows BASELINE's north star prices follow in `roofline_other`.  Work models: DESIGN.md section 4."""
     import torch
 
     from unopose_amd import ops
@@ -134,32 +135,55 @@ def roofline_leg(model, batch, img):
         rows.append(r)
         return r
 
-    # ViT patch attention: 4 T^2 64 flop per (image, head), 2B images x 12 heads, T = 5 + (img/14)^2 tokens
+    # the ViT linears: the four shapes of one block, bf16, M = 2B x T rows, T = 5 + (img/14)^2 tokens
     T = 5 + (img // 14) ** 2
+    M = 2 * B * T
+    shapes, flops, secs, alg_bytes = [], 0.0, 0.0, 0.0
+    for name, K_, N_, gelu in (("qkv", 768, 2304, False), ("proj", 768, 768, False), ("fc1", 768, 3072, True),
+                               ("fc2", 3072, 768, False)):
+        a = torch.randn(M, K_, device=x.device).bfloat16()
+        w = (torch.randn(N_, K_, device=x.device) / K_ ** 0.5).bfloat16()
+        bias = torch.randn(N_, device=x.device)
+        t = hip_event_time(lambda: ops.linear_bf16_hip(a, w, bias, gelu), 10, stream)
+        r = row("vit_linear_%s(M=%d,K=%d,N=%d%s)" % (name, M, K_, N_, ",+bias+GELU" if gelu else ""), "mfma",
+                2.0 * M * K_ * N_, 1e12, 2500.0, "TFLOP/s", t)
+        r["algorithmic_bytes"] = 2.0 * (M * K_ + N_ * K_ + M * N_) + 4.0 * N_  # A, W, C in bf16 + fp32 bias, each once
+        shapes.append(r)
+        flops += 2.0 * M * K_ * N_
+        secs += t
+        alg_bytes += r["algorithmic_bytes"]
+        del a, w, bias
+    traffic = _pmc_traffic_gemm(B, T, alg_bytes)
+    gemm = dict(bound="mfma", kernel="gemm_bf16_kernel: the four linears of one ViT-B block at M=%d, flop-weighted" % M,
+                achieved=flops / secs / 1e12, peak=2500.0, unit="TFLOP/s", frac=flops / secs / 1e12 / 2500.0, traffic=traffic,
+                launches=4, us=secs * 1e6, flop=flops, algorithmic_bytes=alg_bytes, shapes=shapes,
+                note="hand-written bf16 MFMA GEMM (256x256 tiles, LDS-DMA operand stages, persistent XCD-aware tile walk), bias / "
+                     "GELU in the epilogue; `achieved` = sum of the four shapes' flops / sum of their HIP-event launch times; "
+                     "12 blocks x 4 launches per step")
+    rows[:] = []
+    # ViT patch attention: 4 T^2 64 flop per (image, head), 2B images x 12 heads
     qkv = torch.randn(2 * B, T, 2304, device=x.device).bfloat16()
     t = hip_event_time(lambda: ops.vit_attention(qkv, 12), 10, stream)
     vit = row("vit_attn_kernel(T=%d)" % T, "mfma", 2.0 * B * 12 * 4.0 * T * T * 64, 1e12, 2500.0, "TFLOP/s", t,
               "QK^T + PV flops; softmax exp/sum VALU work shares the issue port with the matrix core")
+    vit["traffic"] = _pmc_traffic("vit_attn_kernel", B) if T == 1374 else None
     del qkv
-    # the ViT linears (the largest share of the step): the four shapes of one block, bf16, M = 2B x T rows
-    M = 2 * B * T
-    for name, K_, N_, gelu in (("qkv", 768, 2304, False), ("proj", 768, 768, False), ("fc1", 768, 3072, True),
-                               ("fc2", 3072, 768, False)):
-        a = torch.randn(M, K_, device=x.device).bfloat16()
-        lin = torch.nn.Linear(K_, N_).to(x.device)
-
-        def f():
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                return ops.linear(a, lin, gelu=True) if gelu else ops.linear(a, lin)
-
-        t = hip_event_time(f, 10, stream)
-        row("vit_linear_%s(M=%d,K=%d,N=%d%s)" % (name, M, K_, N_, ",+bias+GELU" if gelu else ""), "mfma",
-            2.0 * M * K_ * N_, 1e12, 2500.0, "TFLOP/s", t, ops.linear_backend())
-        del a, lin
+    # the fp32-class linears (bf16 hi/lo split, 3 MFMAs per product): the reference's default precision
+    if ops.USE_F32X3:
+        for name, K_, N_, epi in (("qkv", 768, 2304, 0), ("fc1", 768, 3072, 1)):
+            a_s = ops.split_f32(torch.randn(M, K_, device=x.device))
+            w_s = ops.split_f32(torch.randn(N_, K_, device=x.device) / K_ ** 0.5)
+            bias = torch.randn(N_, device=x.device)
+            t = hip_event_time(lambda: ops.linear_f32x3(a_s, w_s, bias, M, N_, K_, gelu=bool(epi), out="split"), 5, stream)
+            row("vit_linear_f32x3_%s(M=%d,K=%d,N=%d%s)" % (name, M, K_, N_, ",+bias+GELU" if epi else ""), "mfma",
+                2.0 * M * K_ * N_, 1e12, 2500.0 / 3.0, "TFLOP/s", t,
+                "fp32-equivalent flops against 1/3 of the bf16 dense peak (3 bf16 MFMAs per product)")
+            del a_s, w_s, bias
     # PE, S=256, bf16 hi/lo-split matrix cores; 20864 flop per neighbour row
     t = hip_event_time(lambda: ops.pe_group_mlp_max(x, pe.r2, pe.ns2, pe.mlp2, bf16x3=True), 10, stream)
-    dom = row("pe_group_mlp_max_bf16x3_kernel(S=%d)" % pe.ns2, "mfma", B * N * pe.ns2 * 20864.0, 1e12, 2500.0,
-              "TFLOP/s", t, "algorithmic fp32-equivalent flops; the kernel issues 3 bf16 MFMAs per product")
+    r = row("pe_group_mlp_max_bf16x3_kernel(S=%d)" % pe.ns2, "mfma", B * N * pe.ns2 * 20864.0, 1e12, 2500.0,
+            "TFLOP/s", t, "algorithmic fp32-equivalent flops; the kernel issues 3 bf16 MFMAs per product")
+    r["traffic"] = _pmc_traffic("pe_group_mlp_max_bf16x3_kernel", B)
     t = hip_event_time(lambda: ops.pe_group_mlp_max(x, pe.r2, pe.ns2, pe.mlp2, bf16x3=False), 5, stream)
     row("pe_group_mlp_max_kernel(S=%d, exact fp32 MFMA)" % pe.ns2, "mfma", B * N * pe.ns2 * 20864.0, 1e12, 157.3,
         "TFLOP/s", t)
@@ -178,28 +202,40 @@ def roofline_leg(model, batch, img):
     tem = batch["tem1_pts"].float().contiguous()
     t = hip_event_time(lambda: _ext.furthest_point_sampling(tem, 2048), 3, stream)
     rows.append(dict(kernel="fps_kernel(5000->2048)", bound="latency", us=t * 1e6, us_per_iteration=t * 1e6 / 2047))
-    if img >= 448:  # 12 attention launches outweigh the 2 PE launches once T^2 grows
-        dom, key = vit, "vit_attn_kernel"
-    else:
-        key = "pe_group_mlp_max_bf16x3_kernel"
-    traffic = _pmc_traffic(key, B) if (key != "vit_attn_kernel" or T == 1374) else None
-    out = dict(roofline=dict(bound=dom["bound"], kernel=dom["kernel"], achieved=dom["achieved"], peak=dom["peak"],
-                             unit=dom["unit"], frac=dom["frac"], traffic=traffic, note=dom["note"]),
-               roofline_other=[r for r in rows if r is not dom])
-    return out
+    return dict(roofline=gemm, roofline_other=rows)
+
+
+def _pmc_summary():
+    for rnd in ("r03", "r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd + "_pmc_summary.json")
+        if os.path.exists(path):
+            return json.load(open(path)), "profiles/%s_pmc_summary.json" % rnd
+    return None, None
+
+
+def _pmc_traffic_gemm(B, T, alg_bytes):
+    """HBM bytes of the four ViT linears (one launch each) from the committed PMC passes: per shape and summed, beside the
+    algorithmic bytes; null when the batch / token count differ from the profiled ones (B=32, T=1374)."""
+    doc, src = _pmc_summary()
+    if doc is None or B != 32 or T != 1374 or "gemm_shapes" not in doc:
+        return None
+    per = {k: v["hbm_bytes_per_launch"] for k, v in doc["gemm_shapes"].items()}
+    if sorted(per) != ["fc1", "fc2", "proj", "qkv"]:
+        return None
+    tot = sum(per.values())
+    return dict(hbm_bytes=tot, launches=4, hbm_bytes_per_launch=tot / 4.0, per_shape=per, algorithmic_bytes=alg_bytes,
+                ratio_to_algorithmic=tot / alg_bytes, source=src)
 
 
 def _pmc_traffic(kernel, B):
     """HBM bytes per launch from the committed PMC passes (profiles/r0N_pmc_summary.json: FETCH_SIZE and
     WRITE_SIZE collected in separate rocprofv3 runs at B=32, FETCH_SIZE doubled per the gfx950 note);
     null when the batch differs from the profiled one."""
-    for rnd in ("r02", "r01"):
-        path = os.path.join(ROOT, "profiles", rnd + "_pmc_summary.json")
-        if B == 32 and os.path.exists(path):
-            k = json.load(open(path))["kernels"].get(kernel)
-            if k is not None:
-                return dict(hbm_bytes_per_launch=k["hbm_bytes_per_launch"], source="profiles/%s_pmc_summary.json" % rnd)
-    return None
+    doc, src = _pmc_summary()
+    if doc is None or B != 32:
+        return None
+    k = doc["kernels"].get(kernel)
+    return None if k is None else dict(hbm_bytes_per_launch=k["hbm_bytes_per_launch"], source=src)
 
 
 def _cpu_model_name():
@@ -212,43 +248,51 @@ def _cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline_leg(img, batches=(1, 8), timed=3):
+def cpu_baseline_leg(img, batches=(1, 8), timed=2):
     """The oracle (torch-CPU port of the reference forward + the C `_ext` port; kind "port": the reference's
     Python cannot travel) timed on this host's cores on a bounded sample of the same workload
     (SURVEY.md 8(d)): per batch size one warm-up forward, then `timed` timed forwards; value = the best
-    batch size's median rate."""
+    batch size's median rate.  The reported value uses torch's intra-op pool at min(32, cores) threads (more threads
+    only add contention at these op sizes); the same forward with EVERY hardware thread is timed once beside it
+    (`all_cores`), so the choice is visible in the line."""
     import torch
 
     from oracle import unopose_ref as R
     from oracle.pointnet2_oracle import ext as oext
     from unopose_amd.synthetic import make_batch
 
-    # torch's intra-op pool: every core up to 32 (more threads than that only add contention on these op sizes;
-    # the C `_ext` port is single-threaded) -- `cores` reports the threads actually used
-    threads = min(32, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
+    host = os.cpu_count() or 1
+    threads = min(32, host)
     cfg = R.default_cfg()
     sd = R.random_state_dict(cfg, seed=0, img_size=img, tame=0.1)
-    by_batch = {}
-    for b in batches:
+
+    def run(b, n_threads, n_timed):
+        torch.set_num_threads(n_threads)
         ep, _, _ = make_batch(b, 2048, 5000, img, seed=1)
         rand = torch.rand(b, 18000, generator=torch.Generator().manual_seed(2))
         times = []
         with torch.no_grad():
-            for i in range(1 + timed):
+            for i in range(1 + n_timed):
                 t0 = time.perf_counter()
                 R.unopose_forward(ep, sd, cfg, rand, oext)
-                log("cpu_baseline B=%d forward %d: %.2f s" % (b, i, time.perf_counter() - t0))
+                log("cpu_baseline B=%d threads=%d forward %d: %.2f s" % (b, n_threads, i, time.perf_counter() - t0))
                 if i:
                     times.append(time.perf_counter() - t0)
         times.sort()
         med = times[len(times) // 2]
-        by_batch[str(b)] = dict(pairs_per_s=b / med, median_s=med, min_s=times[0], max_s=times[-1], timed=timed, warmup=1)
+        return dict(pairs_per_s=b / med, median_s=med, min_s=times[0], max_s=times[-1], timed=n_timed, warmup=1)
+
+    by_batch = {str(b): run(b, threads, timed) for b in batches}
     best = max(by_batch.values(), key=lambda r: r["pairs_per_s"])
-    return dict(value=best["pairs_per_s"], unit="pairs/s", cores=threads, host_cores=os.cpu_count(), kind="port",
-                cpu_model=_cpu_model_name(), by_batch=by_batch,
-                sample=f"batches of {list(batches)} pairs (2048 query / 5000 reference points, {img}x{img} crops), 1 warm-up + "
-                       f"{timed} timed forwards each, fp32, torch {threads} threads + C `_ext` port; value = best median")
+    out = dict(value=best["pairs_per_s"], unit="pairs/s", cores=threads, host_cores=host, kind="port",
+               cpu_model=_cpu_model_name(), by_batch=by_batch,
+               sample=f"batches of {list(batches)} pairs (2048 query / 5000 reference points, {img}x{img} crops), 1 warm-up + "
+                      f"{timed} timed forwards each, fp32, torch {threads} threads + C `_ext` port; value = best median")
+    if host > threads:
+        b = max(batches)
+        r = run(b, host, 1)
+        out["all_cores"] = dict(threads=host, batch=b, **r)
+    return out
 
 
 def main():
@@ -314,7 +358,14 @@ def main():
     if world > 1:  # one flat broadcast of the weights from rank 0 over RCCL / xGMI
         from unopose_amd.runner import broadcast_module_
 
+        broadcast_module_(model, 0)  # first call: communicator set-up included
+        sync()
+        dist.barrier()
+        sync()
+        tb = time.perf_counter()
         broadcast_module_(model, 0)
+        sync()
+        bcast_ms = (time.perf_counter() - tb) * 1e3
 
     graphed = None
     if args.graph and not args.dry_run:
@@ -362,11 +413,14 @@ def main():
     if pipe is not None:
         pipe.drain()
     poses = torch.cat([out["pred_R"].reshape(B, 9), out["pred_t"], out["pred_pose_score"].reshape(B, 1)], 1)
+    sync()
+    dt_local = time.perf_counter() - t0  # this rank's own K steps, before it meets the others
     if world > 1:  # gather of poses to rank 0 (the reference lacks it: every rank writes the same file)
         poses = poses.to(comm_dev)
         gathered = [torch.empty_like(poses) for _ in range(world)] if rank == 0 else None
         dist.gather(poses, gathered, 0)
     sync()
+    gather_ms = (time.perf_counter() - t0 - dt_local) * 1e3  # includes waiting for the slowest rank
     if world > 1:
         dist.barrier()
     sync()
@@ -375,6 +429,10 @@ def main():
         tmax = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
+        mine = torch.tensor([dt_local / args.steps * 1e3, gather_ms, bcast_ms], device=comm_dev, dtype=torch.float64)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [[float(v) for v in e.tolist()] for e in every]
 
     log("timed region done: %.2f ms/step" % (dt / args.steps * 1e3))
     rot_err = (out["pred_R"] - R_gt).abs().amax(dim=(1, 2))
@@ -401,6 +459,14 @@ def main():
         "sanity": {"median_rot_err_vs_gt": rot_err.median().item(),
                    "frac_pairs_solved(<0.05)": (rot_err < 0.05).float().mean().item()},
     }
+    if world > 1:
+        res["per_rank_ms_per_step"] = [r[0] for r in per_rank]
+        res["collectives"] = {"backend": "RCCL (nccl)" if backend == "nccl" else backend,
+                              "weights_broadcast_ms": max(r[2] for r in per_rank),
+                              "poses_gather_ms_per_rank": [r[1] for r in per_rank],
+                              "what": "broadcast: second flat broadcast of all parameters + buffers from rank 0 (communicator already up), outside "
+                                      "the timed region; gather: the one pose gather that closes the timed region (includes the wait for the "
+                                      "slowest rank); no collective on the data path"}
     if args.dry_run:
         res["dry_run"] = True
     if pipe is not None:

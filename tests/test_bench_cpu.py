@@ -26,6 +26,10 @@ def test_bench_gpus2_spawns_two_ranks():
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == "weak"
     assert res["config"]["sharding"].startswith("dp2")
     assert abs(res["value"] - 2 * 4 * 3 / (res["ms_per_step"] * 3e-3)) < 1e-6 * res["value"]  # whole-job aggregate
+    # per-rank step times and the two collectives of the job (weights broadcast, pose gather) are in the line
+    assert len(res["per_rank_ms_per_step"]) == 2 and all(0 < v <= res["ms_per_step"] * 1.001 for v in res["per_rank_ms_per_step"])
+    c = res["collectives"]
+    assert c["weights_broadcast_ms"] >= 0 and len(c["poses_gather_ms_per_rank"]) == 2
 
 
 def test_bench_single_rank_dry_run_and_world_mismatch():

@@ -141,6 +141,41 @@ def test_runner_with_pipelined_chunks_writes_the_same_lines(model, tmp_path):
 
 
 @torch.no_grad()
+def test_runner_pipeline_with_reference_cache_equals_sequential(model, tmp_path):
+    """ADVICE round 2 (runner.py:103): pipeline= and ref_cache= together.  Missing reference views are encoded through
+    `PipelinedForward.encode_reference` -- the pipeline's autocast dtype, ordered after the forwards in flight -- so the lines equal
+    those of the chunk-by-chunk loop run under the same autocast with its own cache; the second image reuses the first one's views."""
+    from unopose_amd.pipeline import PipelinedForward
+    from unopose_amd.runner import ReferenceCache, inference_and_save
+    from unopose_amd.synthetic import make_batch
+
+    images = []
+    for i in range(2):
+        ep, _, _ = make_batch(5, S=224, seed=80 + i, device="cuda")
+        if images:  # same reference views as image 0: every lookup of image 1 is a hit
+            for k in ("tem1_rgb", "tem1_choose", "tem1_pts"):
+                ep[k] = images[0][k][0]
+        img = {k: v[None] for k, v in ep.items()}
+        img.update(score=torch.full((1, 5, 1), 0.5 + 0.1 * i, device="cuda"), obj_id=torch.arange(1, 6, dtype=torch.int32).reshape(1, 5, 1),
+                   scene_id=torch.IntTensor([48]), img_id=torch.IntTensor([3 + i]), ref_keys=[(48, 1, j) for j in range(5)])
+        images.append(img)
+    torch.manual_seed(5)
+    ca = ReferenceCache(model)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        a = inference_and_save(model, images, str(tmp_path / "a.csv"), instance_batch_size=2, ref_cache=ca)
+    torch.manual_seed(5)
+    cb = ReferenceCache(model)
+    pipe = PipelinedForward(model, depth=2)
+    b = inference_and_save(model, images, str(tmp_path / "b.csv"), instance_batch_size=2, ref_cache=cb, pipeline=pipe)
+    pipe.close()
+    assert (ca.misses, ca.hits) == (cb.misses, cb.hits) == (5, 5)
+    strip = lambda lines: [",".join(l.split(",")[:-1]) for l in lines]  # noqa: E731
+    assert strip(a) == strip(b) and len(a) == 10
+    for k in ca.store:  # the cached features themselves: same precision, same numbers
+        for name in ca.store[k]:
+            assert torch.equal(ca.store[k][name], cb.store[k][name]), (k, name)
+
+
 @torch.no_grad()
 def test_pipeline_cold_start_on_a_fresh_model():
     """No warm-up: the FIRST forwards of a freshly constructed model go through the pipeline, so its weight caches are built by
@@ -253,3 +288,24 @@ def test_no_library_gemm_on_the_eval_path(model, precision):
             setattr(owner, name, orig)
     assert not clean, clean[:8]
     assert fired > 20
+
+
+@torch.no_grad()
+def test_library_bf16_fallback_is_refused_while_forwards_overlap():
+    """ADVICE round 2 (ops.py:202): a bf16 linear whose shape csrc/gemm.hip does not take must not slip to a library GEMM
+    silently while PipelinedForward has several forwards in flight -- `ops.linear` raises; one at a time it still runs."""
+    from unopose_amd import ops
+
+    lin = torch.nn.Linear(100, 100).cuda()
+    x = torch.randn(64, 100, device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = ops.linear(x, lin)  # allowed: nothing else in flight
+        assert y.shape == (64, 100)
+        prev, ops.FORBID_LIBRARY_BF16_GEMM = ops.FORBID_LIBRARY_BF16_GEMM, True
+        try:
+            with pytest.raises(RuntimeError, match="library GEMM"):
+                ops.linear(x, lin)
+            lin2 = torch.nn.Linear(128, 256).cuda()  # a shape the own kernel takes: unaffected
+            assert ops.linear(torch.randn(64, 128, device="cuda"), lin2).shape == (64, 256)
+        finally:
+            ops.FORBID_LIBRARY_BF16_GEMM = prev

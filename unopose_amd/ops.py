@@ -291,6 +291,10 @@ def linear(x, lin, relu=False, gelu=False):
         # same L2 -> LDS stream (~10 TB/s chip-wide) and the library's deeper pipeline is 0-25 % ahead, so those stay there.
         if own_gemm_ok(rows, N, K) and (HIP_GEMM_ALL or gelu):
             return linear_bf16_hip(_c(xb).reshape(rows, K), cache[1], cache[3], gelu, relu).reshape(*xb.shape[:-1], N)
+        if FORBID_LIBRARY_BF16_GEMM:
+            raise RuntimeError(f"ops.linear: a {rows} x {K} -> {N} bf16 linear does not fit csrc/gemm.hip (N % 256, K % 64) and would go to "
+                               "a library GEMM while several forwards are in flight (PipelinedForward, depth > 1): library stream-K "
+                               "kernels of two streams can starve each other.  Use depth=1 for this model configuration")
         if relu and cache[2] is not None:
             x2 = xb.reshape(-1, xb.shape[-1])
             return torch._addmm_activation(cache[2], x2, cache[1].t()).reshape(*xb.shape[:-1], cache[1].shape[0])
@@ -304,6 +308,9 @@ def linear(x, lin, relu=False, gelu=False):
         return F.relu(y) if relu else (F.gelu(y) if gelu else y)
 
 
+# set by pipeline.PipelinedForward around every forward it enqueues with more than one in flight: the bf16 library fallback of
+# `linear` raises instead of dispatching silently (ops.py:202)
+FORBID_LIBRARY_BF16_GEMM = False
 USE_FUSED_LINEAR_LN = os.environ.get("UNOPOSE_FUSED_LINEAR_LN", "1") == "1"  # A/B switch
 
 
@@ -314,7 +321,7 @@ def linear_add_layernorm(h, lin, x, norm):
     N, K = lin.weight.shape
     rows = h.numel() // K
     if (USE_FUSED_LINEAR_LN and not _DIFF and h.is_cuda and torch.is_autocast_enabled() and HIP_GEMM_ALL and N == 256
-            and own_gemm_ok(rows, N, K) and tuple(norm.normalized_shape) == (256,) and norm.weight is not None and lin.bias is not None):
+            and own_gemm_ok(rows, N, K) and tuple(norm.normalized_shape) == (256,) and norm.weight is not None and norm.bias is not None and lin.bias is not None):
         cache = _bf16_weights(lin)
         with torch.autocast("cuda", enabled=False):
             hb = _c(h if h.dtype == torch.bfloat16 else h.to(torch.bfloat16)).reshape(rows, K)

@@ -111,7 +111,11 @@ class PipelinedForward:
         if use_stages:
             if self._stage_streams is None:
                 self._stage_streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device, priority=-1)]
-            t, start, done = self._submit_stages(end_points)
+            prev_forbid, ops.FORBID_LIBRARY_BF16_GEMM = ops.FORBID_LIBRARY_BF16_GEMM, True
+            try:
+                t, start, done = self._submit_stages(end_points)
+            finally:
+                ops.FORBID_LIBRARY_BF16_GEMM = prev_forbid
         elif s is None:
             start = torch.cuda.Event(enable_timing=True) if self.timing else None
             if start is not None:
@@ -129,8 +133,8 @@ class PipelinedForward:
             for v in end_points.values():
                 if torch.is_tensor(v) and v.is_cuda:
                     v.record_stream(s)
-            prev = ops.SERIALIZE_BIG_GEMMS
-            ops.SERIALIZE_BIG_GEMMS = True
+            prev, prev_forbid = ops.SERIALIZE_BIG_GEMMS, ops.FORBID_LIBRARY_BF16_GEMM
+            ops.SERIALIZE_BIG_GEMMS = ops.FORBID_LIBRARY_BF16_GEMM = True
             try:
                 with torch.cuda.stream(s):
                     start = torch.cuda.Event(enable_timing=True) if self.timing else None
@@ -140,7 +144,7 @@ class PipelinedForward:
                     done = torch.cuda.Event(enable_timing=self.timing)
                     done.record(s)
             finally:
-                ops.SERIALIZE_BIG_GEMMS = prev
+                ops.SERIALIZE_BIG_GEMMS, ops.FORBID_LIBRARY_BF16_GEMM = prev, prev_forbid
             t = Ticket(out, done, s)
             if self._warm is None:
                 self._warm = done
@@ -178,6 +182,20 @@ class PipelinedForward:
                 done = torch.cuda.Event(enable_timing=self.timing)
                 done.record(st)
         return Ticket(out, done, st), start, done
+
+    def encode_reference(self, tem1_rgb, tem1_choose, tem1_pts):
+        """`model.encode_reference` for a `runner.ReferenceCache` used together with this pipeline: same autocast dtype as the
+        pipelined forwards (a cached reference must carry the numbers the uncached forward would compute), on the caller's
+        current stream, ordered AFTER every forward in flight (GPU-side waits, the host does not block) so that the encoder's
+        kernels never share the device with them; later `submit`s wait for the caller's stream as always."""
+        cur = torch.cuda.current_stream(self.device)
+        for t in self._pending:
+            cur.wait_event(t.done)
+        with torch.no_grad():
+            if self.autocast_dtype is None:
+                return self.model.encode_reference(tem1_rgb, tem1_choose, tem1_pts)
+            with torch.autocast("cuda", dtype=self.autocast_dtype):
+                return self.model.encode_reference(tem1_rgb, tem1_choose, tem1_pts)
 
     def drain(self):
         """Host-wait for everything submitted so far."""

@@ -64,14 +64,16 @@ class ReferenceCache:
         self.model, self.max_items, self.store = model, max_items, OrderedDict()
         self.hits = self.misses = 0
 
-    def lookup(self, keys, tem1_rgb, tem1_choose, tem1_pts):
+    def lookup(self, keys, tem1_rgb, tem1_choose, tem1_pts, encode=None):
+        """`encode`: the encoder to use for missing views instead of `model.encode_reference` under the caller's autocast state --
+        `PipelinedForward.encode_reference` when the forwards go through a pipeline (its precision, its stream ordering)."""
         first = {}
         for i, k in enumerate(keys):
             if k not in self.store:
                 first.setdefault(k, i)  # one encode per distinct missing view
         if first:
             sel = torch.as_tensor(list(first.values()), device=tem1_pts.device)
-            enc = self.model.encode_reference(tem1_rgb[sel], tem1_choose[sel], tem1_pts[sel])
+            enc = (encode or self.model.encode_reference)(tem1_rgb[sel], tem1_choose[sel], tem1_pts[sel])
             for j, k in enumerate(first):
                 self.store[k] = {name: v[j].clone() for name, v in enc.items()}
         for k in keys:
@@ -101,7 +103,7 @@ def run_image(model, data, instance_batch_size=16, device=None, ref_cache=None, 
         inputs = {k: data[k][0][s:e].contiguous() for k in _INPUT_KEYS if k in data}
         if ref_cache is not None and "ref_keys" in data:
             inputs.update(ref_cache.lookup(list(data["ref_keys"][s:e]), inputs["tem1_rgb"], inputs["tem1_choose"],
-                                           inputs["tem1_pts"]))
+                                           inputs["tem1_pts"], None if pipeline is None else pipeline.encode_reference))
         pending.append((s, e, pipeline.submit(inputs).result if pipeline is not None else (lambda o=model(inputs): o)))
     for s, e, get in pending:
         out = get()
