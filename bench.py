@@ -48,6 +48,13 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the extra fp32 (reference default precision) leg")
+    ap.add_argument("--train", action="store_true",
+                    help="time the TRAINING step instead (BASELINE configs[3]: --batch 8 pairs per rank, --train-pts 4096 points per cloud, "
+                         "224x224 crops, frozen backbone, Adam; N > 1: DistributedDataParallel, gradient all-reduce over RCCL).  A step = "
+                         "forward in train mode + process_loss + backward + gradient hygiene + optimiser step")
+    ap.add_argument("--train-pts", type=int, default=4096, help="query points and fine_npoint of the training step (the reference's own "
+                    "training config: 2048 with 5000 reference points)")
+    ap.add_argument("--train-dtype", default="fp32", choices=["fp32", "bf16"], help="fp32 = the reference's training default (train.amp off)")
     ap.add_argument("--dry-run", action="store_true",
                     help="TEST HOOK (tests/test_bench_cpu.py): replace the model step by a host stub so that the launch / "
                          "rendezvous / barrier / gather / JSON path runs without a GPU (backend gloo); never a measurement")
@@ -295,6 +302,85 @@ def cpu_baseline_leg(img, batches=(1, 8), timed=2):
     return out
 
 
+def train_main(args, world, rank, dev, sync):
+    """bench.py --train: the training step of BASELINE configs[3]; one JSON line like the forward bench."""
+    import torch
+    import torch.distributed as dist
+
+    from unopose_amd.model import UNOPose, default_model_cfg
+    from unopose_amd.synthetic import make_train_batch, trained_like_
+    from unopose_amd.train import build_optimizer, freeze_backbone, train_step, wrap_ddp
+
+    B = args.batch if args.batch != 32 else 8  # --batch's default is the forward bench's; configs[3] is 8 pairs per rank
+    img = args.img if args.img != 518 else 224  # the reference trains on 224 x 224 crops (configs/main_cfg.py:190)
+    npts = args.train_pts
+    nt = 5000 if npts <= 2048 else npts + npts // 2
+    torch.manual_seed(0)
+    cfg = default_model_cfg(fine_npoint=npts, feature_extraction=dict(img_size=img))
+    model = freeze_backbone(trained_like_(UNOPose(cfg)).to(dev))
+    batch = make_train_batch(B, npts, nt, img, seed=300 + rank, device=dev)
+    net = wrap_ddp(model, dev) if world > 1 else model
+    opt, sched = build_optimizer(model, lr=1e-4, total_iters=188340)
+    amp = torch.bfloat16 if args.train_dtype == "bf16" else None
+    losses = []
+
+    def step():
+        info = train_step(net, batch, opt, sched, amp_dtype=amp)
+        losses.append(info["loss"])
+
+    log("model + batch ready (rank %d of %d)" % (rank, world))
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt_local = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    per_rank = None
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+        mine = torch.tensor([dt_local / args.steps * 1e3], device=dev, dtype=torch.float64)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(e.item()) for e in every]
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    res = {
+        "metric": "(query,ref) pairs/sec training step",
+        "value": world * B * args.steps / dt,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.train_dtype,
+        "data": "synthetic",
+        "config": {"workload": f"UNOPose training step (BASELINE configs[3]), {B} pairs/GPU, {npts} query pts, {nt}->{npts} reference pts, "
+                               f"196 coarse pts, {img}x{img} crops, frozen DINOv2 ViT-B/14 reg4 (fused inference kernels, no_grad), "
+                               f"{n_train / 1e6:.1f} M trainable parameters, Adam(1e-4, (0.5, 0.999), 1e-6), flat-and-anneal schedule",
+                   "sharding": f"dp{world} (replicas, bucketed gradient all-reduce over RCCL overlapped with backward)" if world > 1 else "dp1"},
+        "loss_first_last": [float(losses[0]), float(losses[-1])],
+    }
+    if per_rank is not None:
+        res["per_rank_ms_per_step"] = per_rank
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -331,6 +417,8 @@ def main():
         if not args.dry_run:
             torch.cuda.synchronize()
 
+    if args.train:
+        return train_main(args, world, rank, dev, sync)
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
     B = args.batch

@@ -53,6 +53,14 @@ def make_batch(B, nq=2048, nt=5000, S=224, seed=0, noise=5e-4, device="cpu"):
     return out, torch.stack(Rs).to(device), torch.stack(ts).to(device)
 
 
+def make_train_batch(B, nq=2048, nt=5000, S=224, seed=0, noise=5e-4, device="cpu"):
+    """`make_batch` + the two labels a training item carries (`rotation_label` (B,3,3), `translation_label` (B,3):
+    pfoneref_training_dataset_v2.py:560-590); the pose noise of the coarse stage is drawn inside the forward."""
+    batch, R, t = make_batch(B, nq, nt, S, seed, noise, device)
+    batch["rotation_label"], batch["translation_label"] = R, t
+    return batch
+
+
 def trained_like_(model, seed=0, tame=0.1):
     """In-place seeded init that behaves like a trained matcher on congruent pairs (there are no
     checkpoints in this environment): default torch init, BN running stats randomised, token-mixing
