@@ -39,3 +39,13 @@ def test_product_never_imports_oracle():
     for path in glob.glob(os.path.join(ROOT, "unopose_amd", "**", "*.py"), recursive=True):
         src = open(path).read()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md's table maps every C-ABI symbol to the reference interface it replaces: no declared symbol may be missing
+    from it and it may not name symbols the header no longer declares."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    declared = _declared_symbols()
+    named = set(re.findall(r"`(unopose_[a-z0-9_]+)`", doc))
+    assert sorted(set(declared) - named) == []
+    assert sorted(s for s in named - set(declared) if s not in ("unopose_amd", "unopose_hip", "unopose_stream_t", "unopose_ball_query.restype")) == []

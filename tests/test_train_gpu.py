@@ -102,3 +102,41 @@ def test_train_step_at_baseline_config3_shape():
     missing = [k for k, p in m.named_parameters() if p.requires_grad and p.grad is None]
     assert missing == [], missing
     assert all(p.grad is None for p in m.feature_extraction.rgb_net.vit.parameters())
+
+
+@pytest.mark.parametrize("amp", [False, True])
+@pytest.mark.parametrize("relu", [False, True])
+def test_trainable_linear_on_own_gemm_matches_torch_autograd(amp, relu):
+    """`ops.linear` in differentiable mode: forward and input gradient on csrc/gemm_f32.hip (fp32) / csrc/gemm.hip (autocast),
+    weight / bias gradients through torch -- against torch.nn.functional.linear's autograd in float64 (fp32 mode: the bf16 x 3
+    products give ~2^-17 relative error) or in the same bf16 autocast (bf16 mode: operand rounding only)."""
+    from unopose_amd import ops
+
+    torch.manual_seed(0)
+    rows, K, N = 3 * 197, 256, 512
+    lin = torch.nn.Linear(K, N).cuda()
+    x = torch.randn(3, 197, K, device="cuda", requires_grad=True)
+    gy = torch.randn(3, 197, N, device="cuda")
+    with ops.differentiable(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        y = ops.linear(x, lin, relu=relu)
+    assert y.grad_fn is not None and type(y.grad_fn).__name__ == "_LinearFnBackward"  # the own-GEMM path, not nn.Linear
+    y.float().backward(gy)
+    got = (y.detach().float(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x.grad = lin.weight.grad = lin.bias.grad = None
+    if amp:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            r = torch.nn.functional.linear(x, lin.weight, lin.bias)
+            r = torch.relu(r) if relu else r
+        r.float().backward(gy)
+        want = (r.detach().float(), x.grad, lin.weight.grad, lin.bias.grad)
+        tol = 2e-2
+    else:
+        xd, wd, bd = x.detach().double().requires_grad_(), lin.weight.detach().double().requires_grad_(), lin.bias.detach().double().requires_grad_()
+        r = torch.nn.functional.linear(xd, wd, bd)
+        r = torch.relu(r) if relu else r
+        r.backward(gy.double())
+        want = (r.detach(), xd.grad, wd.grad, bd.grad)
+        tol = 3e-5
+    for name, g, w in zip(("y", "dx", "dw", "db"), got, want):
+        scale = float(w.abs().max())
+        assert float((g.double() - w.double()).abs().max()) < tol * scale, (name, float((g.double() - w.double()).abs().max()), scale)

@@ -302,7 +302,7 @@ class _AttentionOutput(nn.Module):
     def forward(self, x):
         if x.is_cuda and not ops.is_differentiable():  # squeeze + residual + LayerNorm: one launch under autocast
             return ops.linear_add_layernorm(ops.linear(x, self.expand, relu=True), self.squeeze, x, self.norm)
-        return self.norm(x + self.squeeze(F.relu(self.expand(x))))
+        return self.norm(x + ops.linear(ops.linear(x, self.expand, relu=True), self.squeeze))
 
 
 class TransformerLayer(nn.Module):
@@ -322,7 +322,7 @@ class TransformerLayer(nn.Module):
         if x.is_cuda and not ops.is_differentiable():
             x = ops.linear_add_layernorm(h, a.linear, x, a.norm)
         else:
-            x = a.norm(a.linear(h) + x)
+            x = a.norm(ops.linear(h, a.linear) + x)
         return self.output(x)
 
 
@@ -400,7 +400,7 @@ class LinearTransformerLayer(nn.Module):
         if x.is_cuda and not ops.is_differentiable():
             x = ops.linear_add_layernorm(h, a.linear, x, a.norm)
         else:
-            x = a.norm(a.linear(h) + x)
+            x = a.norm(ops.linear(h, a.linear) + x)
         return self.output(x)
 
 

@@ -34,7 +34,7 @@ def _block_outputs(out_proj, score_head, f1, f2, n1, temp):
     """What the training branch keeps per transformer block (C:62-76, Fi:85-99): the similarity of the projected
     features, the overlap scores and the saliency = overlap scores propagated through the row / column softmax."""
     scores = score_head(torch.cat((f1, f2), dim=1))
-    atten = ops.feature_similarity(out_proj(f1), out_proj(f2), temp)
+    atten = ops.feature_similarity(ops.linear(f1, out_proj), ops.linear(f2, out_proj), temp)
     s1, s2 = scores[:, 1:(n1 + 1)], scores[:, (n1 + 2):]
     inner = atten[:, 1:, 1:]
     m1 = torch.matmul(F.softmax(inner, dim=2), s2)
@@ -62,8 +62,8 @@ class CoarsePointMatchingOneRef(nn.Module):
         (R, t) when the caller injects the draw, as the parity tests do)."""
         B, n1 = f1.shape[:2]
         bg = self.bg_token.expand(B, -1, -1)
-        f1 = torch.cat([bg, self.in_proj(f1)], dim=1)
-        f2 = torch.cat([bg, self.in_proj(f2)], dim=1)
+        f1 = torch.cat([bg, ops.linear(f1, self.in_proj)], dim=1)
+        f2 = torch.cat([bg, ops.linear(f2, self.in_proj)], dim=1)
         attens, scores, sals = [], [], []
         for blk, head in zip(self.transformers, self.score_heads):
             f1, f2 = blk(f1, geo1, f2, geo2)
@@ -129,8 +129,8 @@ class FinePointMatchingOneRef(nn.Module):
         B, n1 = p1.shape[:2]
         p1_ = (p1 - end_points["init_t"].unsqueeze(1)) @ end_points["init_R"] if "init_R" in end_points else p1
         bg = self.bg_token.expand(B, -1, -1)
-        f1 = torch.cat([bg, self.in_proj(f1) + self.PE(p1_)], dim=1)
-        f2 = torch.cat([bg, self.in_proj(f2) + self.PE(p2)], dim=1)
+        f1 = torch.cat([bg, ops.linear(f1, self.in_proj) + self.PE(p1_)], dim=1)
+        f2 = torch.cat([bg, ops.linear(f2, self.in_proj) + self.PE(p2)], dim=1)
         attens, scores, sals = [], [], []
         for blk, head in zip(self.transformers, self.score_heads):
             f1, f2 = blk(f1, geo1, fps_idx1, f2, geo2, fps_idx2)
@@ -364,7 +364,7 @@ class UNOPose(nn.Module):
         B, _, H, W = rgb.shape
         side = H // 14
         z = torch.cat([o[:, 5:, :] for o in taps], dim=2).float()
-        z = net.output_upscaling(z).reshape(B, side, side, 4, 4, net.out_dim)
+        z = ops.linear(z, net.output_upscaling).reshape(B, side, side, 4, 4, net.out_dim)
         low = z.permute(0, 1, 3, 2, 4, 5).reshape(B, 4 * side, 4 * side, net.out_dim)
         return ops.bilinear_sample_pixels(low, choose, H, W)
 

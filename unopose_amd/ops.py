@@ -248,6 +248,104 @@ def linear_f32_raw(x, w, b, owner, tag):
     return linear_f32x3(split_f32(_c(x.float()).reshape(rows, K)), c[1], c[2], rows, N, K).reshape(*x.shape[:-1], N)
 
 
+# ---- trainable linears: forward and input gradient on the hand-written GEMMs, recorded by autograd ------
+TRAIN_OWN_GEMM = os.environ.get("UNOPOSE_TRAIN_OWN_GEMM", "1") == "1"  # A/B switch: 0 = nn.Linear through the library
+
+
+def _transposed_weights(lin, kind):
+    """W^T (K,N) in the operand form of the input-gradient GEMM dX = dY W, cached on the module per weight version:
+    kind "f32": split layout of csrc/gemm_f32.hip, "bf16": bf16 rows."""
+    key = (lin.weight._version, lin.weight.data_ptr(), kind)
+    cache = lin.__dict__.setdefault("_wt_cache", {})
+    c = cache.get(kind)
+    if c is None or c[0] != key:
+        with torch.no_grad():
+            wt = lin.weight.detach().float().t().contiguous()
+            c = (key, split_f32(wt) if kind == "f32" else wt.to(torch.bfloat16))
+        cache[kind] = c
+    return c[1]
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) for the trainable layers of the matcher, act in {none, ReLU}.  Forward: csrc/gemm_f32.hip (fp32: bf16 x 3
+    matrix-core products, fp32 accumulation) or csrc/gemm.hip (autocast: bf16 operands) with bias / ReLU in the epilogue -- the
+    kernels of the eval path.  Backward: dX = (dY * act') W on the same kernels against a cached W^T; dW = dY^T X and db = sum dY
+    are reductions over the rows and go through torch (fp32 accumulate).  Gradients follow torch.nn.functional.linear's to
+    the rounding of the products (tests/test_train_gpu.py)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, lin, relu, bf16):
+        K = x.shape[-1]
+        N = weight.shape[0]
+        x2 = _c(x).reshape(-1, K)
+        rows = x2.shape[0]
+        if bf16:
+            c = _bf16_weights(lin)
+            xb = x2 if x2.dtype == torch.bfloat16 else x2.to(torch.bfloat16)
+            y = linear_bf16_hip(xb, c[1], c[3], False, relu)
+            ctx.save_for_backward(xb, y if relu else None)
+        else:
+            c = _f32x3_weights(lin)
+            x2 = x2.float()
+            y = linear_f32x3(split_f32(x2), c[1], c[2], rows, N, K, False, relu)
+            ctx.save_for_backward(x2, y if relu else None)
+        ctx.lin, ctx.relu, ctx.bf16, ctx.shape, ctx.has_bias, ctx.in_dtype = lin, relu, bf16, x.shape, bias is not None, x.dtype
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, y = ctx.saved_tensors
+        lin = ctx.lin
+        N, K = lin.weight.shape
+        g = _c(gy).reshape(-1, N)
+        if ctx.relu:
+            g = g * (y > 0).to(g.dtype)
+        rows = g.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if ctx.bf16 and own_gemm_ok(rows, K, N):
+                gb16 = g if g.dtype == torch.bfloat16 else g.to(torch.bfloat16)
+                gx = linear_bf16_hip(_c(gb16), _transposed_weights(lin, "bf16"), _zero_bias(K, g.device), False, False)
+            elif not ctx.bf16 and f32x3_ok(rows, K, N):
+                gx = linear_f32x3(split_f32(_c(g.float())), _transposed_weights(lin, "f32"), _zero_bias(K, g.device), rows, K, N)
+            else:
+                gx = g.to(lin.weight.dtype) @ lin.weight.detach()
+            gx = gx.reshape(ctx.shape).to(ctx.in_dtype)
+        if ctx.needs_input_grad[1]:
+            gw = (g.t() @ x2.to(g.dtype)).to(lin.weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.float().sum(0).to(lin.bias.dtype)
+        return gx, gw, gb, None, None, None
+
+
+_ZERO_BIAS = {}
+
+
+def _zero_bias(n, device):
+    key = (n, device)
+    if key not in _ZERO_BIAS:
+        _ZERO_BIAS[key] = torch.zeros(n, device=device)
+    return _ZERO_BIAS[key]
+
+
+def linear_train(x, lin, relu=False):
+    """The training-mode `linear`: own GEMM forward + input gradient under autograd when the shape fits, else nn.Linear."""
+    N, K = lin.weight.shape
+    rows = x.numel() // K
+    bf16 = torch.is_autocast_enabled()
+    ok = TRAIN_OWN_GEMM and x.is_cuda and rows > 0 and (own_gemm_ok(rows, N, K) if bf16 else (x.dtype == torch.float32 and f32x3_ok(rows, N, K)))
+    if not ok:
+        y = lin(x)
+        return F.relu(y) if relu else y
+    return _LinearFn.apply(x, lin.weight, lin.bias, lin, relu, bf16)
+
+
+def _lin(x, lin):
+    """Inside the op-by-op composites: the trainable form in differentiable mode, the plain module call otherwise (the
+    composites stay library-only A/B references of the fused kernels)."""
+    return linear_train(x, lin) if (_DIFF and torch.is_grad_enabled()) else lin(x)
+
+
 def _f32_path(x):
     return x.is_cuda and x.dtype == torch.float32 and not _DIFF and not torch.is_autocast_enabled()
 
@@ -278,6 +376,8 @@ def linear(x, lin, relu=False, gelu=False):
         if f32x3_ok(rows, N, K):
             c = _f32x3_weights(lin)
             return linear_f32x3(split_f32(_c(x).reshape(rows, K)), c[1], c[2], rows, N, K, gelu, relu).reshape(*x.shape[:-1], N)
+    if _DIFF and not gelu and torch.is_grad_enabled():
+        return linear_train(x, lin, relu)
     if _DIFF or not (torch.is_autocast_enabled() and x.is_cuda):
         y = lin(x)
         return F.relu(y) if relu else (F.gelu(y) if gelu else y)
@@ -709,8 +809,8 @@ def geo_embedding_torch(points, m):
             return torch.stack([torch.sin(om), torch.cos(om)], dim=-1).reshape(*idx.shape, -1)
 
         sd, sa = sinus(d_idx), sinus(a_idx)
-    d_emb = m.proj_d(sd)
-    a_emb = m.proj_a(sa)
+    d_emb = _lin(sd, m.proj_d)
+    a_emb = _lin(sa, m.proj_a)
     a_emb = a_emb.max(dim=3)[0] if m.reduction_a == "max" else a_emb.mean(dim=3)
     return d_emb + a_emb
 
@@ -838,9 +938,9 @@ def token_attention_torch(x, mem, att, heads, embed=None):
     """Op-by-op composite of the same function (fp32 path; A/B reference for the HIP kernel)."""
     B, n, C = x.shape
     hd = C // heads
-    q = att.proj_q(x).reshape(B, n, heads, hd)
-    k = att.proj_k(mem).reshape(B, -1, heads, hd)
-    v = att.proj_v(mem).reshape(B, -1, heads, hd)
+    q = _lin(x, att.proj_q).reshape(B, n, heads, hd)
+    k = _lin(mem, att.proj_k).reshape(B, -1, heads, hd)
+    v = _lin(mem, att.proj_v).reshape(B, -1, heads, hd)
     s = torch.einsum("bnhc,bmhc->bhnm", q, k)
     if embed is not None:
         wp = att.proj_p.weight.reshape(heads, hd, C)  # rows of W_p grouped by head
@@ -931,7 +1031,7 @@ def _focused_linear_attention_hip(xq, xkv, att, focusing):
 
 def focused_linear_attention_torch(xq, xkv, att, heads, focusing):
     """Op-by-op composite, kv branch (the shape test at transformer.py:560 is static)."""
-    q, k, v = att.proj_q(xq), att.proj_k(xkv), att.proj_v(xkv)
+    q, k, v = _lin(xq, att.proj_q), _lin(xkv, att.proj_k), _lin(xkv, att.proj_v)
     dt = v.dtype
     q, k = q.float(), k.float()
     scale = F.softplus(att.scale.float())
