@@ -46,6 +46,9 @@ def parse(argv=None):
                     help="PipelinedForward(stages=...): 1 = ViT half and matcher half of every forward on two streams, 0 = whole "
                          "forwards side by side, auto = by ViT size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the CPU port once with EVERY hardware thread (adds ~10 min on a 256-thread host: 292 s per B=8 forward, "
+                         "0.027 pairs/s -- profiles/r03_bench_n1_bf16_s518.json holds that run)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the extra fp32 (reference default precision) leg")
     ap.add_argument("--train", action="store_true",
@@ -255,13 +258,14 @@ def _cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline_leg(img, batches=(1, 8), timed=2):
+def cpu_baseline_leg(img, batches=(1, 8), timed=2, all_cores=False):
     """The oracle (torch-CPU port of the reference forward + the C `_ext` port; kind "port": the reference's
     Python cannot travel) timed on this host's cores on a bounded sample of the same workload
     (SURVEY.md 8(d)): per batch size one warm-up forward, then `timed` timed forwards; value = the best
-    batch size's median rate.  The reported value uses torch's intra-op pool at min(32, cores) threads (more threads
-    only add contention at these op sizes); the same forward with EVERY hardware thread is timed once beside it
-    (`all_cores`), so the choice is visible in the line."""
+    batch size's median rate.  The reported value uses torch's intra-op pool at min(32, cores) threads: more threads
+    only add contention at these op sizes -- with all 256 hardware threads of the GPU box's host the same B=8 forward takes
+    292 s instead of 26 s (0.027 vs 0.30 pairs/s; `--cpu-all-cores` repeats that measurement, the committed run is
+    profiles/r03_bench_n1_bf16_s518.json)."""
     import torch
 
     from oracle import unopose_ref as R
@@ -295,7 +299,7 @@ def cpu_baseline_leg(img, batches=(1, 8), timed=2):
                cpu_model=_cpu_model_name(), by_batch=by_batch,
                sample=f"batches of {list(batches)} pairs (2048 query / 5000 reference points, {img}x{img} crops), 1 warm-up + "
                       f"{timed} timed forwards each, fp32, torch {threads} threads + C `_ext` port; value = best median")
-    if host > threads:
+    if all_cores and host > threads:
         b = max(batches)
         r = run(b, host, 1)
         out["all_cores"] = dict(threads=host, batch=b, **r)
@@ -591,7 +595,7 @@ def main():
             res.update(roofline_leg(model, batch, args.img))
             log("roofline leg done")
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline_leg(args.img)
+            res["cpu_baseline"] = cpu_baseline_leg(args.img, all_cores=args.cpu_all_cores)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

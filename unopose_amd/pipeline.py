@@ -190,7 +190,8 @@ class PipelinedForward:
         kernels never share the device with them; later `submit`s wait for the caller's stream as always."""
         cur = torch.cuda.current_stream(self.device)
         for t in self._pending:
-            cur.wait_event(t.done)
+            if t._done is not None:
+                cur.wait_event(t._done)
         with torch.no_grad():
             if self.autocast_dtype is None:
                 return self.model.encode_reference(tem1_rgb, tem1_choose, tem1_pts)
