@@ -185,6 +185,14 @@ int unopose_pe_group_mlp_max(const float *xyz, int B, int N, float radius, int n
  * assign_labels: streaming softmax statistics into stats_ws (2*B*(R+C) floats:
  * [rmax B*R | 1/rsum B*R | cmax B*C | 1/csum B*C], the sums of exp(x - max) stored as reciprocals) and the foreground masks
  * w1 (B,R-1) = [argmax_j a_ij > 0], w2 (B,C-1) = [argmax_i a_ij > 0]  (:444-447, :542-545). */
+/* Training (core/unopose/utils/loss_utils.py:181-187, the two-way InfoNCE "atten" loss of compute_overlap_loss):
+ * softmax_stats writes the statistics alone (same stats_ws layout); infonce_grad writes, for labels label1 (B,R-1) / label2 (B,C-1)
+ * (int64; 0 = background column / row) and the upstream gradient g (B) of
+ *   L_b = 0.5 (mean_{i>=1} CE(row i over all columns, label1) + mean_{j>=1} CE(column j over all rows, label2)),
+ * dL/dx into grad (B,R,C) in one pass over x. */
+int unopose_softmax_stats(const float *x, int B, int R, int C, float *stats_ws, unopose_stream_t stream);
+int unopose_infonce_grad(const float *x, int B, int R, int C, const float *stats_ws, const long long *label1,
+                         const long long *label2, const float *g, float *grad, unopose_stream_t stream);
 int unopose_assign_labels(const float *atten, int B, int R, int C, const float *score1,
                           const float *score2, float *stats_ws, float *w1, float *w2,
                           unopose_stream_t stream);

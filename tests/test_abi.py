@@ -49,3 +49,25 @@ def test_integration_doc_names_every_entry_point():
     named = set(re.findall(r"`(unopose_[a-z0-9_]+)`", doc))
     assert sorted(set(declared) - named) == []
     assert sorted(s for s in named - set(declared) if s not in ("unopose_amd", "unopose_hip", "unopose_stream_t", "unopose_ball_query.restype")) == []
+
+
+def test_no_packed_fp32_instructions_in_any_kernel():
+    """DESIGN.md section 7 (round 3): kernels containing v_pk_{mul,add,fma}_f32 return wrong values when MFMA waves of another kernel
+    share their CU.  Every source is compiled to gfx950 ISA with the product flags; none may contain such an instruction."""
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+
+    from unopose_amd import build
+
+    srcs = sorted(f for f in os.listdir(build.CSRC) if f.endswith(".hip"))
+
+    def count(f):
+        r = subprocess.run([build._hipcc(), *build.FLAGS, *build.EXTRA_FLAGS.get(f, []), "-S", "--cuda-device-only", os.path.join(build.CSRC, f), "-o", "-"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return f, len(re.findall(r"\bv_pk_(?:mul|add|fma)_f32\b", r.stdout)), len(re.findall(r"\bv_mfma_", r.stdout))
+
+    with ThreadPoolExecutor(6) as ex:
+        res = list(ex.map(count, srcs))
+    assert [(f, n) for f, n, _ in res if n] == []
+    assert sum(m for _, _, m in res) > 1000  # the disassembly really is the device code (the MFMA kernels are in it)

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libunopose_hip.so")
+# UNOPOSE_LIB: an alternative build of the SAME library (scripts/build_variant.py: same sources, other compiler flags) for same-box A/Bs
+SO_PATH = os.environ.get("UNOPOSE_LIB") or os.path.join(_HERE, "libunopose_hip.so")
 
 _lib = None
 
@@ -34,6 +35,8 @@ SIGNATURES = {
     "unopose_query_lrf_group": [_P, _I, _I, _F, _I, _P, _P],
     "unopose_weighted_procrustes": [_P, _P, _P, _I, _I, _F, _F, _P, _P, _P],
     "unopose_assign_labels": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "unopose_softmax_stats": [_P, _I, _I, _I, _P, _P],
+    "unopose_infonce_grad": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "unopose_fine_correspondences": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "unopose_upproj_plan": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "unopose_linear_add_layernorm_bf16": [_P, _P, _P, _P, _P, _P, _F, _P, ctypes.c_long, _I, _P],

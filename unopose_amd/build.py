@@ -16,8 +16,16 @@ SO = os.path.join(HERE, "libunopose_hip.so")
 ARCH = "gfx950"
 # -ffp-contract=off: fp32 distance expressions must round exactly as written so
 # FPS / ball_query indices are bit-identical to oracle/ (DESIGN.md "fp-contract").
-FLAGS = [*os.environ.get("UNOPOSE_EXTRA_HIPCC_FLAGS", "").split(), "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall",
-         "-Wno-unused-function"]
+# -fno-slp-vectorize -fno-vectorize: NO packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  hipcc -O2 / -O3 forms them
+# out of scalar fp32 code (97 in query_lrf_group alone); kernels that contain them return wrong values for a few elements per
+# launch whenever waves of ANOTHER kernel issuing MFMAs share their CU -- 23 of 30 launches beside a neighbour that does nothing but
+# v_mfma, 0 of 30 when built with this flag or at -O1, and never beside VALU / LDS / memory / barrier neighbours
+# (scripts/ubench/coresidency_matrix.py, geom_var.py; the loop vectoriser forms a few more, hence both flags).
+# Packed fp32 brings no throughput on gfx950, so the
+# flags cost nothing (898 vs 892 pairs/s, inside the run-to-run spread).  tests/test_abi.py compiles every source to ISA with
+# these flags and fails if a packed-fp32 instruction is left.
+FLAGS = [*os.environ.get("UNOPOSE_EXTRA_HIPCC_FLAGS", "").split(), "-O3", "-fno-slp-vectorize", "-fno-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 # Dense-math kernels: `nnan` lets fmaxf lower to ONE v_max_f32 instead of canonicalise + max (the PE tile
 # loop had 288 v_max for 112 logical maxima).  Not applied to the index-producing files (pointnet2, geom,
 # posehead), whose NaN behaviour follows the reference's fminf / fmaxf semantics.

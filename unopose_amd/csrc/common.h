@@ -136,6 +136,18 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 #endif
 }
 
+#ifndef UNOPOSE_SUM_VGPR
+#define UNOPOSE_SUM_VGPR 0  // 1: the four row results reach every lane through ds_bpermute (VGPR to VGPR) instead of v_readlane (SGPR)
+#endif
+// lane index the compiler cannot see through (keeps ds_bpermute from being folded into v_readlane)
+__device__ __forceinline__ int opaque_lane(int l) {
+  asm volatile("" : "+v"(l));
+  return l;
+}
+__device__ __forceinline__ float lane_bcast_vgpr(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(opaque_lane(src_lane) << 2, __float_as_int(v)));
+}
+
 __device__ __forceinline__ float wave_sum_f32(float v) {
 #if UNOPOSE_SUM_SHFL
   // probe: no DPP at all -- the same pairing tree through ds_bpermute
@@ -147,6 +159,12 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
   v += dpp_f32<0x112, 0xF>(v, 0.f);
   v += dpp_f32<0x114, 0xF>(v, 0.f);
   v += dpp_f32<0x118, 0xF>(v, 0.f);
+#if UNOPOSE_SUM_VGPR
+  {
+    const float q0 = lane_bcast_vgpr(v, 15), q1 = lane_bcast_vgpr(v, 31), q2 = lane_bcast_vgpr(v, 47), q3 = lane_bcast_vgpr(v, 63);
+    return (q3 + q2) + (q1 + q0);
+  }
+#endif
 #if UNOPOSE_ROW_BCAST
   v += dpp_f32<0x142, 0xA>(v, 0.f);
   v += dpp_f32<0x143, 0xC>(v, 0.f);

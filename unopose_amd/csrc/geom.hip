@@ -105,6 +105,12 @@ __global__ __launch_bounds__(256) void lrf_global_kernel(const float *__restrict
   }
 }
 
+#ifndef UNOPOSE_VOTE_VGPR
+#define UNOPOSE_VOTE_VGPR 0  // probes of the co-residency finding (scripts/ubench/geom_var.py)
+#endif
+#ifndef UNOPOSE_QLG_NOEIG
+#define UNOPOSE_QLG_NOEIG 0
+#endif
 #ifndef UNOPOSE_LRF_DEBUG
 #define UNOPOSE_LRF_DEBUG 0  // probe build (scripts/ubench): per-centre intermediates of the frame into a debug buffer
 #endif
@@ -181,8 +187,30 @@ __global__ __launch_bounds__(256) void query_lrf_group_kernel(const float *__res
     a22 = wave_sum_f32(a22) * inv_s;
     Vec3 e0, e1, z0;
     float l0, l1, l2;
+#if UNOPOSE_QLG_NOEIG
+    {  // probe: no eigen-solver -- a direction computed with three multiplies and one rsqrt
+      const float nx = a00 + 1e-3f, ny = a01, nz = a02, rn = __builtin_amdgcn_rsqf(nx * nx + ny * ny + nz * nz);
+      z0 = v3(nx * rn, ny * rn, nz * rn);
+      e0 = e1 = z0;
+      l0 = l1 = l2 = 0.f;
+    }
+#else
     eig_sym3(a00, a01, a02, a11, a12, a22, e0, e1, z0, l0, l1, l2);
+#endif
 
+#if UNOPOSE_VOTE_VGPR
+    float votef = 0.f;  // probe: the sign vote as a wave sum of +-1 (exact in fp32), never through an SGPR mask
+    for (int l0i = 0; l0i < S; l0i += 64) {
+      const int l = l0i + lane;
+      float pr = 0.f;
+      if (l < S) {
+        const int k = nbr[l];
+        pr = z0.x * (cx - sx[k]) + z0.y * (cy - sy[k]) + z0.z * (cz - sz[k]);
+      }
+      votef += (pr > 1e-3f ? 1.f : 0.f) - (pr < -1e-3f ? 1.f : 0.f);
+    }
+    const int vote = (int)wave_sum_f32(votef);
+#else
     int vote = 0;
     for (int l0i = 0; l0i < S; l0i += 64) {
       const int l = l0i + lane;
@@ -193,6 +221,7 @@ __global__ __launch_bounds__(256) void query_lrf_group_kernel(const float *__res
       }
       vote += __builtin_popcountll(__ballot(pr > 1e-3f)) - __builtin_popcountll(__ballot(pr < -1e-3f));
     }
+#endif
     const Vec3 zp = vote < 0 ? scale(z0, -1.f) : z0;
 
     float vx = 0, vy = 0, vz = 0;

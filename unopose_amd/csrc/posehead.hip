@@ -398,11 +398,66 @@ __global__ __launch_bounds__(256) void coarse_score_kernel(const float *__restri
   }
 }
 
+// ---- training: gradient of the two-way InfoNCE ("atten") loss of compute_overlap_loss (loss_utils.py:181-187) w.r.t. the
+// similarity matrix, from the streaming softmax statistics above:
+//   L_b = 0.5 ( mean_{i>=1} CE(row i over ALL columns, label1[i-1]) + mean_{j>=1} CE(column j over ALL rows, label2[j-1]) )
+//   dL_b / dx_ij = 0.5 ( [i>=1] (softmax_row(i,j) - [j == label1[i-1]]) / (R-1) + [j>=1] (softmax_col(i,j) - [i == label2[j-1]]) / (C-1) )
+// scaled by the upstream gradient g[b].  One read and one write of the matrix; four elements per lane.
+__global__ __launch_bounds__(256) void infonce_grad_kernel(const float *__restrict__ x, int R, int C, const float *__restrict__ rmax,
+                                                           const float *__restrict__ rinv, const float *__restrict__ cmax,
+                                                           const float *__restrict__ cinv, const long long *__restrict__ label1,
+                                                           const long long *__restrict__ label2, const float *__restrict__ g,
+                                                           float *__restrict__ grad) {
+  const int b = blockIdx.z, i = blockIdx.y;
+  const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (j0 >= C) return;
+  const size_t rowoff = ((size_t)b * R + i) * C;
+  const float gb = 0.5f * g[b];
+  const float wr = i >= 1 ? gb / (float)(R - 1) : 0.f, wc = gb / (float)(C - 1);
+  const float rm = rmax[(size_t)b * R + i], ri = rinv[(size_t)b * R + i];
+  const int lab1 = i >= 1 ? (int)label1[(size_t)b * (R - 1) + i - 1] : -1;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int j = j0 + u;
+    if (j >= C) break;
+    const float v = x[rowoff + j];
+    float d = wr * (ph_exp(v - rm) * ri - (j == lab1 ? 1.f : 0.f));
+    if (j >= 1) {
+      const float pc = ph_exp(v - cmax[(size_t)b * C + j]) * cinv[(size_t)b * C + j];
+      d += wc * (pc - ((int)label2[(size_t)b * (C - 1) + j - 1] == i ? 1.f : 0.f));
+    }
+    grad[rowoff + j] = d;
+  }
+}
+
 }  // namespace unopose
 
 using namespace unopose;
 
 extern "C" {
+
+// The streaming softmax statistics alone (training: the two-way InfoNCE loss needs row and column log-sum-exps of the similarity).
+int unopose_softmax_stats(const float *x, int B, int R, int C, float *stats_ws, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(x && stats_ws, "softmax_stats: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && R >= 1 && C >= 1 && B <= 65535, "softmax_stats: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  float *rmax = stats_ws, *rsum = rmax + (size_t)B * R, *cmax = rsum + (size_t)B * R, *csum = cmax + (size_t)B * C;
+  hipLaunchKernelGGL(row_stats_kernel, dim3(cdiv(R, 4), B), dim3(256), 0, s, x, R, C, rmax, rsum);
+  hipLaunchKernelGGL(col_stats_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, s, x, R, C, cmax, csum);
+  return check_launch("softmax_stats");
+}
+
+int unopose_infonce_grad(const float *x, int B, int R, int C, const float *stats_ws, const long long *label1, const long long *label2,
+                         const float *g, float *grad, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(x && stats_ws && label1 && label2 && g && grad, "infonce_grad: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && R >= 2 && C >= 2 && B <= 65535 && R <= 65535, "infonce_grad: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  const float *rmax = stats_ws, *rsum = rmax + (size_t)B * R, *cmax = rsum + (size_t)B * R, *csum = cmax + (size_t)B * C;
+  hipLaunchKernelGGL(infonce_grad_kernel, dim3(cdiv(C, 1024), R, B), dim3(256), 0, (hipStream_t)stream, x, R, C, rmax, rsum, cmax, csum,
+                     label1, label2, g, grad);
+  return check_launch("infonce_grad");
+}
 
 // Statistics of the soft assignment: ws = 2*(R+C) floats per batch element
 // [rmax R | rsum R | cmax C | csum C]; w1 (B,R-1), w2 (B,C-1).

@@ -17,6 +17,19 @@ def _pairwise_sq_dist(x, y):
     return ((x ** 2).sum(-1).unsqueeze(-1) - 2 * xy + (y ** 2).sum(-1).unsqueeze(-2)).clamp(min=0.0)
 
 
+def _infonce(atten, label1, label2):
+    """0.5 (CE over the columns for every query row + CE over the rows for every reference column), background = class 0
+    (loss_utils.py:181-187).  On a HIP device: unopose_amd.ops.infonce_two_way (streaming statistics + one gradient pass)."""
+    if atten.is_cuda:
+        from . import ops
+
+        return ops.infonce_two_way(atten, label1, label2)
+    a = atten.float()
+    l1 = F.cross_entropy(a.transpose(1, 2)[:, :, 1:], label1, reduction="none").mean(1)  # classes = columns, per query row
+    l2 = F.cross_entropy(a[:, :, 1:], label2, reduction="none").mean(1)
+    return 0.5 * (l1 + l2)
+
+
 def weighted_bce(pred, target):
     """Class-balanced binary cross entropy per sample: positives weighted by the negative fraction and vice versa
     (loss_utils.py:111-129).  pred, target (B, n) in [0, 1] -> (B,)."""
@@ -52,10 +65,7 @@ def _overlap_losses(end_points, atten_list, score_list, saliency_list, pts1, pts
     d2, nn2 = dist.min(1)
     label2 = torch.where(d2 <= dis_thres, nn2 + 1, torch.zeros_like(nn2))
     for i, atten in enumerate(atten_list):
-        a = atten.float()
-        l1 = F.cross_entropy(a.transpose(1, 2)[:, :, 1:], label1, reduction="none").mean(1)  # classes = columns, per query row
-        l2 = F.cross_entropy(a[:, :, 1:], label2, reduction="none").mean(1)
-        end_points[f"{prefix}_atten_loss{i}"] = 0.5 * (l1 + l2)
+        end_points[f"{prefix}_atten_loss{i}"] = _infonce(atten, label1, label2)
     pred = atten_list[-1][:, 1:, :].max(dim=2)[1]
     fg = (pred > 0).float()
     end_points[f"{prefix}_acc"] = (pred == label1).float().mean(1)

@@ -20,8 +20,9 @@ from .modules import (GeometricStructureEmbedding, GeometricTransformer, Positio
 STACKED_FINE = os.environ.get("UNOPOSE_STACKED_FINE", "1") == "1"  # A/B switch for the 2B-stacked fine matcher
 # Reference-cloud PE on a side stream under the coarse stage: OFF by default since round 3 -- the PE / frame kernels are not
 # reproducible when waves of the token attention kernel share their CU; "1" restores the round-2 overlap (+1.5 %).
-PE_UNDER_COARSE = os.environ.get("UNOPOSE_PE_UNDER_COARSE", "0") == "1"
-GEOM_UNDER_VIT = int(os.environ.get("UNOPOSE_GEOM_UNDER_VIT", "1"))  # 1: LRF / FPS-196 / gathers, 2: + embedding
+PE_UNDER_COARSE = os.environ.get("UNOPOSE_PE_UNDER_COARSE", "1") == "1"
+GEOM_UNDER_VIT = int(os.environ.get("UNOPOSE_GEOM_UNDER_VIT", "1"))  # 1: FPS-196 / gathers, 2: + frames + embedding
+LRF_UNDER_VIT = os.environ.get("UNOPOSE_LRF_UNDER_VIT", "1") == "1"  # the two global frames on the side stream as well
 
 
 def _scores(scores, n1):
@@ -286,12 +287,12 @@ class UNOPose(nn.Module):
                 pre["idx_o"] = ops.furthest_point_sample(dense_po, self.coarse_npoint)
                 pre["sparse_pm"] = ops.gather_rows(dense_pm.float(), pre["idx_m"])
                 pre["sparse_po"] = ops.gather_rows(dense_po.float(), pre["idx_o"])
-                # (the two global frames are NOT computed here: the frame kernels change their results when waves of an MFMA kernel of
-                # another stream -- the previous batch's token attention in a pipelined runner -- share their CU: DESIGN.md section 7;
-                # `_forward_from` computes them on the matcher's own stream)
-                if GEOM_UNDER_VIT > 1:
+                # (the frame kernels used to change results here, beside the previous batch's token attention in a pipelined runner:
+                # packed-fp32 instructions next to another kernel's MFMAs, DESIGN.md section 7 -- the library is built without them now)
+                if GEOM_UNDER_VIT > 1 or LRF_UNDER_VIT:
                     pre["sparse_pm_lrf"] = ops.gather_rows(ops.lrf_global(end_points["pts"], self.use_ref_rad), pre["idx_m"])
                     pre["sparse_po_lrf"] = ops.gather_rows(ops.lrf_global(tem_pts, self.use_ref_rad), pre["idx_o"])  # NB App-E.1: full 5000-point cloud
+                if GEOM_UNDER_VIT > 1:
                     bg_point = torch.ones(dense_pm.size(0), 1, 3, device=dense_pm.device)
                     pre["geo"] = self.geo_embedding(torch.cat([torch.cat([bg_point, pre["sparse_pm_lrf"]], dim=1),
                                                                torch.cat([bg_point, pre["sparse_po_lrf"]], dim=1)], dim=0))

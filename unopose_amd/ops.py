@@ -248,8 +248,59 @@ def linear_f32_raw(x, w, b, owner, tag):
     return linear_f32x3(split_f32(_c(x.float()).reshape(rows, K)), c[1], c[2], rows, N, K).reshape(*x.shape[:-1], N)
 
 
+# ---- two-way InfoNCE loss of the matchers (loss_utils.py:181-187) on the streaming softmax statistics ---------------------------
+USE_FUSED_INFONCE = os.environ.get("UNOPOSE_FUSED_INFONCE", "1") == "1"  # A/B switch: 0 = two F.cross_entropy calls
+
+
+class _InfoNCEFn(torch.autograd.Function):
+    """atten (B,R,C) fp32, label1 (B,R-1), label2 (B,C-1) int64 -> (B,) loss
+    0.5 (mean_i CE(row i >= 1 over all columns, label1) + mean_j CE(column j >= 1 over all rows, label2)).
+    Forward: two statistics passes over the matrix (csrc/posehead.hip, the eval path's kernels) + gathers of the labelled
+    entries; backward: ONE pass writing the gradient.  torch's log_softmax over a non-last dimension of the 4097 x 4097 fine
+    similarity ran at 0.36 TB/s and was 19 % of the training step."""
+
+    @staticmethod
+    def forward(ctx, atten, label1, label2):
+        B, R, C = atten.shape
+        x = _c(atten.float())
+        ws = torch.empty(2 * B * (R + C), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            call("unopose_softmax_stats", ptr(x), B, R, C, ptr(ws), stream_ptr())
+        rmax, rinv = ws[:B * R].reshape(B, R), ws[B * R:2 * B * R].reshape(B, R)
+        cmax, cinv = ws[2 * B * R:2 * B * R + B * C].reshape(B, C), ws[2 * B * R + B * C:].reshape(B, C)
+        lse_r = rmax[:, 1:] - torch.log(rinv[:, 1:])
+        lse_c = cmax[:, 1:] - torch.log(cinv[:, 1:])
+        picked_r = torch.gather(x[:, 1:, :], 2, label1.unsqueeze(2)).squeeze(2)          # x[i, label1[i-1]], i >= 1
+        picked_c = torch.gather(x[:, :, 1:], 1, label2.unsqueeze(1)).squeeze(1)          # x[label2[j-1], j], j >= 1
+        ctx.save_for_backward(x, ws, label1, label2)
+        return 0.5 * ((lse_r - picked_r).mean(1) + (lse_c - picked_c).mean(1))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ws, label1, label2 = ctx.saved_tensors
+        B, R, C = x.shape
+        grad = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            call("unopose_infonce_grad", ptr(x), B, R, C, ptr(ws), ptr(_c(label1)), ptr(_c(label2)), ptr(_c(g.float())), ptr(grad), stream_ptr())
+        return grad, None, None
+
+
+def infonce_two_way(atten, label1, label2):
+    """The "atten" loss of compute_overlap_loss for one transformer block -> (B,)."""
+    if USE_FUSED_INFONCE and atten.is_cuda and atten.shape[1] <= 65535:
+        return _InfoNCEFn.apply(atten, label1, label2)
+    a = atten.float()
+    l1 = F.cross_entropy(a.transpose(1, 2)[:, :, 1:], label1, reduction="none").mean(1)  # classes = columns, per query row
+    l2 = F.cross_entropy(a[:, :, 1:], label2, reduction="none").mean(1)
+    return 0.5 * (l1 + l2)
+
+
 # ---- trainable linears (SURVEY.md 8(f-4)): forward and input gradient on the hand-written GEMMs, recorded by autograd ------
 TRAIN_OWN_GEMM = os.environ.get("UNOPOSE_TRAIN_OWN_GEMM", "1") == "1"  # A/B switch: 0 = nn.Linear through the library
+# The persistent 256 x 256-tile kernels pay off from a few tens of GFLOP per launch (measured at the training shapes: a
+# 32 776 x 256 x 256 linear takes 38 us on csrc/gemm_f32.hip and 17 us on the library, the 4096 x 3072 x 4096 up-projection
+# 0.31 vs 0.86 ms): below this many flops the training step keeps nn.Linear.
+TRAIN_OWN_GEMM_MIN_FLOP = float(os.environ.get("UNOPOSE_TRAIN_OWN_GEMM_MIN_FLOP", "2e10"))
 
 
 def _transposed_weights(lin, kind):
@@ -333,7 +384,8 @@ def linear_train(x, lin, relu=False):
     N, K = lin.weight.shape
     rows = x.numel() // K
     bf16 = torch.is_autocast_enabled()
-    ok = TRAIN_OWN_GEMM and x.is_cuda and rows > 0 and (own_gemm_ok(rows, N, K) if bf16 else (x.dtype == torch.float32 and f32x3_ok(rows, N, K)))
+    ok = TRAIN_OWN_GEMM and x.is_cuda and rows > 0 and 2.0 * rows * N * K >= TRAIN_OWN_GEMM_MIN_FLOP and \
+        (own_gemm_ok(rows, N, K) if bf16 else (x.dtype == torch.float32 and f32x3_ok(rows, N, K)))
     if not ok:
         y = lin(x)
         return F.relu(y) if relu else y
