@@ -48,7 +48,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time the CPU port once with EVERY hardware thread (adds ~10 min on a 256-thread host: 292 s per B=8 forward, "
-                         "0.027 pairs/s -- profiles/r03_bench_n1_bf16_s518.json holds that run)")
+                         "0.027 pairs/s -- profiles/r03_bench_n1_bf16_s518_first_with_all_cores.json holds that run)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the extra fp32 (reference default precision) leg")
     ap.add_argument("--train", action="store_true",
@@ -265,7 +265,7 @@ def cpu_baseline_leg(img, batches=(1, 8), timed=2, all_cores=False):
     batch size's median rate.  The reported value uses torch's intra-op pool at min(32, cores) threads: more threads
     only add contention at these op sizes -- with all 256 hardware threads of the GPU box's host the same B=8 forward takes
     292 s instead of 26 s (0.027 vs 0.30 pairs/s; `--cpu-all-cores` repeats that measurement, the committed run is
-    profiles/r03_bench_n1_bf16_s518.json)."""
+    profiles/r03_bench_n1_bf16_s518_first_with_all_cores.json)."""
     import torch
 
     from oracle import unopose_ref as R
