@@ -315,6 +315,8 @@ def train_main(args, world, rank, dev, sync):
     from unopose_amd.synthetic import make_train_batch, trained_like_
     from unopose_amd.train import build_optimizer, freeze_backbone, train_step, wrap_ddp
 
+    if os.environ.get("UNOPOSE_TRAIN_NO_MIOPEN") == "1":  # A/B: torch's native BatchNorm / convolution kernels instead of MIOpen's
+        torch.backends.cudnn.enabled = False
     B = args.batch if args.batch != 32 else 8  # --batch's default is the forward bench's; configs[3] is 8 pairs per rank
     img = args.img if args.img != 518 else 224  # the reference trains on 224 x 224 crops (configs/main_cfg.py:190)
     npts = args.train_pts
