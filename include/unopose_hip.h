@@ -365,6 +365,12 @@ int unopose_row_dot(const void *x, int x_bf16, const float *w, float b, long row
 int unopose_normalize_rows_bf16(const void *x, int x_bf16, long rows, int C, float temp, void *out, unopose_stream_t stream);
 /* vt (B, C, pad) bf16: vt[b,c,j] = v[b,j,c] (rows of v `ld` elements apart), zero for m <= j < pad: the value image of
  * unopose_token_attention. */
+/* out (B, prepend + J, row) = rows of feats (B, N, row) picked by idx (B, J; int32 or int64): row idx - off, or alt (B, row) where
+ * idx - off < 0; with prepend = 1 row 0 of every batch is alt as well.  Rows are row_bytes long (a multiple of 4, any element
+ * type).  The (B,N,C)-layout gather the model uses instead of gather_operation's transposes (model_utils.py:146-149) and the
+ * background-token sampling of the sparse-to-dense block (transformer.py:655-662: index 0 = the background token). */
+int unopose_gather_rows(const void *feats, int B, int N, int row_bytes, const void *idx, int idx_is_i64, int J, int off,
+                        const void *alt, int prepend, void *out, unopose_stream_t stream);
 int unopose_transpose_pad_bf16(const void *v, long ld, int B, int m, int C, int pad, void *vt, unopose_stream_t stream);
 
 /* nn.Linear on bf16 data with a fused epilogue (timm ViT blocks: qkv / proj / fc1 + GELU / fc2, and the

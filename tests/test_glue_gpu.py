@@ -133,3 +133,26 @@ def test_bmm_f32_strided_contractions():
     assert kvt.shape == (3, 4, 64, 64) and kvt.is_contiguous() and (kvt.double() - ref).abs().max().item() < 1e-4
     x, r = torch.randn(2, 33, 3, generator=g).cuda(), torch.randn(2, 3, 3, generator=g).cuda()
     assert (ops.bmm_nt_f32(x, r.transpose(1, 2)) - x @ r).abs().max().item() < 1e-5
+
+
+def test_gather_rows_kernel_matches_torch_composite():
+    """unopose_gather_rows (csrc/glue.hip): plain (B,N,C)-layout gather for fp32 points (12-byte rows), fp32 / bf16 features, int32 and
+    int64 indices, and the background-token form (index 0 -> the alternative row, optional prepended row) of transformer.py:655-662."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    for dtype, C in ((torch.float32, 3), (torch.float32, 256), (torch.bfloat16, 256), (torch.bfloat16, 6)):
+        feats = torch.randn(5, 301, C, generator=g).cuda().to(dtype)
+        for idt in (torch.int32, torch.int64):
+            idx = torch.randint(0, 301, (5, 77), generator=g).cuda().to(idt)
+            want = torch.gather(feats, 1, idx.long().unsqueeze(2).expand(-1, -1, C))
+            assert torch.equal(ops.gather_rows(feats, idx), want)
+            idx[:, ::5] = 0
+            bg = torch.randn(5, 1, C, generator=g).cuda()
+            base = torch.where((idx == 0).unsqueeze(-1), bg.to(dtype), torch.gather(feats, 1, (idx.long() - 1).clamp(min=0).unsqueeze(2).expand(-1, -1, C)))
+            assert torch.equal(ops.gather_rows(feats, idx, off=1, alt=bg), base)
+            assert torch.equal(ops.gather_rows(feats, idx, off=1, alt=bg, prepend=True), torch.cat([bg.to(dtype), base], 1))
+    # differentiable mode / tensors that carry gradients keep the autograd-recorded composite
+    f = torch.randn(2, 10, 4, device="cuda", requires_grad=True)
+    out = ops.gather_rows(f, torch.randint(0, 10, (2, 3), device="cuda"))
+    assert out.grad_fn is not None

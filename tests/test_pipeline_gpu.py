@@ -230,8 +230,8 @@ def test_stage_mode_at_bench_size_equals_one_at_a_time():
 
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_no_library_gemm_on_the_eval_path(model, precision):
-    """Regression guard for DESIGN.md section 7 (library bf16 GEMM kernels corrupt registers of kernels running beside them; the
-    fp32 library SGEMM runs at a third of csrc/gemm_f32.hip): during an eval forward NO torch matmul-class op may run on GPU data,
+    """Regression guard for DESIGN.md section 7 (the library's stream-K bf16 GEMMs hang when forwards overlap; its fp32 SGEMM runs
+    at a third of csrc/gemm_f32.hip): during an eval forward NO torch matmul-class op may run on GPU data,
     in either precision -- every contraction is a hand-written kernel (csrc/gemm.hip, gemm_f32.hip, bmm_f32.hip, the attention /
     embedding / PE kernels).  Self-checking: with the own GEMMs switched off the guard must fire."""
     import contextlib

@@ -435,9 +435,7 @@ class SparseToDenseTransformer(nn.Module):
         re-assembled per block (the reference's layout costs two 134 MB concatenations per block at B=32).
         Returns the new (dense, bg)."""
         # T:655-662 with App-E.2's off-by-one: index i addresses row i of [bg | dense], i.e. bg for i == 0
-        g = ops.gather_rows(dense, (idx_all - 1).clamp(min=0))
-        g = torch.where((idx_all == 0).unsqueeze(-1), bg.to(g.dtype), g)
-        f0, f1 = self.sparse_layer.forward_stacked(torch.cat([bg.to(g.dtype), g], 1), e_all)
+        f0, f1 = self.sparse_layer.forward_stacked(ops.gather_rows(dense, idx_all, off=1, alt=bg, prepend=True), e_all)
         new = self.dense_layer(dense, torch.cat([f0[:, 1:], f1[:, 1:]], 0))
         return new, torch.cat([f0[:, 0:1], f1[:, 0:1]], 0)
 

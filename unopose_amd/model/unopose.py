@@ -18,8 +18,8 @@ from .modules import (GeometricStructureEmbedding, GeometricTransformer, Positio
 
 
 STACKED_FINE = os.environ.get("UNOPOSE_STACKED_FINE", "1") == "1"  # A/B switch for the 2B-stacked fine matcher
-# Reference-cloud PE on a side stream under the coarse stage: OFF by default since round 3 -- the PE / frame kernels are not
-# reproducible when waves of the token attention kernel share their CU; "1" restores the round-2 overlap (+1.5 %).
+# Reference-cloud PE on a side stream under the coarse stage.  (Switched off for part of round 3 while the PE / frame kernels were not
+# reproducible beside the token attention of another stream; the cause -- packed-fp32 instructions, DESIGN.md section 7 -- is gone.)
 PE_UNDER_COARSE = os.environ.get("UNOPOSE_PE_UNDER_COARSE", "1") == "1"
 GEOM_UNDER_VIT = int(os.environ.get("UNOPOSE_GEOM_UNDER_VIT", "1"))  # 1: FPS-196 / gathers, 2: + frames + embedding
 LRF_UNDER_VIT = os.environ.get("UNOPOSE_LRF_UNDER_VIT", "1") == "1"  # the two global frames on the side stream as well

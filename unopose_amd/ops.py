@@ -162,11 +162,10 @@ def linear_bf16_hip(x2, w, bias_f32, gelu=False, relu=False):
 
 def own_gemm_ok(rows, N, K):
     """Does csrc/gemm.hip take this bf16 linear?  With HIP_GEMM_ALL: every shape its tiling admits (N % 256 == 0,
-    K % 64 == 0, any row count) -- NO hipBLASLt bf16 kernel is left on the autocast path.  That matters beyond speed:
-    hipBLASLt's bf16 GEMM kernels of this ROCm release corrupt vector registers of wavefronts of OTHER kernels that
-    share a SIMD with them (scripts/ubench/lrf_dbg.py: a one-wavefront frame kernel beside a library bf16 GEMM on
-    another stream returns wrong sums in lanes 48-63 in 3-40 % of launches, never beside the hand-written kernels or an
-    fp32 library GEMM), so nothing may run concurrently with one."""
+    K % 64 == 0, any row count) -- NO hipBLASLt bf16 kernel is left on the autocast path.  That matters beyond speed: the
+    library's stream-K kernels spin on partner workgroups and hang when forwards overlap.  (Round 2 also
+    blamed them for wrong sums in other kernels; round 3 traced those to packed-fp32 instructions in the VICTIM kernels beside any
+    MFMA kernel -- the library is built without them now, see build.py.)"""
     if not USE_HIP_GEMM or N % 256 != 0 or K % 64 != 0 or rows < 1:
         return False
     return HIP_GEMM_ALL or rows >= HIP_GEMM_MIN_ROWS
@@ -639,11 +638,30 @@ def score_head(x, lin):
         return ((x.float() * cache[1]).sum(-1, keepdim=True) + cache[2]).to(torch.bfloat16)
 
 
-def gather_rows(feats, idx):
-    """out[b,j,:] = feats[b, idx[b,j], :]  (the (B,N,C)-layout twin of gather_operation; avoids the two
-    transpose copies around every reference call, model_utils.py:146-149, transformer.py:658)."""
+def gather_rows(feats, idx, off=0, alt=None, prepend=False):
+    """out[b,j,:] = feats[b, idx[b,j] - off, :]  (the (B,N,C)-layout twin of gather_operation; avoids the two transpose copies
+    around every reference call, model_utils.py:146-149, transformer.py:658).  `alt` (B,1,C) / (B,C): the row taken where
+    idx - off < 0, and -- with `prepend` -- an extra row 0 of the output: the background-token sampling of the sparse-to-dense
+    block in one launch (csrc/glue.hip; index cast + clamp + gather + compare + where + cat otherwise)."""
     B, N, C = feats.shape
-    return torch.gather(feats, 1, idx.long().unsqueeze(2).expand(-1, -1, C))
+    J = idx.shape[1]
+    if (feats.is_cuda and not _DIFF and not feats.requires_grad and feats.is_contiguous() and idx.is_contiguous() and idx.dtype in (torch.int32, torch.int64)
+            and (C * feats.element_size()) % 4 == 0 and B <= 65535):
+        if alt is not None:
+            alt = _c(alt.reshape(B, C).to(feats.dtype))
+        out = torch.empty(B, J + int(prepend), C, dtype=feats.dtype, device=feats.device)
+        with torch.cuda.device(feats.device):
+            call("unopose_gather_rows", ptr(feats), B, N, C * feats.element_size(), ptr(idx), int(idx.dtype == torch.int64), J, int(off),
+                 None if alt is None else ptr(alt), int(prepend), ptr(out), stream_ptr())
+        return out
+    i = idx.long() - off
+    g = torch.gather(feats, 1, i.clamp(min=0).unsqueeze(2).expand(-1, -1, C))
+    if alt is not None:
+        a = alt.reshape(B, 1, C).to(g.dtype)
+        g = torch.where((i < 0).unsqueeze(-1), a, g)
+        if prepend:
+            g = torch.cat([a, g], 1)
+    return g
 
 
 def vit_attention(qkv, heads):
@@ -1203,16 +1221,17 @@ def feature_similarity(f1, f2, temp):
     bf16 write, a division pass and the fp32 cast the pose heads ask for (1.6 GB per step at B=32)."""
     if _DIFF:  # the reference's expression, dtype and all (model_utils.py:260-282)
         return F.normalize(f1, p=2, dim=2) @ F.normalize(f2, p=2, dim=2).transpose(1, 2) / temp
+    if f1.is_cuda and torch.is_autocast_enabled() and HIP_GEMM_ALL and _own_f32(f1):
+        # no library bf16 GEMM on the path (own_gemm_ok): the bf16-rounded normalised operands, multiplied by the exact-fp32 MFMA
+        # kernel (exact products, fp32 sums -- what the bf16 bmm with fp32 output computes up to summation order)
+        with torch.autocast("cuda", enabled=False):
+            return bmm_nt_f32(normalize_rows_bf16(f1, temp).float(), normalize_rows_bf16(f2, 1.0).float())
     a, b = F.normalize(f1.float(), p=2, dim=2), F.normalize(f2.float(), p=2, dim=2)
     if f1.is_cuda and torch.is_autocast_enabled() and not HIP_GEMM_ALL:
         with torch.autocast("cuda", enabled=False):
             return torch.bmm((a / temp).to(torch.bfloat16), b.to(torch.bfloat16).transpose(1, 2), out_dtype=torch.float32)
     if f1.is_cuda and torch.is_autocast_enabled():
-        # no library bf16 GEMM on the path (own_gemm_ok): the same bf16-rounded operands, multiplied by the exact-fp32 MFMA
-        # kernel (exact products, fp32 sums -- what the bf16 bmm with fp32 output computes up to summation order)
         with torch.autocast("cuda", enabled=False):
-            if _own_f32(f1):
-                return bmm_nt_f32(normalize_rows_bf16(f1, temp).float(), normalize_rows_bf16(f2, 1.0).float())
             return torch.bmm((a / temp).to(torch.bfloat16).float(), b.to(torch.bfloat16).float().transpose(1, 2))
     if _own_f32(f1) and a.dtype == torch.float32:
         return bmm_nt_f32(_c(a), _c(b)) / temp

@@ -6,14 +6,13 @@ of the chip idles between launches).  Consecutive batches are independent, so a 
 kernels of batch i fill the gaps -- and run beside -- the large kernels of batch i+1: +8 % pairs/s at 518x518, +14 % at
 224x224 (bench.py, same box A/B), with every result bit-identical to the one-stream order (same kernels, same inputs).
 
-What makes this safe is that NO hipBLASLt bf16 GEMM kernel is left on the bf16 path (`ops.own_gemm_ok`: every linear
-runs on csrc/gemm.hip, the few odd contractions in fp32 or as element-wise arithmetic).  Two reasons, both measured:
-(1) the library's stream-K kernels spin on partner workgroups -- three forwards in flight hang with them, none do without;
-(2) the library's bf16 kernels corrupt vector registers of wavefronts of OTHER kernels sharing a SIMD with them
-(scripts/ubench/lrf_dbg.py: lanes 48-63 of an unrelated one-wavefront kernel return wrong sums in 3-40 % of launches beside a
-library bf16 GEMM on another stream; never beside the hand-written kernels or fp32 library GEMMs), so nothing may run
-concurrently with one.  With them gone, pipelined and one-at-a-time execution give bit-identical poses
-(tests/test_pipeline_gpu.py).  The fp32 path (library GEMMs throughout) is run one batch at a time.
+What makes this safe: (1) NO library GEMM is left on the eval path (`ops.own_gemm_ok`, csrc/gemm.hip, gemm_f32.hip, bmm_f32.hip):
+hipBLASLt's stream-K kernels spin on partner workgroups -- three forwards in flight hang with them, none do without;
+(2) no kernel of libunopose_hip.so contains packed-fp32 instructions (build.py: -fno-slp-vectorize -fno-vectorize): kernels that do
+return wrong values for a few elements when waves of another kernel issuing MFMAs share their CU (DESIGN.md section 7, round 3 --
+round 2 had attributed this to the library's bf16 GEMMs).  With both in place pipelined and one-at-a-time execution give
+bit-identical poses, also at the bench size in stage mode (tests/test_pipeline_gpu.py, tests/test_coresidency_gpu.py).
+The fp32 path is run one batch at a time.
 
 The reference has no counterpart (its runner, engine/oneref_inference_utils_v1.py:13-136, calls the model batch by
 batch on the default stream); `runner.inference_and_save` uses this class for consecutive detection batches.
