@@ -654,6 +654,8 @@ def gather_rows(feats, idx, off=0, alt=None, prepend=False):
             call("unopose_gather_rows", ptr(feats), B, N, C * feats.element_size(), ptr(idx), int(idx.dtype == torch.int64), J, int(off),
                  None if alt is None else ptr(alt), int(prepend), ptr(out), stream_ptr())
         return out
+    if off == 0 and alt is None:
+        return torch.gather(feats, 1, idx.long().unsqueeze(2).expand(-1, -1, C))
     i = idx.long() - off
     g = torch.gather(feats, 1, i.clamp(min=0).unsqueeze(2).expand(-1, -1, C))
     if alt is not None:
