@@ -14,17 +14,88 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 KERNEL = "_ZN7unopose22query_lrf_group_kernelEPKfifiiPf"
 LLVM = "/opt/rocm/lib/llvm/bin"
-VARIANTS = ["orig", "after1", "after7", "before7", "both7", "all_valu7"]
+VARIANTS = ["orig", "after1", "after7", "before7", "both7", "all_valu7", "split_all", "split_mul", "split_add", "split_plain", "split_modified",
+            "keep_mul_opselhi", "keep_mul_opsel", "keep_mul_neg", "keep_mul_plain", "keep_add"] + [f"keep_one_{k}" for k in range(9)]
+# keep_one_k: ONLY the k-th v_pk_mul_f32 with op_sel (in program order) stays packed
+# keep_X: every packed instruction is split EXCEPT class X, which stays packed -- failing means class X alone is enough:
+#   mul_opselhi: v_pk_mul_f32 with op_sel_hi only;  mul_opsel: with op_sel (any);  mul_neg: with neg_lo / neg_hi and no op_sel*;
+#   mul_plain: v_pk_mul_f32 without modifiers;  add: every v_pk_add_f32
+# split_*: packed instructions REPLACED by their two scalar halves (same registers, same arithmetic: v_pk_mul_f32 v[a:b], X, Y ->
+# v_mul_f32 v_a, X.lo, Y.lo ; v_mul_f32 v_b, X.hi, Y.hi with op_sel / op_sel_hi / neg_lo / neg_hi honoured): all of them, only the
+# multiplies, only the adds, only the plain VGPR-pair forms, only the forms with operand-select / negate modifiers or SGPR sources.
+
+
+def _elem(op, k):
+    m = re.fullmatch(r"([vs])\[(\d+):(\d+)\]", op)
+    if m:
+        return f"{m.group(1)}{int(m.group(2)) + k}"
+    return op  # inline constant / literal: the same value in both halves
+
+
+def split_packed(ln):
+    """One v_pk_{mul,add}_f32 line -> two scalar VOP3 lines, or None when a half would read a register the other half has
+    already overwritten (none in this kernel)."""
+    m = re.match(r"\s*v_pk_(mul|add)_f32\s+(v\[\d+:\d+\]),\s*([^,]+),\s*([^\s]+)(.*)", ln)
+    op, dst, s0, s1, mods = m.group(1), m.group(2), m.group(3).strip(), m.group(4).strip(), m.group(5)
+
+    def mod(name, default):
+        mm = re.search(name + r":\[(\d),(\d)\]", mods)
+        return [int(mm.group(1)), int(mm.group(2))] if mm else default
+    op_sel, op_sel_hi, neg_lo, neg_hi = mod("op_sel", [0, 0]), mod("op_sel_hi", [1, 1]), mod("neg_lo", [0, 0]), mod("neg_hi", [0, 0])
+    d = [_elem(dst, 0), _elem(dst, 1)]
+    lo = [("-" if neg_lo[0] else "") + _elem(s0, op_sel[0]), ("-" if neg_lo[1] else "") + _elem(s1, op_sel[1])]
+    hi = [("-" if neg_hi[0] else "") + _elem(s0, op_sel_hi[0]), ("-" if neg_hi[1] else "") + _elem(s1, op_sel_hi[1])]
+    lo_line = f"\tv_{op}_f32_e64 {d[0]}, {lo[0]}, {lo[1]}\n"
+    hi_line = f"\tv_{op}_f32_e64 {d[1]}, {hi[0]}, {hi[1]}\n"
+    reads = lambda ops_, r: any(o.lstrip("-") == r for o in ops_)  # noqa: E731
+    if not reads(hi, d[0]):
+        return [lo_line, hi_line]
+    if not reads(lo, d[1]):
+        return [hi_line, lo_line]
+    strip = lambda ops_: [o.lstrip("-") for o in ops_]  # noqa: E731
+    if sorted(strip(lo)) == sorted(strip(hi)) and lo[0][:1] != "-" and lo[1][:1] != "-" and hi[0][:1] != "-" and hi[1][:1] != "-":
+        return [lo_line, f"\tv_mov_b32_e32 {d[1]}, {d[0]}\n"]  # both halves are the same commutative expression
+    if not reads(lo, d[0]) and not reads(hi, d[1]):
+        # crossed halves: each result is computed in the OTHER destination register first, then the two are swapped
+        return [f"\tv_{op}_f32_e64 {d[0]}, {hi[0]}, {hi[1]}\n", f"\tv_{op}_f32_e64 {d[1]}, {lo[0]}, {lo[1]}\n", f"\tv_swap_b32 {d[0]}, {d[1]}\n"]
+    return None
+
+
+def wants_split(ins_line, name):
+    is_mul = "v_pk_mul" in ins_line
+    modified = bool(re.search(r"op_sel|neg_|\bs\[", ins_line))
+    if name.startswith("keep_"):
+        has_sel, has_selhi, has_neg = "op_sel:" in ins_line, "op_sel_hi:" in ins_line, "neg_" in ins_line
+        cls = "add" if not is_mul else ("mul_opsel" if has_sel else ("mul_opselhi" if has_selhi else ("mul_neg" if has_neg else "mul_plain")))
+        return cls != name[5:]
+    return {"split_all": True, "split_mul": is_mul, "split_add": not is_mul, "split_plain": not modified, "split_modified": modified}.get(name, False)
 
 
 def transform(lines, name):
     out, inside = [], False
+    nth = [-1]
     for ln in lines:
         if ln.startswith(KERNEL + ":"):
             inside = True
         ins = ln.strip().split()[0] if ln.strip() else ""
         pk = inside and re.match(r"v_pk_(mul|add|fma)_f32", ins)
         valu = inside and ins.startswith("v_") and not ins.startswith("v_mfma")
+        if pk and name.startswith("keep_one_"):
+            if "v_pk_mul" in ln and "op_sel:" in ln:
+                nth[0] += 1
+                if nth[0] == int(name[9:]):
+                    print("   kept packed:", ln.strip(), flush=True)
+                    out.append(ln)
+                    continue
+            two = split_packed(ln)
+            if two is not None:
+                out += two
+                continue
+        if pk and name.startswith(("split", "keep_")) and wants_split(ln, name):
+            two = split_packed(ln)
+            if two is not None:
+                out += two
+                continue
         if pk and name in ("before7", "both7"):
             out.append("\ts_nop 7\n")
         out.append(ln)
@@ -72,7 +143,10 @@ def neighbour():
 
 
 base = None
+ONLY = os.environ.get("ASM_VAR_ONLY")
 for name in VARIANTS:
+    if ONLY and name not in ONLY.split(","):
+        continue
     mod, fn = ctypes.c_void_p(), ctypes.c_void_p()
     assert hip.hipModuleLoad(ctypes.byref(mod), os.path.join(HERE, f"_asmvar_{name}.hsaco").encode()) == 0
     assert hip.hipModuleGetFunction(ctypes.byref(fn), mod, KERNEL.encode()) == 0

@@ -110,6 +110,26 @@ __global__ __launch_bounds__(256) void hv_pkf32(float *out, int iters) {
   }
   out[blockIdx.x * 256 + threadIdx.x] = s + acc.x;
 }
+// 9 pkmul_opsel: the minimal reproducer asm_var.py arrived at -- v_pk_mul_f32 with an op_sel modifier (the lo half reads the HI
+// element of a source pair).  out[..] = number of iterations in which the packed result differs from the same two products
+// computed with v_mul_f32 (self-checking: no reference run needed; must be 0).
+__global__ __launch_bounds__(256) void hv_pkmul_opsel(float *out, int iters) {
+  const int lane = threadIdx.x & 63;
+  int bad = 0;
+  float carry = 0.f;
+  for (int i = 0; i < iters; ++i) {
+    f32x2 a = {seedf(i, lane, blockIdx.x) + carry, seedf(i + 1, lane, blockIdx.x)};
+    f32x2 b = {seedf(i + 2, lane, blockIdx.x), seedf(i + 3, lane, blockIdx.x) - carry};
+    f32x2 p;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(b));  // p.lo = a.lo * b.hi, p.hi = a.hi * b.lo
+    float w0, w1;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(w0) : "v"(a.x), "v"(b.y));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(w1) : "v"(a.y), "v"(b.x));
+    bad += (__float_as_uint(p.x) != __float_as_uint(w0)) || (__float_as_uint(p.y) != __float_as_uint(w1));
+    carry = w0 * 0.125f;
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = (float)bad;
+}
 extern "C" int hazard_victim_launch(int which, void *out, int blocks, int iters, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   float *o = (float *)out;
@@ -121,6 +141,7 @@ extern "C" int hazard_victim_launch(int which, void *out, int blocks, int iters,
     case 4: hipLaunchKernelGGL(hv_ldslist, dim3(blocks), dim3(256), 0, s, o, iters); break;
     case 5: hipLaunchKernelGGL(hv_eig, dim3(blocks), dim3(256), 0, s, o, iters); break;
     case 6: hipLaunchKernelGGL(hv_readlane, dim3(blocks), dim3(256), 0, s, o, iters); break;
+    case 9: hipLaunchKernelGGL(hv_pkmul_opsel, dim3(blocks), dim3(256), 0, s, o, iters); break;
     case 8: hipLaunchKernelGGL(hv_pkf32, dim3(blocks), dim3(256), 0, s, o, iters); break;
     default: hipLaunchKernelGGL(hv_cmpmask, dim3(blocks), dim3(256), 0, s, o, iters); break;
   }

@@ -17,7 +17,8 @@ ARCH = "gfx950"
 # -ffp-contract=off: fp32 distance expressions must round exactly as written so
 # FPS / ball_query indices are bit-identical to oracle/ (DESIGN.md "fp-contract").
 # -fno-slp-vectorize -fno-vectorize: NO packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  hipcc -O2 / -O3 forms them
-# out of scalar fp32 code (97 in query_lrf_group alone); kernels that contain them return wrong values for a few elements per
+# out of scalar fp32 code (97 in query_lrf_group alone); kernels that contain them (precisely: v_pk_mul_f32 with an op_sel modifier,
+# isolated by re-assembling the ISA, scripts/ubench/asm_var.py) return wrong values for a few elements per
 # launch whenever waves of ANOTHER kernel issuing MFMAs share their CU -- 23 of 30 launches beside a neighbour that does nothing but
 # v_mfma, 0 of 30 when built with this flag or at -O1, and never beside VALU / LDS / memory / barrier neighbours
 # (scripts/ubench/coresidency_matrix.py, geom_var.py; the loop vectoriser forms a few more, hence both flags).
