@@ -212,6 +212,12 @@ int unopose_fine_correspondences(const float *atten, int B, int R, int C, const 
 int unopose_upproj_plan(const long long *choose, int B2, int Np, int H, int W, int side, int tok_offset, int tok_stride,
                         int cap_rows, int *ws, int *row_list, int *cellmap, int *tile_info, unopose_stream_t stream);
 
+/* linear_bf16 with explicit row strides (in elements, multiples of 8): A rows lda apart, W rows ldw apart, C rows ldc apart -- an
+ * nn.Linear (oneref_feature_extraction.py:24-42, transformer.py:151-193) over a column slice of a wider activation, or into one,
+ * without a copy. */
+int unopose_linear_bf16_ld(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, long M, int N, int K,
+                           int epilogue, unopose_stream_t stream);
+
 /* C = LayerNorm(A W^T + bias + resid) * ln_w + ln_b for 256-wide layers (N = 256 = one tile: a row's statistics stay inside the
  * workgroup): the output projection / FFN squeeze of the matcher's transformer layers with the residual add and the post-LN
  * (core/unopose/model/transformer.py:151-193) in the GEMM epilogue, on the fp32 accumulators.  A (M,K), W (256,K), resid and C

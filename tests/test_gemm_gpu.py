@@ -151,3 +151,24 @@ def test_fp32_linears_take_the_f32x3_path_and_match_torch():
     z = ops.linear(h, lin, relu=True)
     mag = h.abs().double() @ lin.weight.abs().double().t() + lin.bias.abs().double()
     assert ((z.double() - F.relu(h.double() @ lin.weight.double().t() + lin.bias.double())).abs() <= mag * 3 * 2.0 ** -17).all()
+
+
+def test_strided_linear_matches_the_dense_path():
+    """unopose_linear_bf16_ld (row strides for A, W and C): bit-identical to the dense kernel call (same tiles, same K order -- only
+    the addresses change); pad columns of A / W are never read, those of C never written."""
+    from unopose_amd import ops
+    from unopose_amd._lib import call, ptr, stream_ptr
+
+    torch.manual_seed(0)
+    M, K, N = 1500, 1024, 512
+    a = torch.randn(M, K, device="cuda").bfloat16()
+    w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda")
+    want = ops.linear_bf16_hip(a, w, b, gelu=True)
+    ap = torch.full((M, K + 64), 7.0, device="cuda").bfloat16()
+    ap[:, :K] = a
+    wp = torch.full((N, K + 128), -3.0, device="cuda").bfloat16()
+    wp[:, :K] = w
+    cp = torch.zeros(M, N + 8, device="cuda", dtype=torch.bfloat16)
+    call("unopose_linear_bf16_ld", ptr(ap), K + 64, ptr(wp), K + 128, ptr(b), ptr(cp), N + 8, M, N, K, 1, stream_ptr())
+    assert torch.equal(cp[:, :N], want) and float(cp[:, N:].abs().max()) == 0.0  # pad columns of A / W never read, of C never written

@@ -54,6 +54,12 @@ constexpr bool kMfma = GEMM_ABL != 2 && GEMM_ABL < 5, kFrag = GEMM_ABL != 3 && G
 // tile_info[0] = number of tiles, read on the device: the host never learns it); C is (tiles * 256, 256).
 // EPI 3 (N == 256 only: a row is one tile wide): C = LayerNorm(A W^T + bias + resid) * ln_w + ln_b, the post-LN glue of the
 // matcher's transformer layers (transformer.py:151-193) -- the residual add and the LayerNorm run on the fp32 accumulators.
+#ifndef GEMM_ROTX
+#define GEMM_ROTX 5  // K-tile rotation between XCDs (-1: spread evenly, xcd * nk / 8) and between steps
+#endif
+#ifndef GEMM_ROTS
+#define GEMM_ROTS 3
+#endif
 template <int EPI, bool GATHER = false>  // EPI 0: bias; 1: bias + GELU; 2: bias + ReLU; 3: bias + residual + LayerNorm
 __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict__ A, const u16 *__restrict__ W,
                                                            const float *__restrict__ bias, u16 *__restrict__ C, int M,
@@ -61,7 +67,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
                                                            const int *__restrict__ row_list = nullptr,
                                                            const int *__restrict__ tile_info = nullptr,
                                                            const u16 *__restrict__ resid = nullptr, const float *__restrict__ ln_w = nullptr,
-                                                           const float *__restrict__ ln_b = nullptr, float ln_eps = 0.f) {
+                                                           const float *__restrict__ ln_b = nullptr, float ln_eps = 0.f, int lda = 0,
+                                                           int ldw = 0, int ldc = 0) {
+  // row strides in elements (0 = dense; unopose_linear_bf16_ld).  (Padding the 6144-byte rows of the ViT's hidden activation by 64
+  // elements was tried against L2 channel camping: no gain on the fc1 -> fc2 pair)
+  const int LDA = lda ? lda : K, LDW = ldw ? ldw : K, LDC = ldc ? ldc : N;
   const int tiles = GATHER ? __builtin_amdgcn_readfirstlane(tile_info[0]) : tiles_arg;
   __shared__ __attribute__((aligned(1024))) char smem[2 * GEMM_BUFBYTES];
   __shared__ __attribute__((aligned(16))) float bias_lds[GEMM_BN];  // this tile's bias slice (LDS reads: no vmcnt traffic in the epilogue)
@@ -86,8 +96,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   const int cq = tiles >> 3, cr = tiles & 7;
   const int chunk_base = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, chunk_len = cq + (xcd < cr ? 1 : 0);
   const int tiles_m = tiles / tiles_n, per_group = GEMM_GM * tiles_n;
-  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, (int)((size_t)M * K * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, (int)((size_t)N * K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, (int)((size_t)M * LDA * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, (int)((size_t)N * LDW * 2), 0x00020000);
   const int nk = K / GEMM_BK;
 
   // ---- fragment read addresses: tile row r = base + l31 (base a multiple of 32), chunk c = 2 ks + hi:
@@ -130,15 +140,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
       const int c = (lane & 7) ^ ((row >> 1) & 7);
       int arow = (GEMM_SAME ? 0 : p.m0) + row;
       if (GATHER) arow = max(row_list[p.m0 + row], 0);  // padding rows of a group (-1) compute on row 0; nobody reads them
-      p.a_off[i] = (uint32_t)(((size_t)arow * K + c * 8) * 2);
-      p.w_off[i] = (uint32_t)(((size_t)((GEMM_SAME ? 0 : p.n0) + row) * K + c * 8) * 2);
+      p.a_off[i] = (uint32_t)(((size_t)arow * LDA + c * 8) * 2);
+      p.w_off[i] = (uint32_t)(((size_t)((GEMM_SAME ? 0 : p.n0) + row) * LDW + c * 8) * 2);
     }
     // K-tile rotation, uniform over the tiles an XCD runs together (they must stay on the same K-slice to share it) and
     // different between XCDs / steps: the chip as a whole touches different 128-byte columns at any instant.
     // GEMM_SKEW: tiles sharing a panel start 0..SKEW-1 K-tiles apart, so a K-slice one of them has fetched is RESIDENT in L2
     // when the others ask for it
     const int skew = ((tm & 3) + tn) % (GEMM_SKEW > 1 ? GEMM_SKEW : 1);
-    p.rot = __builtin_amdgcn_readfirstlane((xcd * 5 + step * 3 + skew) % nk);
+    p.rot = __builtin_amdgcn_readfirstlane(((GEMM_ROTX < 0 ? xcd * nk / 8 : xcd * GEMM_ROTX) + step * GEMM_ROTS + skew) % nk);
   };
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
   auto stage_tile = [&](const TileP &p, int buf, int kt) {  // the wave's 4 A + 4 W pieces of K-tile kt
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
         const int row = it * 8 + (lane >> 3), q = lane & 7;
         const uint4 v = *reinterpret_cast<const uint4 *>(cw + row * 128 + ((q ^ (row & 7)) << 4));
         const int m = m0 + wm * 128 + ps * 64 + row;
-        const size_t off = GATHER ? ((size_t)m * GEMM_BN + wn * 64 + q * 8) * 2 : ((size_t)m * N + n0 + wn * 64 + q * 8) * 2;
+        const size_t off = GATHER ? ((size_t)m * GEMM_BN + wn * 64 + q * 8) * 2 : ((size_t)m * LDC + n0 + wn * 64 + q * 8) * 2;
         if (GEMM_EABL == 1) {
           asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
         } else if (GATHER || m < M) {
@@ -407,6 +417,34 @@ int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C
     hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
                        K, tiles_n, tiles, nt);
   return check_launch("linear_bf16");
+}
+
+int unopose_linear_bf16_ld(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, long M, int N, int K,
+                           int epilogue, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(A && W && bias && C, "linear_bf16_ld: null pointer");
+  UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && K >= GEMM_BK && K % GEMM_BK == 0,
+                  "linear_bf16_ld: needs N %% 256 == 0 and K %% 64 == 0 (got M=%ld N=%d K=%d)", M, N, K);
+  UNOPOSE_REQUIRE(lda >= K && ldw >= K && ldc >= N && lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0,
+                  "linear_bf16_ld: row strides must cover the rows and be multiples of 8 elements (lda=%d ldw=%d ldc=%d)", lda, ldw, ldc);
+  UNOPOSE_REQUIRE((size_t)M * lda * 2 < (1UL << 32) && (size_t)N * ldw * 2 < (1UL << 32), "linear_bf16_ld: operand larger than 4 GiB");
+  UNOPOSE_REQUIRE(epilogue >= 0 && epilogue <= 2, "linear_bf16_ld: epilogue must be 0 (bias), 1 (bias + GELU) or 2 (bias + ReLU)");
+  const int tiles_m = cdiv(M, GEMM_BM), tiles_n = N / GEMM_BN, tiles = tiles_m * tiles_n;
+  hipStream_t s = (hipStream_t)stream;
+  const int n_cu = gemm_cu_count();
+  const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
+  const int nt = use_nt_store(M, N);
+#define UNOPOSE_LD_LAUNCH(E)                                                                                                                \
+  hipLaunchKernelGGL(gemm_bf16_kernel<E>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N, K, tiles_n, \
+                     tiles, nt, (const int *)nullptr, (const int *)nullptr, (const u16 *)nullptr, (const float *)nullptr,                     \
+                     (const float *)nullptr, 0.f, lda, ldw, ldc)
+  if (epilogue == 1)
+    UNOPOSE_LD_LAUNCH(1);
+  else if (epilogue == 2)
+    UNOPOSE_LD_LAUNCH(2);
+  else
+    UNOPOSE_LD_LAUNCH(0);
+#undef UNOPOSE_LD_LAUNCH
+  return check_launch("linear_bf16_ld");
 }
 
 int unopose_linear_add_layernorm_bf16(const void *A, const void *W, const float *bias, const void *resid, const float *ln_w,
