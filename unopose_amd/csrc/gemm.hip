@@ -54,6 +54,9 @@ constexpr bool kMfma = GEMM_ABL != 2 && GEMM_ABL < 5, kFrag = GEMM_ABL != 3 && G
 // tile_info[0] = number of tiles, read on the device: the host never learns it); C is (tiles * 256, 256).
 // EPI 3 (N == 256 only: a row is one tile wide): C = LayerNorm(A W^T + bias + resid) * ln_w + ln_b, the post-LN glue of the
 // matcher's transformer layers (transformer.py:151-193) -- the residual add and the LayerNorm run on the fp32 accumulators.
+#ifndef GEMM_PP
+#define GEMM_PP 0  // 1 / 2: ping-pong K loop (see the kernel); 2 = all 8 DMA pieces in phase 0
+#endif
 #ifndef GEMM_ROTX
 #define GEMM_ROTX 5  // K-tile rotation between XCDs (-1: spread evenly, xcd * nk / 8) and between steps
 #endif
@@ -206,6 +209,57 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
     if (wave == 0) *reinterpret_cast<float4 *>(bias_lds + lane * 4) = cur_bv;  // read after the K loop's barriers
     __syncthreads();
     bf16x8 wf0[2], af0[4], wf1[2], af1[4];
+#if GEMM_PP
+    // ---- ping-pong K loop (GEMM_PP): the two wave groups of the workgroup (wm = 0: waves 0-3, wm = 1: waves 4-7 -- one wave of each
+    // per SIMD) run ONE BARRIER apart, so that while one group issues the 8 MFMAs of a k-substep (256 matrix-pipe cycles, s_setprio 1)
+    // the other issues its LDS fragment reads and its LDS-DMA pieces, and vice versa: a K-tile is 4 phases of
+    //     [6 ds_read_b128 (+ DMA pieces of K-tile kt + 1 in phases 0 / 1)]  barrier  [lgkmcnt(0), 8 MFMAs]  barrier
+    // Ordering rules (a reader may be one barrier ahead of an issuer): the wave's own DMA of K-tile kt + 1 is waited for (vmcnt 0)
+    // BEFORE the first barrier of phase 3 -- every wave of the other group has then passed that barrier before anybody reads the
+    // buffer in phase 0 of K-tile kt + 1; the fragment reads of phase 3 are retired (lgkmcnt 0) before that same barrier, so the
+    // DMA of K-tile kt + 2 -- issued after the NEXT barrier at the earliest -- cannot overtake a read of the buffer it overwrites.
+    auto phase_mfma = [&](const bf16x8(&wf)[2], const bf16x8(&af)[4], bool wait_reads) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      if (wait_reads) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+      mfma8(wf, af);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stage_part = [&](const TileP &p, int buf, int kt, int i0, int i1) {  // pieces i0 .. i1-1 (A and W) of the wave's 4 + 4
+      kt += p.rot;
+      if (kt >= nk) kt -= nk;
+      const uint32_t la = lds0 + (uint32_t)(buf * GEMM_BUFBYTES + wave * 4096);
+      for (int i = i0; i < i1; ++i) {
+        gemm_dma16(la + i * 1024, p.a_off[i], a_rs, kt * (GEMM_BK * 2));
+        gemm_dma16(la + i * 1024 + GEMM_OPBYTES, p.w_off[i], w_rs, kt * (GEMM_BK * 2));
+      }
+    };
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      const char *lb = smem + buf * GEMM_BUFBYTES;
+      const bool more_k = kt + 1 < nk && kDma;
+      read_frags(lb, 0, wf0, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more_k) stage_part(cur, buf ^ 1, kt + 1, 0, GEMM_PP == 2 ? 4 : 2);
+      phase_mfma(wf0, af0, true);
+      read_frags(lb, 1, wf1, af1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more_k && GEMM_PP != 2) stage_part(cur, buf ^ 1, kt + 1, 2, 4);
+      phase_mfma(wf1, af1, true);
+      read_frags(lb, 2, wf0, af0);
+      phase_mfma(wf0, af0, true);
+      read_frags(lb, 3, wf1, af1);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      phase_mfma(wf1, af1, false);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();  // both groups have executed the same number of barriers again
+#else
     read_frags(smem, 0, wf0, af0);
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
@@ -249,6 +303,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
       if (kt + 1 < nk) read_frags(smem + (buf ^ 1) * GEMM_BUFBYTES, 0, wf0, af0);
     }
 
+#endif
     // ---- next tile's first K-tile in flight under this tile's epilogue; then the pending MFMA group of the last K-tile
     const bool more = EPI != 3 && can_prefetch && ti + nslots < chunk_len;  // (EPI 3: the LayerNorm epilogue needs the registers)
     TileP nxt;
@@ -259,7 +314,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
       stage_tile(nxt, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+#if !GEMM_PP
     mfma8(wf1, af1);
+#endif
     if (EPI == 3) {
       // v = acc + bias + residual; row statistics across the 4 column waves through LDS; normalise in place
 #pragma unroll
