@@ -98,13 +98,14 @@ def log(msg):
     print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
-def hip_event_time(fn, iters, stream):
+def hip_event_time(fn, iters, stream, warm=1):
     """Average duration (s) of `fn` measured with events recorded on `stream` (the stream the kernels
     are launched on)."""
     import torch
 
     with torch.cuda.stream(stream):
-        fn()
+        for _ in range(warm):
+            fn()
         stream.synchronize()
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
@@ -154,7 +155,7 @@ def roofline_leg(model, batch, img):
         a = torch.randn(M, K_, device=x.device).bfloat16()
         w = (torch.randn(N_, K_, device=x.device) / K_ ** 0.5).bfloat16()
         bias = torch.randn(N_, device=x.device)
-        t = hip_event_time(lambda: ops.linear_bf16_hip(a, w, bias, gelu), 10, stream)
+        t = hip_event_time(lambda: ops.linear_bf16_hip(a, w, bias, gelu), 20, stream, warm=3)
         r = row("vit_linear_%s(M=%d,K=%d,N=%d%s)" % (name, M, K_, N_, ",+bias+GELU" if gelu else ""), "mfma",
                 2.0 * M * K_ * N_, 1e12, 2500.0, "TFLOP/s", t)
         r["algorithmic_bytes"] = 2.0 * (M * K_ + N_ * K_ + M * N_) + 4.0 * N_  # A, W, C in bf16 + fp32 bias, each once
