@@ -156,3 +156,62 @@ def test_gather_rows_kernel_matches_torch_composite():
     f = torch.randn(2, 10, 4, device="cuda", requires_grad=True)
     out = ops.gather_rows(f, torch.randint(0, 10, (2, 3), device="cuda"))
     assert out.grad_fn is not None
+
+
+def _unsplit(xs, C):
+    """(rows, 2C) bf16 split layout -> fp32 hi + lo."""
+    rows = xs.shape[0]
+    blocks = xs.reshape(rows, C // 32, 2, 32).float()
+    return (blocks[:, :, 0] + blocks[:, :, 1]).reshape(rows, C)
+
+
+def test_scale_residual_layernorm_f32_kernel():
+    """unopose_scale_residual_layernorm_f32: the residual update is the two-rounding x + (gamma * y) of the op-by-op path bit for bit;
+    the LayerNorm comes back in the split layout of csrc/gemm_f32.hip (hi + lo within 2^-16 of the fp32 value)."""
+    from unopose_amd import ops
+
+    torch.manual_seed(0)
+    x = torch.randn(3, 101, 768, device="cuda")
+    y = torch.randn(3, 101, 768, device="cuda")
+    gamma = torch.rand(768, device="cuda")
+    norm = torch.nn.LayerNorm(768, eps=1e-6).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+    want_x = x + y * gamma
+    want_n = norm(want_x)
+    xs = x.clone()
+    ns = ops.scale_residual_layernorm_f32_(xs, y, gamma, norm)
+    assert torch.equal(xs, want_x)
+    got_n = _unsplit(ns, 768).reshape(3, 101, 768)
+    assert float((got_n - want_n).abs().max()) < 2e-5 * float(want_n.abs().max())
+    # LayerNorm only (y = None) and residual only (norm = None)
+    xs2 = x.clone()
+    n_only = _unsplit(ops.scale_residual_layernorm_f32_(xs2, None, None, norm), 768).reshape(3, 101, 768)
+    assert torch.equal(xs2, x) and float((n_only - norm(x)).abs().max()) < 2e-5 * float(norm(x).abs().max())
+    xs3 = x.clone()
+    assert ops.scale_residual_layernorm_f32_(xs3, y, gamma, None) is xs3 and torch.equal(xs3, want_x)
+    # the layout is the split kernel's: the hi halves are the bf16 roundings of the values the pair encodes (lo < half an ulp of hi)
+    hi = ns.reshape(-1, 24, 2, 32)[:, :, 0].float()
+    assert float((hi - _unsplit(ns, 768).reshape(-1, 24, 32)).abs().max()) <= 2.0 ** -8 * float(hi.abs().max())
+
+
+@torch.no_grad()
+def test_vit_fp32_fused_blocks_match_the_op_by_op_path(monkeypatch):
+    """ViT without autocast: the fused fp32-class blocks (split-layout LayerNorms feeding the GEMMs) against the same model run block
+    by block through torch LayerNorm / multiply / add (both on csrc/gemm_f32.hip): taps agree to fp32 rounding."""
+    from unopose_amd import ops
+    from unopose_amd.model.modules import ViT
+
+    torch.manual_seed(1)
+    vit = ViT(img_size=224).cuda().eval()
+    for p in vit.parameters():
+        if p.dim() == 1 and p.numel() == 768 and float(p.abs().max()) < 1e-3:
+            p.fill_(0.3)  # LayerScale gammas: make the branches matter
+    x = torch.randn(3, 3, 224, 224, device="cuda")
+    fused = vit(x)
+    monkeypatch.setattr(ops, "vit_f32_fused_ok", lambda *a, **k: False)
+    plain = vit(x)
+    assert len(fused) == len(plain) == 4
+    for a, b in zip(fused, plain):
+        assert float((a - b).abs().max()) < 5e-5 * float(b.abs().max())

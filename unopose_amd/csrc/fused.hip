@@ -190,6 +190,70 @@ __global__ __launch_bounds__(256) void scale_residual_layernorm_kernel(float *__
   }
 }
 
+// The fp32 twin (the reference's default precision, csrc/gemm_f32.hip): x[r,:] += gamma * y[r,:] with y FP32 (y == NULL: no update),
+// and LayerNorm(x[r,:]) written in the SPLIT layout the fp32-class GEMM reads (per row and 32-channel block one 128-byte line
+// [hi (32 bf16) | lo (32 bf16)]; out == NULL: residual update only).  Replaces LayerScale multiply + residual add + LayerNorm +
+// split pass (four trips over the residual stream) of a ViT block branch.
+__global__ __launch_bounds__(256) void scale_residual_layernorm_f32_kernel(float *__restrict__ x, const float *__restrict__ y,
+                                                                           const float *__restrict__ gamma, const float *__restrict__ w,
+                                                                           const float *__restrict__ bias, long rows, int C, float eps,
+                                                                           char *__restrict__ out) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+      xv = *reinterpret_cast<const float4 *>(x + (size_t)r * C + c);
+      if (y) {
+        const float4 yv = *reinterpret_cast<const float4 *>(y + (size_t)r * C + c);
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + c);
+        xv.x += g.x * yv.x; xv.y += g.y * yv.y; xv.z += g.z * yv.z; xv.w += g.w * yv.w;
+        *reinterpret_cast<float4 *>(x + (size_t)r * C + c) = xv;
+      }
+    }
+    v[i * 4 + 0] = xv.x; v[i * 4 + 1] = xv.y; v[i * 4 + 2] = xv.z; v[i * 4 + 3] = xv.w;
+    s += (xv.x + xv.y) + (xv.z + xv.w);
+  }
+  if (!out) return;
+  const float mean = wave_sum_f32(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i * 4 + e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum_f32(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+      const float4 wv = *reinterpret_cast<const float4 *>(w + c), bv = *reinterpret_cast<const float4 *>(bias + c);
+      const float n0 = (v[i * 4 + 0] - mean) * rstd * wv.x + bv.x, n1 = (v[i * 4 + 1] - mean) * rstd * wv.y + bv.y;
+      const float n2 = (v[i * 4 + 2] - mean) * rstd * wv.z + bv.z, n3 = (v[i * 4 + 3] - mean) * rstd * wv.w + bv.w;
+      uint2 h, l;
+      h.x = cvt_pk_bf16_f32(n0, n1);
+      h.y = cvt_pk_bf16_f32(n2, n3);
+      l.x = cvt_pk_bf16_f32(n0 - __uint_as_float(h.x << 16), n1 - __uint_as_float(h.x & 0xffff0000u));
+      l.y = cvt_pk_bf16_f32(n2 - __uint_as_float(h.y << 16), n3 - __uint_as_float(h.y & 0xffff0000u));
+      // channels c .. c+3 = half of the 8-element chunk c / 8 of 32-channel block c / 32: hi at +0, lo at +64 of the 128-byte line
+      char *line = out + (size_t)r * C * 4 + (size_t)(c >> 5) * 128 + ((c >> 3) & 3) * 16 + ((c >> 2) & 1) * 8;
+      *reinterpret_cast<uint2 *>(line) = h;
+      *reinterpret_cast<uint2 *>(line + 64) = l;
+    }
+  }
+}
+
 // x[r,:] += gamma[:] * y[r,:]   (x fp32 in place, y bf16)  -- LayerScale residual of a ViT block
 __global__ __launch_bounds__(256) void scale_residual_kernel(float *__restrict__ x, const u16 *__restrict__ y,
                                                              const float *__restrict__ gamma, long n4, int C) {
@@ -330,6 +394,16 @@ int unopose_scale_residual_layernorm(float *x, const void *y_bf16, const float *
   hipLaunchKernelGGL(scale_residual_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                      (hipStream_t)stream, x, (const u16 *)y_bf16, gamma, w, bias, rows, C, eps, (u16 *)out_bf16);
   return check_launch("scale_residual_layernorm");
+}
+
+int unopose_scale_residual_layernorm_f32(float *x, const float *y, const float *gamma, const float *w, const float *bias, long rows, int C,
+                                         float eps, void *out_split, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(x && (y || out_split) && (!y || gamma) && (!out_split || (w && bias)), "scale_residual_layernorm_f32: null pointer");
+  UNOPOSE_REQUIRE(rows >= 0 && C >= 32 && C % 32 == 0 && C <= 1024, "scale_residual_layernorm_f32: C must be a multiple of 32, <= 1024");
+  if (rows == 0) return UNOPOSE_OK;
+  hipLaunchKernelGGL(scale_residual_layernorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, gamma, w,
+                     bias, rows, C, eps, (char *)out_split);
+  return check_launch("scale_residual_layernorm_f32");
 }
 
 int unopose_scale_residual(float *x, const void *y_bf16, const float *gamma, long rows, int C,

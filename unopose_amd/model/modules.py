@@ -68,6 +68,25 @@ class _Block(nn.Module):
             return x, None
         return x, ops.scale_residual_layernorm_(x, y, self.ls2.gamma, next_norm)
 
+    def forward_fused_f32(self, x, n1s, next_norm):
+        """The same without autocast (the reference's default precision): `n1s` = norm1(x) in the split layout of csrc/gemm_f32.hip;
+        qkv, fc1 and fc2 read split operands directly (fc1 hands its GELU output to fc2 in that layout too), the attention core and
+        the projection run on fp32 data, and each LayerScale residual also emits the next LayerNorm in split form -- one pass over
+        the residual stream per branch instead of multiply + add + LayerNorm + split."""
+        B, T, C = x.shape
+        rows = B * T
+        a, m = self.attn, self.mlp
+        cq = ops._f32x3_weights(a.qkv)
+        qkv = ops.linear_f32x3(n1s, cq[1], cq[2], rows, 3 * C, C).reshape(B, T, 3 * C)
+        y = ops.linear(ops.vit_attention(qkv, a.heads), a.proj)
+        n2s = ops.scale_residual_layernorm_f32_(x, y, self.ls1.gamma, self.norm2)
+        c1, c2 = ops._f32x3_weights(m.fc1), ops._f32x3_weights(m.fc2)
+        hs = ops.linear_f32x3(n2s, c1[1], c1[2], rows, 4 * C, C, gelu=True, out="split")
+        y = ops.linear_f32x3(hs, c2[1], c2[2], rows, C, 4 * C).reshape(B, T, C)
+        if next_norm is None:
+            return ops.scale_residual_layernorm_f32_(x, y, self.ls2.gamma, None), None
+        return x, ops.scale_residual_layernorm_f32_(x, y, self.ls2.gamma, next_norm)
+
     def forward(self, x):
         if torch.is_autocast_enabled() and x.dtype == torch.float32 and x.is_cuda and not ops.is_differentiable():
             # fused glue (csrc/fused.hip): LayerNorm -> bf16 in one pass, LayerScale residual in one pass;
@@ -130,6 +149,14 @@ class ViT(nn.Module):
             # fused glue: each block's LayerScale residual also produces the next LayerNorm (csrc/fused.hip)
             x = x.contiguous()
             return self._fused_blocks(x, ops.add_layernorm(x, None, self.blocks[0].norm1, torch.bfloat16), taps_side_by_side)
+        if ops.vit_f32_fused_ok(x, self):
+            x = x.contiguous()
+            ns = ops.scale_residual_layernorm_f32_(x, None, None, self.blocks[0].norm1)
+            for i, blk in enumerate(self.blocks):
+                x, ns = blk.forward_fused_f32(x, ns, self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None)
+                if i in taps:
+                    outs.append(self.norm(x))
+            return outs
         for i, blk in enumerate(self.blocks):
             x = blk(x)
             if i in taps:
@@ -506,7 +533,7 @@ class PositionalEncoding(nn.Module):
                 f1 = self.mlp1(ops.query_lrf_group(pts, self.r1, self.ns1)).max(dim=3)[0]
                 f2 = self.mlp2(ops.query_lrf_group(pts, self.r2, self.ns2)).max(dim=3)[0]
             return torch.cat([f1, f2], dim=1).transpose(1, 2)
-        if pts.is_cuda and torch.is_autocast_enabled() and self.r2 >= self.r1 and self.ns1 % 32 == 0 and self.ns2 % 32 == 0:
+        if pts.is_cuda and (torch.is_autocast_enabled() or ops.USE_F32X3) and self.r2 >= self.r1 and self.ns1 % 32 == 0 and self.ns2 % 32 == 0:
             # the wide scale first: its neighbour lists are the candidates of the narrow scale (csrc/pe.hip)
             f2, cand = ops.pe_group_mlp_max(pts, self.r2, self.ns2, self.mlp2, want_cand=True)
             f1 = ops.pe_group_mlp_max(pts, self.r1, self.ns1, self.mlp1, cand_in=cand)

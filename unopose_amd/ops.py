@@ -1139,8 +1139,8 @@ def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None, cand_in=None, want_
     `cand_in` lets this pass test those candidates instead of scanning the cloud (same result).
     `out_split` = (buf (Btot,N,2W) bf16 viewed as the split layout of a W-wide fp32 row, first cloud b0, first channel c0):
     the 128 channels go straight into that operand of csrc/gemm_f32.hip (bf16x3 kernel only); returns buf."""
-    if bf16x3 is None:
-        bf16x3 = torch.is_autocast_enabled()
+    if bf16x3 is None:  # the hi/lo-split matrix-core form is the fp32-class arithmetic of every other contraction of the fp32 path too
+        bf16x3 = torch.is_autocast_enabled() or USE_F32X3
     if [tuple(l.conv.weight.shape[:2]) for l in mlp.layers()] != [(32, 6), (64, 32), (128, 64)] or nsample % 32:
         return pe_group_mlp_max_unfused(pts, radius, nsample, mlp)  # other widths: grouping kernel + GEMMs
     pts = _c(pts.float())
@@ -1456,6 +1456,27 @@ def scale_residual_(x, y, gamma):
     with torch.cuda.device(x.device):
         call("unopose_scale_residual", ptr(x), ptr(y), ptr(gamma), x.numel() // C, C, stream_ptr())
     return x
+
+
+def scale_residual_layernorm_f32_(x, y, gamma, norm):
+    """fp32 twin for the no-autocast path: x (fp32, contiguous) += gamma * y (fp32) in place (y None: no update); returns
+    LayerNorm(x) in the split layout of csrc/gemm_f32.hip as a (rows, 2C) bf16 tensor (norm None: residual update only, returns x)."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and (y is None or y.dtype == torch.float32)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    out = None if norm is None else torch.empty(rows, 2 * C, dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        call("unopose_scale_residual_layernorm_f32", ptr(x), None if y is None else ptr(_c(y)), None if y is None else ptr(gamma),
+             None if norm is None else ptr(norm.weight), None if norm is None else ptr(norm.bias), rows, C,
+             0.0 if norm is None else float(norm.eps), None if out is None else ptr(out), stream_ptr())
+    return x if norm is None else out
+
+
+def vit_f32_fused_ok(x, vit):
+    """The no-autocast ViT on the fused fp32-class path (split-layout LayerNorm outputs feeding csrc/gemm_f32.hip directly)?"""
+    C = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.float32 and not _DIFF and not torch.is_autocast_enabled() and USE_F32X3 and C % 32 == 0 and C <= 1024
+            and f32x3_ok(x.numel() // C, 3 * C, C) and f32x3_ok(x.numel() // C, C, 4 * C))
 
 
 def scale_residual_layernorm_(x, y, gamma, norm):
