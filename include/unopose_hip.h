@@ -287,6 +287,9 @@ int unopose_token_attention_f32(const float *q, int ldq, const float *k, int ldk
                                 const float *qp, int ldqp, const float *E, int B, int n, int m,
                                 float scale, float *out, unopose_stream_t stream);
 int unopose_vit_attention_f32(const float *qkv, int B, int T, int H, float *out, unopose_stream_t stream);
+/* The same with the output in the split layout of unopose_linear_f32x3 ((B,T,2 H 64) bf16: the operand of the projection that
+ * follows, timm Attention.proj). */
+int unopose_vit_attention_f32_split(const float *qkv, int B, int T, int H, void *out_split, unopose_stream_t stream);
 
 /* ViT attention core (timm Attention as driven by core/unopose/model/oneref_feature_extraction.py:38-41):
  * out (B,T,H*64) = softmax(q k^T / 8) v per head, flash-style.  qkv (B,T,3,H,64) = the fused qkv Linear

@@ -215,3 +215,13 @@ def test_vit_fp32_fused_blocks_match_the_op_by_op_path(monkeypatch):
     assert len(fused) == len(plain) == 4
     for a, b in zip(fused, plain):
         assert float((a - b).abs().max()) < 5e-5 * float(b.abs().max())
+
+
+def test_vit_attention_f32_split_output():
+    """The fp32 ViT attention writing the split layout == the split kernel applied to its fp32 output, bit for bit."""
+    from unopose_amd import ops
+
+    torch.manual_seed(2)
+    qkv = torch.randn(3, 261, 2304, device="cuda")
+    want = ops.split_f32(ops.vit_attention(qkv, 12).reshape(-1, 768))
+    assert torch.equal(ops.vit_attention_f32_split(qkv, 12), want)

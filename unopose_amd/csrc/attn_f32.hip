@@ -165,6 +165,9 @@ __global__ __launch_bounds__(256) void token_attn_f32_kernel(const float *__rest
 // ---- ViT attention (see vit_attn.hip): flash-style, K / V^T chunks in LDS as fp32 ----------------------
 constexpr int AV_CHUNK = 64, AV_LDK = 64 + 4, AV_LDV = AV_CHUNK + 4;
 
+// SPLIT: the output is written in the split layout of csrc/gemm_f32.hip (per token and 32-channel block one 128-byte line
+// [hi (32 bf16) | lo (32 bf16)]) -- the operand form of the projection GEMM that follows, instead of fp32 + a split pass.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float *__restrict__ qkv, int T, int H, float scale_log2e,
                                                            float *__restrict__ out) {
   // K chunk + V^T chunk (2 x 17 KiB); the same 34 KiB are re-used as the output transpose buffer at the end
@@ -275,9 +278,22 @@ __global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float *__restri
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int row = it * 4 + (lane >> 4), seg = lane & 15;
-    if (q0 + row < T)
-      *reinterpret_cast<float4 *>(out + ((size_t)b * T + q0 + row) * (H * 64) + h * 64 + seg * 4) =
-          *reinterpret_cast<const float4 *>(&Ot[wave][row][seg * 4]);
+    if (q0 + row < T) {
+      const float4 v = *reinterpret_cast<const float4 *>(&Ot[wave][row][seg * 4]);
+      if (SPLIT) {
+        const int c = h * 64 + seg * 4;
+        uint2 hi, lo;
+        hi.x = cvt_pk_bf16_f32(v.x, v.y);
+        hi.y = cvt_pk_bf16_f32(v.z, v.w);
+        lo.x = cvt_pk_bf16_f32(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u));
+        lo.y = cvt_pk_bf16_f32(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u));
+        char *line = reinterpret_cast<char *>(out) + ((size_t)b * T + q0 + row) * (size_t)(H * 64) * 4 + (size_t)(c >> 5) * 128 + (c & 31) * 2;
+        *reinterpret_cast<uint2 *>(line) = hi;
+        *reinterpret_cast<uint2 *>(line + 64) = lo;
+      } else {
+        *reinterpret_cast<float4 *>(out + ((size_t)b * T + q0 + row) * (H * 64) + h * 64 + seg * 4) = v;
+      }
+    }
   }
 }
 
@@ -313,9 +329,19 @@ int unopose_vit_attention_f32(const float *qkv, int B, int T, int H, float *out,
   UNOPOSE_REQUIRE(B >= 0 && T >= 1 && H >= 1 && B <= 65535 && H <= 65535, "vit_attention_f32: bad sizes");
   if (B == 0) return UNOPOSE_OK;
   dim3 grid(cdiv(T, 128), H, B);
-  hipLaunchKernelGGL(vit_attn_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, T, H,
+  hipLaunchKernelGGL(vit_attn_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, qkv, T, H,
                      0.125f * 1.4426950408889634f, out);
   return check_launch("vit_attention_f32");
+}
+
+int unopose_vit_attention_f32_split(const float *qkv, int B, int T, int H, void *out_split, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(qkv && out_split, "vit_attention_f32_split: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && T >= 1 && H >= 1 && B <= 65535 && H <= 65535, "vit_attention_f32_split: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  dim3 grid(cdiv(T, 128), H, B);
+  hipLaunchKernelGGL(vit_attn_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, qkv, T, H, 0.125f * 1.4426950408889634f,
+                     (float *)out_split);
+  return check_launch("vit_attention_f32_split");
 }
 
 }  // extern "C"

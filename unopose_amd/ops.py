@@ -688,6 +688,18 @@ def vit_attention(qkv, heads):
     return vit_attention_torch(qkv, heads)
 
 
+def vit_attention_f32_split(qkv, heads):
+    """fp32 qkv (B,T,3C) -> the attention output in the split layout of csrc/gemm_f32.hip, a (B*T, 2C) bf16 tensor: the operand of
+    the projection GEMM, written by the attention kernel itself (no fp32 round trip, no split pass)."""
+    B, T, C3 = qkv.shape
+    assert qkv.dtype == torch.float32 and qkv.is_cuda and C3 == 3 * heads * 64
+    qkv = _c(qkv)
+    out = torch.empty(B * T, 2 * (C3 // 3), dtype=torch.bfloat16, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        call("unopose_vit_attention_f32_split", ptr(qkv), B, T, heads, ptr(out), stream_ptr())
+    return out
+
+
 def vit_attention_torch(qkv, heads):
     """Op-by-op composite of the same function."""
     B, T, C3 = qkv.shape
@@ -1476,7 +1488,7 @@ def vit_f32_fused_ok(x, vit):
     """The no-autocast ViT on the fused fp32-class path (split-layout LayerNorm outputs feeding csrc/gemm_f32.hip directly)?"""
     C = x.shape[-1]
     return (x.is_cuda and x.dtype == torch.float32 and not _DIFF and not torch.is_autocast_enabled() and USE_F32X3 and C % 32 == 0 and C <= 1024
-            and f32x3_ok(x.numel() // C, 3 * C, C) and f32x3_ok(x.numel() // C, C, 4 * C))
+            and C % 64 == 0 and f32x3_ok(x.numel() // C, 3 * C, C) and f32x3_ok(x.numel() // C, C, 4 * C))
 
 
 def scale_residual_layernorm_(x, y, gamma, norm):
