@@ -554,3 +554,57 @@ def test_unsupported_shapes_fall_back_to_gpu_composites(model):
     x = torch.rand(1, 100, 3).cuda()
     mlp = model.fine_point_matching.PE.mlp1
     assert ops.pe_group_mlp_max(x, 0.3, 16, mlp).shape == (1, 100, 128)  # nsample not a multiple of 32
+
+
+@torch.no_grad()
+def test_untamed_weights_end_to_end_intermediates_vs_oracle(model, oracle_ext):
+    """the end-to-end fixtures use tamed weights (random weights make the POSE degenerate).
+    This test drives the whole forward with UNTAMED random weights and compares every stage's tensors -- not the pose -- with the
+    oracle run on the same inputs on the CPU: sampling indices bit-exact, ViT pixel features, sparse subsets, coarse-stage token
+    features / similarity / scores (no local frames involved: tight), fine-stage token features given the SAME initial pose (PE rests
+    on local frames, implementation-defined where ill-conditioned: the bulk of the tokens must agree)."""
+    from oracle import unopose_ref as R
+    from unopose_amd.synthetic import make_batch
+
+    cfg = R.default_cfg()
+    sd = R.random_state_dict(cfg, seed=0)  # untamed: the weights of the `model` fixture
+    rand = torch.rand(1, 18000, generator=torch.Generator().manual_seed(4))
+    # The 5000 -> 2048 FPS runs on points divided by a radius that torch reduces in a different order on the GPU and on the CPU: an
+    # ulp there can flip a near-tie of the FPS.  That is outside what this test compares, so the first seed whose FPS subset agrees is
+    # used (the FPS itself is pinned bit for bit on identical inputs in test_pointnet2_gpu.py / the golden forwards).
+    for seed in range(321, 331):
+        ep_cpu, _, _ = make_batch(1, 2048, 5000, 224, seed=seed)
+        ep = {k: v.cuda() for k, v in ep_cpu.items()}
+        ep["coarse_rand"] = rand.cuda()
+        taps, ctaps, ftaps = {}, {}, {}
+        model.taps, model.coarse_point_matching.taps, model.fine_point_matching.taps = taps, ctaps, ftaps
+        try:
+            out = model(ep)
+        finally:
+            model.taps = model.coarse_point_matching.taps = model.fine_point_matching.taps = None
+        tem = ep_cpu["tem1_pts"]
+        tem_n = tem / (torch.norm(tem - tem.mean(1, keepdim=True), dim=2).max(1)[0].reshape(-1, 1, 1) + 1e-6)
+        idx = oracle_ext.furthest_point_sampling(tem_n.contiguous(), 2048).long()
+        if torch.equal(torch.gather(tem_n, 1, idx.unsqueeze(2).expand(-1, -1, 3)), taps["dense_po"].cpu()):
+            break
+    else:
+        pytest.skip("no seed with an ulp-stable FPS subset among ten")
+    ref = R.unopose_forward({k: v.clone() for k, v in ep_cpu.items()}, sd, cfg, rand, oracle_ext, detail=True)
+    c_ref = R.coarse_point_matching(ref["sparse_pm"], ref["sparse_fm"], ref["geo_m"], ref["sparse_po"], ref["sparse_fo"], ref["geo_o"], sd,
+                                    "coarse_point_matching", cfg.coarse_point_matching, rand, detail=True)[-1]
+    f_ref = R.fine_point_matching(ref["dense_pm"], ref["dense_fm"], ref["geo_m"], ref["fps_idx_m"], ref["dense_po"], ref["dense_fo"], ref["geo_o"],
+                                  ref["fps_idx_o"], ref["init_R"], ref["init_t"], sd, "fine_point_matching", cfg.fine_point_matching, oracle_ext,
+                                  detail=True)[-1]
+    rel = lambda a, b: float((a.float().cpu() - b.float()).abs().max() / b.float().abs().max())  # noqa: E731
+    assert torch.equal(taps["fps_idx_m"].cpu().long(), ref["fps_idx_m"].long()) and torch.equal(taps["fps_idx_o"].cpu().long(), ref["fps_idx_o"].long())
+    assert rel(taps["dense_pm"], ref["dense_pm"]) < 1e-6 and rel(taps["dense_po"], ref["dense_po"]) < 1e-6
+    assert rel(taps["dense_fm"], ref["dense_fm"]) < 2e-4 and rel(taps["dense_fo"], ref["dense_fo"]) < 2e-4  # 12 untamed ViT blocks, fp32-class GEMMs
+    for k in ("f1", "f2", "atten", "score"):
+        assert rel(ctaps[k], c_ref[k]) < 2e-3, (k, rel(ctaps[k], c_ref[k]))  # three geometric transformer blocks on 197 tokens
+    # fine stage: same initial pose required -- the HIP coarse pose equals the oracle's when the hypothesis ranking does (untamed
+    # weights give near-ties); compare the fine stage only in that case, and always require finite outputs of the right shape
+    assert torch.isfinite(out["pred_R"]).all() and out["pred_R"].shape == (1, 3, 3)
+    if float((out["init_R"].cpu() - ref["init_R"]).abs().max()) < 1e-4 and float((out["init_t"].cpu() - ref["init_t"]).abs().max()) < 1e-4:
+        for k in ("f1", "f2"):
+            d = (ftaps[k].float().cpu() - f_ref[k]).abs().amax(dim=2) / f_ref[k].abs().max()
+            assert float((d < 2e-3).float().mean()) > 0.9, (k, float((d < 2e-3).float().mean()))
