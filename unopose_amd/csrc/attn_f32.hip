@@ -162,20 +162,23 @@ __global__ __launch_bounds__(256) void token_attn_f32_kernel(const float *__rest
   }
 }
 
-// ---- ViT attention (see vit_attn.hip): flash-style, K / V^T chunks in LDS as fp32 ----------------------
-constexpr int AV_CHUNK = 64, AV_LDK = 64 + 4, AV_LDV = AV_CHUNK + 4;
+// ---- ViT attention (see vit_attn.hip): flash-style; K / V^T chunks in LDS ALREADY SPLIT into bf16 hi / lo planes ---------------
+// (the staging threads split every element once per workgroup; round 2 kept fp32 in LDS and every wave re-split every fragment at
+// every use -- ~190 of the ~340 vector instructions of a 32-key tile.  Same hi / lo values, so the results are bit-identical.)
+constexpr int AV_CHUNK = 64, AV_LDH = 64 + 8, AV_LDVH = AV_CHUNK + 8;  // u16 row strides of the K planes / the V^T planes
+typedef unsigned short u16f;
 
 // SPLIT: the output is written in the split layout of csrc/gemm_f32.hip (per token and 32-channel block one 128-byte line
 // [hi (32 bf16) | lo (32 bf16)]) -- the operand form of the projection GEMM that follows, instead of fp32 + a split pass.
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float *__restrict__ qkv, int T, int H, float scale_log2e,
                                                            float *__restrict__ out) {
-  // K chunk + V^T chunk (2 x 17 KiB); the same 34 KiB are re-used as the output transpose buffer at the end
-  __shared__ __attribute__((aligned(16))) float smem[AV_CHUNK * AV_LDK + 64 * AV_LDV];
-  float (*Ks)[AV_LDK] = reinterpret_cast<float (*)[AV_LDK]>(smem);
-  float (*Vs)[AV_LDV] = reinterpret_cast<float (*)[AV_LDV]>(smem + AV_CHUNK * AV_LDK);
-  float (*Ot)[32][68] = reinterpret_cast<float (*)[32][68]>(smem);
-  static_assert(4 * 32 * 68 <= AV_CHUNK * AV_LDK + 64 * AV_LDV, "output staging must fit the chunk buffers");
+  // K hi | K lo | V^T hi | V^T lo planes (4 x 9 KiB); the same memory is re-used as the output transpose buffer at the end
+  constexpr int PLANE_K = AV_CHUNK * AV_LDH, PLANE_V = 64 * AV_LDVH;
+  __shared__ __attribute__((aligned(16))) u16f smem16[2 * PLANE_K + 2 * PLANE_V];
+  u16f *Kh = smem16, *Kl = smem16 + PLANE_K, *Vh = smem16 + 2 * PLANE_K, *Vl = Vh + PLANE_V;
+  float (*Ot)[32][68] = reinterpret_cast<float (*)[32][68]>(smem16);
+  static_assert(4 * 32 * 68 * 4 <= (2 * PLANE_K + 2 * PLANE_V) * 2, "output staging must fit the chunk buffers");
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q0 = (blockIdx.x * 4 + wave) * 32;
@@ -197,19 +200,32 @@ __global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float *__restri
   float m_run = -3e38f, l_run = 0.f;
   for (int c0 = 0; c0 < T; c0 += AV_CHUNK) {
     __syncthreads();
-    // 64 keys x 64 channels fp32 for K and V: 1024 float4 each, 4 per thread
+    // 64 keys x 64 channels fp32 for K and V: 1024 float4 each, 4 per thread; split once here
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = tid + i * 256, key = e >> 4, c4 = e & 15;
       const float *src = base + (size_t)min(c0 + key, T - 1) * C3 + h * 64 + c4 * 4;
       const float4 kv = *reinterpret_cast<const float4 *>(src + H * 64);
-      const float4 vv = *reinterpret_cast<const float4 *>(src + 2 * H * 64);
-      *reinterpret_cast<float4 *>(&Ks[key][c4 * 4]) = kv;
-      const bool valid = c0 + key < T;
-      Vs[c4 * 4 + 0][key] = valid ? vv.x : 0.f;
-      Vs[c4 * 4 + 1][key] = valid ? vv.y : 0.f;
-      Vs[c4 * 4 + 2][key] = valid ? vv.z : 0.f;
-      Vs[c4 * 4 + 3][key] = valid ? vv.w : 0.f;
+      float4 vv = *reinterpret_cast<const float4 *>(src + 2 * H * 64);
+      if (c0 + key >= T) vv = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint2 kh, kl;
+      kh.x = af_cvt_pk(kv.x, kv.y);
+      kh.y = af_cvt_pk(kv.z, kv.w);
+      kl.x = af_cvt_pk(kv.x - __uint_as_float(kh.x << 16), kv.y - __uint_as_float(kh.x & 0xFFFF0000u));
+      kl.y = af_cvt_pk(kv.z - __uint_as_float(kh.y << 16), kv.w - __uint_as_float(kh.y & 0xFFFF0000u));
+      *reinterpret_cast<uint2 *>(Kh + key * AV_LDH + c4 * 4) = kh;
+      *reinterpret_cast<uint2 *>(Kl + key * AV_LDH + c4 * 4) = kl;
+      const uint32_t vh0 = af_cvt_pk(vv.x, vv.y), vh1 = af_cvt_pk(vv.z, vv.w);
+      const uint32_t vl0 = af_cvt_pk(vv.x - __uint_as_float(vh0 << 16), vv.y - __uint_as_float(vh0 & 0xFFFF0000u));
+      const uint32_t vl1 = af_cvt_pk(vv.z - __uint_as_float(vh1 << 16), vv.w - __uint_as_float(vh1 & 0xFFFF0000u));
+      Vh[(c4 * 4 + 0) * AV_LDVH + key] = (u16f)(vh0 & 0xFFFF);
+      Vh[(c4 * 4 + 1) * AV_LDVH + key] = (u16f)(vh0 >> 16);
+      Vh[(c4 * 4 + 2) * AV_LDVH + key] = (u16f)(vh1 & 0xFFFF);
+      Vh[(c4 * 4 + 3) * AV_LDVH + key] = (u16f)(vh1 >> 16);
+      Vl[(c4 * 4 + 0) * AV_LDVH + key] = (u16f)(vl0 & 0xFFFF);
+      Vl[(c4 * 4 + 1) * AV_LDVH + key] = (u16f)(vl0 >> 16);
+      Vl[(c4 * 4 + 2) * AV_LDVH + key] = (u16f)(vl1 & 0xFFFF);
+      Vl[(c4 * 4 + 3) * AV_LDVH + key] = (u16f)(vl1 >> 16);
     }
     __syncthreads();
     if (!active) continue;
@@ -221,7 +237,8 @@ __global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float *__restri
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const HL kf = af_load8(&Ks[kt + col][ks * 16 + hb * 8]);
+        const int off = (kt + col) * AV_LDH + ks * 16 + hb * 8;
+        const HL kf{*reinterpret_cast<const bf16x8 *>(Kh + off), *reinterpret_cast<const bf16x8 *>(Kl + off)};
         AF_MFMA3_32(s, kf, qf[ks]);
       }
       float mx = -3e38f;
@@ -255,10 +272,14 @@ __global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float *__restri
         const HL pf = af_split(pv);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const float *vp = &Vs[t * 32 + col][kt + s2 * 16 + 4 * hb];
-          const float4 v0 = *reinterpret_cast<const float4 *>(vp), v1 = *reinterpret_cast<const float4 *>(vp + 8);
-          const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-          const HL vf = af_split(vv);
+          // keys kt + 16 s2 + 4 hb + {0..3} and + 8 + {0..3}: two 8-byte reads per plane
+          const int off = (t * 32 + col) * AV_LDVH + kt + s2 * 16 + 4 * hb;
+          union { bf16x8 v; uint2 h2[2]; } VH, VL;
+          VH.h2[0] = *reinterpret_cast<const uint2 *>(Vh + off);
+          VH.h2[1] = *reinterpret_cast<const uint2 *>(Vh + off + 8);
+          VL.h2[0] = *reinterpret_cast<const uint2 *>(Vl + off);
+          VL.h2[1] = *reinterpret_cast<const uint2 *>(Vl + off + 8);
+          const HL vf{VH.v, VL.v};
           AF_MFMA3_32(o[t], vf, pf);
         }
       }
