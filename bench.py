@@ -203,6 +203,31 @@ def roofline_leg(model, batch, img):
     gp = torch.cat([torch.ones(B, 1, 3, device=x.device), x[:, :n - 1]], 1).contiguous()
     t = hip_event_time(lambda: ops.geo_embedding(gp, model.geo_embedding, out_dtype=torch.bfloat16), 10, stream)
     row("geo_embed_kernel<bf16>", "mfma", B * 8.0 * n * n * 256 * 256, 1e12, 2500.0, "TFLOP/s", t)
+    # correspondence-transformer attention on the 197-token coarse sequences, both clouds stacked (2B): the RPE self-attention streams the
+    # geometric embedding E (B2,197,197,256) bf16 once -- its only HBM-sized operand; the cross-attention (no E) is a 39.7 MFLOP problem
+    # per cloud and layer: launch / latency-sized
+    import ctypes
+
+    from unopose_amd._lib import call, ptr, stream_ptr
+
+    B2 = 2 * B
+    yq = torch.randn(B2, n, 1280, device=x.device).bfloat16()   # [q | q W_p (4 x 256)] rows as the model lays them out
+    ykv = torch.randn(B2, n, 512, device=x.device).bfloat16()
+    vt = torch.randn(B2, 256, 224, device=x.device).bfloat16()
+    Eb = torch.randn(B2, n, n, 256, device=x.device).bfloat16()
+    oa = torch.empty(B2, n, 256, device=x.device, dtype=torch.bfloat16)
+
+    def attn(rpe):
+        call("unopose_token_attention", ptr(yq), 1280, ptr(ykv), 512, ptr(vt), ctypes.c_void_p(yq.data_ptr() + 256 * 2) if rpe else None, 1280,
+             ptr(Eb) if rpe else None, B2, n, n, 0.125, ptr(oa), stream_ptr())
+
+    t = hip_event_time(lambda: attn(True), 10, stream)
+    row("token_attn_kernel<rpe>(self-attention, %d clouds x %d tokens)" % (B2, n), "hbm", 2.0 * B2 * n * n * 256 + 2.0 * B2 * n * (1280 + 512 + 256), 1e9,
+        8000.0, "GB/s", t, "streams the geometric embedding once; 6 launches per step")
+    t = hip_event_time(lambda: attn(False), 10, stream)
+    rows.append(dict(kernel="token_attn_kernel<cross>(%d clouds x %d tokens)" % (B2, n), bound="latency", us=t * 1e6,
+                     tflops=B2 * 4.0 * n * n * 256 / t / 1e12, note="4 n^2 256 flop per cloud: 2.5 GFLOP per launch, 12 launches per step"))
+    del yq, ykv, vt, Eb, oa
     # group_points (the reference's `_ext` gather): HBM-write-bound
     idx = _ext.ball_query(x, x, 0.2, 256)
     xt = x.transpose(1, 2).contiguous()
