@@ -9,71 +9,60 @@
 //     swizzle lives on the per-lane SOURCE address: LDS slot (row, p) holds the row's 16-byte chunk
 //     c = p ^ ((row >> 1) & 7)  and the fragment reads apply the same XOR -- every ds_read_b128 lane group then covers
 //     all 16 slots of the 256-byte bank row (conflict-free), and every DMA instruction still fetches full 128-byte lines;
+//   * two LDS buffers (2 x 64 KiB).  All 8 DMA pieces a wave owes the next K-tile go out in one burst right after the
+//     barrier (every piece then has the whole K-step to land; measured against spreading them over the MFMA groups, pacing
+//     them one per 2 / 3 / 4 MFMAs from wave-dependent offsets, and letting one wave of every SIMD issue all of them:
+//     DESIGN.md section 7), fragment reads run one k-substep ahead of the MFMAs (two register sets), one vmcnt(0) + barrier
+//     per K-tile;
+//   * ROTATED software pipeline: the last MFMA group (k-substep 3) of a K-tile is issued AFTER the barrier that ends the
+//     tile, behind the fragment reads of the next tile's substep 0 -- the matrix pipe restarts at the barrier release
+//     while those reads are in flight;
+//   * every tile starts its K walk at a tile-dependent K-tile (the sum is order-independent): concurrently running
+//     tiles then touch different 128-byte columns of their panels at any instant;
 //   * 8 waves as 2 (M) x 4 (N), 128 x 64 outputs per wave, v_mfma_f32_32x32x16_bf16 with the operands SWAPPED
 //     (rows of the MFMA result = output columns n): a lane then owns 4 consecutive n of one output row, which
 //     packs to 8-byte LDS writes in the epilogue;
-//   * ROUND 4 -- the K loop is a HALF-TILE STREAM with COUNTED waits (never vmcnt(0) inside the stream).  A K-tile is four
-//     16-KiB half-tiles in stream order  A0 (rows 0-63 of each wave row-block), B0 (columns 0-31 of each wave column-block),
-//     B1, A1;  the ring is 2 K-tiles x 4 half-tile slots = 128 KiB.  A K-tile is computed in two PHASES of two 64 x 32 output
-//     quadrants over the whole K-step each (16 MFMAs):  X = (A0 x B0, A0 x B1),  Y = (A1 x B1, A1 x B0),  and every phase is
-//         [fragment reads of the phase | LDS-DMA pieces (X: one half-tile, Y: three) | s_waitcnt vmcnt(8) | lgkmcnt(0)]
-//         s_barrier   [16 MFMAs]   s_barrier
-//     Four half-tiles (8 loads per wave) stay in flight ACROSS the barriers; a half-tile is read one phase after the wait
-//     that covers it and its slot is refilled one phase after its last read (reads retired before the barrier).
-//     The two wave groups (wm = 0 / 1: one wave of each per SIMD) run ONE BARRIER apart, so one group's MFMA segment sits
-//     beside the other group's read / DMA segment on every SIMD (ping-pong).  The guide's 4-phase form (8 MFMAs per phase, 8
-//     barriers per K-tile) was built first and measured 12-16 % slower on every shape: scripts/ubench/gemm_r04_variants.hip;
-//   * the stream does not stop at a tile boundary: while the last two K-tiles of a tile are computed the first six
-//     half-tiles of the NEXT tile (and its bias slice, also by LDS-DMA) are issued, the epilogue stages C through the two slots
-//     of the ring the stream refills last (A1 / B1 of the last K-tile's buffer, 4 KiB per wave), and the next tile's
-//     phases find their operands landed.  Only a workgroup's last tile drains (counted 4 / 2 / 0);
-//   * every tile starts its K walk at a tile-dependent K-tile (the sum is order-independent): concurrently running
-//     tiles then touch different 128-byte columns of their panels at any instant;
 //   * epilogue on the fp32 accumulators: + bias, optional GELU / ReLU / residual + LayerNorm, bf16, staged through LDS
-//     (XOR-swizzled) and written as whole 128-byte row segments with NON-TEMPORAL stores when the output exceeds the L2s.
-#include <type_traits>
-
+//     (XOR-swizzled, the K-loop buffers are free by then) and written as whole 128-byte row segments with NON-TEMPORAL
+//     stores (a round of tiles writes 4 MiB per XCD -- the size of its L2 -- and nothing re-reads C before the next
+//     launch); the next tile's first K-tile streams in meanwhile.
 #include "gemm_common.h"
 
 namespace unopose {
 
 #ifndef GEMM_ABL
-#define GEMM_ABL 0  // scripts/ubench/gemm_var.py: 1 = no LDS-DMA in the K loop, 2 = no MFMAs, 3 = no fragment reads
+#define GEMM_ABL 0  // scripts/ubench/gemm_var.py: 1 = no LDS-DMA in the K loop, 2 = no MFMAs, 3 = no fragment reads, 6 = DMA only
 #endif
 #ifndef GEMM_EABL
-#define GEMM_EABL 0  // epilogue ablations: 1 = no global stores, 2 = no epilogue at all (accumulators kept live), 3 = no bias / activation math
+#define GEMM_EABL 0  // epilogue ablations: 1 = no global stores, 2 = no epilogue at all (accumulators kept live)
 #endif
 #ifndef GEMM_SAME
 #define GEMM_SAME 0  // probe: every tile streams the operands of tile (0, 0) -- an all-hit L2 stream under the full K loop
 #endif
-#ifndef GEMM_PRIO
-#define GEMM_PRIO 0  // 1 = s_setprio 1 around the MFMA segment (measured: -1..2 % with 16-MFMA segments; scripts/ubench/gemm_r04_variants.hip)
+#ifndef GEMM_STAMP
+#define GEMM_STAMP 0  // probe: s_memtime stamps around the K-step's waits of one workgroup (scripts/ubench/gv_stamp.py)
+#endif
+#if GEMM_STAMP
+__device__ unsigned long long g_stamps[8 * 64 * 4];
+extern "C" int unopose_gemm_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
 #endif
 #define GEMM_BK 64
-constexpr bool kMfma = GEMM_ABL != 2, kFrag = GEMM_ABL != 3, kDma = GEMM_ABL != 1;
-
-#ifndef GEMM_ROTX
-#define GEMM_ROTX 5  // K-tile rotation between XCDs (-1: spread evenly, xcd * nk / 8) and between steps
-#endif
-#ifndef GEMM_ROTS
-#define GEMM_ROTS 3
-#endif
-
-#define GEMM_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define GEMM_WAIT_VM_(n) GEMM_WAIT_VM(n)
-
-// LDS map (ONE __shared__ object): [0, 128 Ki) the ring: buffer b at b * 64 Ki = A image (32 Ki) | W image (32 Ki);
-// then 2 x 1 Ki bias slices (tile parity); EPI 3 only: LayerNorm weight / bias (2 x 1 Ki) and the row-statistics exchange (8 Ki).
-#define GEMM_LDS_BIAS (2 * GEMM_BUFBYTES)
-#define GEMM_LDS_LNW (GEMM_LDS_BIAS + 2048)
-#define GEMM_LDS_LNB (GEMM_LDS_LNW + 1024)
-#define GEMM_LDS_LNPART (GEMM_LDS_LNB + 1024)
+constexpr bool kMfma = GEMM_ABL != 2 && GEMM_ABL < 5, kFrag = GEMM_ABL != 3 && GEMM_ABL < 5, kDma = GEMM_ABL != 1;
 
 // GATHER (grouped, row-gathered form; unopose_linear_bf16_gather): output row r of tile t is A row row_list[256 t + r]
 // times the 256-row weight block of the group tile t belongs to (tile_info[1 + g] = first tile of group g, g = 0..N/256;
 // tile_info[0] = number of tiles, read on the device: the host never learns it); C is (tiles * 256, 256).
 // EPI 3 (N == 256 only: a row is one tile wide): C = LayerNorm(A W^T + bias + resid) * ln_w + ln_b, the post-LN glue of the
 // matcher's transformer layers (transformer.py:151-193) -- the residual add and the LayerNorm run on the fp32 accumulators.
+#ifndef GEMM_PP
+#define GEMM_PP 0  // 1 / 2: ping-pong K loop (see the kernel); 2 = all 8 DMA pieces in phase 0
+#endif
+#ifndef GEMM_ROTX
+#define GEMM_ROTX 5  // K-tile rotation between XCDs (-1: spread evenly, xcd * nk / 8) and between steps
+#endif
+#ifndef GEMM_ROTS
+#define GEMM_ROTS 3
+#endif
 template <int EPI, bool GATHER = false>  // EPI 0: bias; 1: bias + GELU; 2: bias + ReLU; 3: bias + residual + LayerNorm
 __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict__ A, const u16 *__restrict__ W,
                                                            const float *__restrict__ bias, u16 *__restrict__ C, int M,
@@ -83,12 +72,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
                                                            const u16 *__restrict__ resid = nullptr, const float *__restrict__ ln_w = nullptr,
                                                            const float *__restrict__ ln_b = nullptr, float ln_eps = 0.f, int lda = 0,
                                                            int ldw = 0, int ldc = 0) {
-  // row strides in elements (0 = dense; unopose_linear_bf16_ld)
+  // row strides in elements (0 = dense; unopose_linear_bf16_ld).  (Padding the 6144-byte rows of the ViT's hidden activation by 64
+  // elements was tried against L2 channel camping: no gain on the fc1 -> fc2 pair)
   const int LDA = lda ? lda : K, LDW = ldw ? ldw : K, LDC = ldc ? ldc : N;
   const int tiles = GATHER ? __builtin_amdgcn_readfirstlane(tile_info[0]) : tiles_arg;
-  __shared__ __attribute__((aligned(1024))) char smem[GEMM_LDS_BIAS + 2048 + (EPI == 3 ? 2048 + 8192 : 0)];
-  float *const lnw_lds = reinterpret_cast<float *>(smem + GEMM_LDS_LNW), *const lnb_lds = reinterpret_cast<float *>(smem + GEMM_LDS_LNB);
-  float2 *const ln_part = reinterpret_cast<float2 *>(smem + GEMM_LDS_LNPART);  // [wm][mb][row][wn]: (sum, sum of squares) of 64 columns
+  __shared__ __attribute__((aligned(1024))) char smem[2 * GEMM_BUFBYTES];
+  __shared__ __attribute__((aligned(16))) float bias_lds[GEMM_BN];  // this tile's bias slice (LDS reads: no vmcnt traffic in the epilogue)
+  __shared__ __attribute__((aligned(16))) float lnw_lds[EPI == 3 ? GEMM_BN : 4], lnb_lds[EPI == 3 ? GEMM_BN : 4];
+  __shared__ float2 ln_part[EPI == 3 ? 2 * 4 * 32 * 4 : 1];  // [wm][mb][row][wn]: (sum, sum of squares) of 64 columns
   if (EPI == 3 && threadIdx.x < GEMM_BN) {  // visible after the first barrier of the tile loop
     lnw_lds[threadIdx.x] = ln_w[threadIdx.x];
     lnb_lds[threadIdx.x] = ln_b[threadIdx.x];
@@ -97,19 +88,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, hi = lane >> 5;
   // ---- persistent, lock-stepped tile walk.  The grid is ONE workgroup per CU (gridDim.x <= 256, a multiple of 8;
-  // 130 KiB of LDS admits one per CU).  Workgroup b sits on XCD b % 8 (observed dispatch rule: a SPEED assumption
+  // 128 KiB of LDS admits one per CU).  Workgroup b sits on XCD b % 8 (observed dispatch rule: a SPEED assumption
   // only) and is slot b / 8 of that XCD; XCD x owns one contiguous range of the tile sequence and its slots take
   // tiles slot, slot + nslots, ... of it.  All workgroups start together and every tile costs the same, so the ~32
   // tiles an XCD has in flight are 32 CONSECUTIVE tiles walking K in lock step: a (GEMM_GM x 32/GEMM_GM) patch of the
-  // output that shares GEMM_GM A panels and 32/GEMM_GM W panels K-slice by K-slice in that XCD's L2.
+  // output that shares GEMM_GM A panels and 32/GEMM_GM W panels K-slice by K-slice in that XCD's L2.  (Measured against a
+  // schedule that keeps the W panels of a column group resident in L2 -- fewer L2 misses, same time: the K loop is not
+  // bound by the miss path)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int cq = tiles >> 3, cr = tiles & 7;
   const int chunk_base = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, chunk_len = cq + (xcd < cr ? 1 : 0);
   const int tiles_m = tiles / tiles_n, per_group = GEMM_GM * tiles_n;
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, (int)((size_t)M * LDA * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, (int)((size_t)N * LDW * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void *)C, 0, GATHER ? 0x7fffffff : (int)((size_t)M * LDC * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void *)bias, 0, N * 4, 0x00020000);
   const int nk = K / GEMM_BK;
 
   // ---- fragment read addresses: tile row r = base + l31 (base a multiple of 32), chunk c = 2 ks + hi:
@@ -118,17 +109,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   uint32_t fr_off[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) fr_off[ks] = (uint32_t)((l31 >> 3) * 1024 + (l31 & 7) * 128 + ((((ks << 1) | hi) ^ fx) << 4));
-  const uint32_t a_base = (uint32_t)(wm * 16384);                // A rows wm*128 ..  (+ ah * 8192 + mbl * 4096)
-  const uint32_t w_base = (uint32_t)(GEMM_OPBYTES + wn * 8192);  // W rows wn*64 ..   (+ bh * 4096)
-  // ---- LDS-DMA destinations of this wave's two pieces of a half-tile (within a buffer); piece i at + i * 1024
-  //      A half ah: rows (wave >> 2) * 128 + ah * 64 + (wave & 3) * 16 + 8 i ..;   B half bh: rows (wave >> 1) * 64 + bh * 32 + (wave & 1) * 16 + 8 i ..
-  const uint32_t a_dst = (uint32_t)((wave >> 2) * 16384 + (wave & 3) * 2048);
-  const uint32_t w_dst = (uint32_t)(GEMM_OPBYTES + (wave >> 1) * 8192 + (wave & 1) * 2048);
+  const uint32_t a_base = (uint32_t)(wm * 128 * 128);                // A rows wm*128 .. (+ mb * 32 rows = mb * 4096 B)
+  const uint32_t w_base = (uint32_t)(GEMM_OPBYTES + wn * 64 * 128);  // W rows wn*64 ..  (+ nb * 4096 B)
 
-  // per-tile DMA parameters: tile origin, K rotation, per-lane source offsets of the wave's pieces
+  // per-tile DMA parameters: tile origin, K rotation, per-lane source offsets of the wave's 4 + 4 pieces
   struct TileP {
     int m0, n0, rot;
-    uint32_t a_off[4], w_off[2];  // a_off[2 ah + i]; the B half enters through the scalar offset (32 rows further)
+    uint32_t a_off[4], w_off[4];
   };
   auto tile_params = [&](int ti, int step, TileP &p) {
     const int t = chunk_base + ti;
@@ -148,20 +135,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
     }
     p.m0 = __builtin_amdgcn_readfirstlane(tm * GEMM_BM);
     p.n0 = __builtin_amdgcn_readfirstlane(tn * GEMM_BN);
-    // per-lane byte offset in the VGPR, K-tile offset in an SGPR; rows past M (ragged last tile) fall outside the
-    // descriptor -> zeros
+    // LDS-DMA piece j = wave * 4 + i covers tile rows 8j .. 8j+7; per-lane byte offset in the VGPR, K-tile offset in an
+    // SGPR; rows past M (ragged last tile) fall outside the descriptor -> zeros
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = (wave >> 2) * 128 + (j >> 1) * 64 + (wave & 3) * 16 + (j & 1) * 8 + (lane >> 3);
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 32 + i * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((row >> 1) & 7);
       int arow = (GEMM_SAME ? 0 : p.m0) + row;
       if (GATHER) arow = max(row_list[p.m0 + row], 0);  // padding rows of a group (-1) compute on row 0; nobody reads them
-      p.a_off[j] = (uint32_t)(((size_t)arow * LDA + c * 8) * 2);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = (wave >> 1) * 64 + (wave & 1) * 16 + i * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      p.a_off[i] = (uint32_t)(((size_t)arow * LDA + c * 8) * 2);
       p.w_off[i] = (uint32_t)(((size_t)((GEMM_SAME ? 0 : p.n0) + row) * LDW + c * 8) * 2);
     }
     // K-tile rotation, uniform over the tiles an XCD runs together (they must stay on the same K-slice to share it) and
@@ -172,181 +154,169 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
     p.rot = __builtin_amdgcn_readfirstlane(((GEMM_ROTX < 0 ? xcd * nk / 8 : xcd * GEMM_ROTX) + step * GEMM_ROTS + skew) % nk);
   };
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
-  enum { H_A0 = 0, H_B0 = 1, H_B1 = 2, H_A1 = 3 };  // a K-tile's half-tiles in stream (= consumption) order
-  // this wave's 2 pieces of half-tile `kind` of K-tile kt (rotation applied here) of tile p into the buffer at byte `bufoff`
-  auto stage_half = [&](const TileP &p, int kind, int kt, uint32_t bufoff) {
-    if (!kDma) return;
-    kt += __builtin_amdgcn_readfirstlane(p.rot);
+  auto stage_tile = [&](const TileP &p, int buf, int kt) {  // the wave's 4 A + 4 W pieces of K-tile kt
+    kt += p.rot;
     if (kt >= nk) kt -= nk;
-    const int so = kt * (GEMM_BK * 2);
-    if (kind == H_A0 || kind == H_A1) {
-      const int ah = kind == H_A1 ? 1 : 0;
-      const uint32_t la = lds0 + bufoff + a_dst + ah * 8192;
-      gemm_dma16(la, p.a_off[2 * ah], a_rs, so);
-      gemm_dma16(la + 1024, p.a_off[2 * ah + 1], a_rs, so);
-    } else {
-      const int bh = kind == H_B1 ? 1 : 0;
-      const uint32_t lw = lds0 + bufoff + w_dst + bh * 4096;
-      const int sob = so + bh * (32 * 2) * LDW;
-      gemm_dma16(lw, p.w_off[0], w_rs, sob);
-      gemm_dma16(lw + 1024, p.w_off[1], w_rs, sob);
+    const uint32_t la = lds0 + (uint32_t)(buf * GEMM_BUFBYTES + wave * 4096);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      gemm_dma16(la + i * 1024, p.a_off[i], a_rs, kt * (GEMM_BK * 2));
+      gemm_dma16(la + i * 1024 + GEMM_OPBYTES, p.w_off[i], w_rs, kt * (GEMM_BK * 2));
     }
   };
-  // the tile's 256 bias values (1 KiB) by LDS-DMA as well: no ordinary load sits between the stream's counted waits.  Every wave
-  // issues the same piece (same bytes, same place), so each wave's own vmcnt covers the copy it reads and the counts stay uniform.
-  auto stage_bias = [&](const TileP &p, int bsel) { gemm_dma16(lds0 + GEMM_LDS_BIAS + bsel * 1024, (uint32_t)(lane * 16), b_rs, __builtin_amdgcn_readfirstlane(p.n0 * 4)); };
-
-  // The stream continues across tiles when the tile has >= 2 K-tiles and the epilogue leaves the registers for the next
-  // tile's offsets (EPI 3, the LayerNorm epilogue, does not: every tile then starts from an empty pipeline).
-  const bool can_stream = EPI != 3 && nk >= 2;
+  // Cross-tile prefetch: the first K-tile of the NEXT tile is put in flight (into buffer 0) right after the last K-tile
+  // of this one, so its DMA latency runs under the epilogue (bias / GELU / stores), which stages C through buffer 1 only.
+  // Needs the last K-tile in buffer 1, i.e. an even number of K-tiles (768 / 64, 3072 / 64).
+  const bool can_prefetch = (nk & 1) == 0;
   TileP cur;
+  float4 cur_bv;  // bias[n0 + 4 lane ..] of the tile (every wave loads it: no branch, no early wait; wave 0 publishes it)
   bool have = false;
-  uint32_t par = 0;  // byte offset of the buffer of the current K-tile (0 / GEMM_BUFBYTES), toggles per K-tile ACROSS tiles
-  int bsel = 0;      // bias slice of the current tile
   for (int ti = slot, step = 0; ti < chunk_len; ti += nslots, ++step) {
     if (!have) {
-      // empty pipeline: bias + half-tiles 0..5 of the stream (K-tile 0 complete, A0 / B0 of K-tile 1)
       tile_params(ti, step, cur);
-      stage_bias(cur, bsel);
-      stage_half(cur, H_A0, 0, par);
-      stage_half(cur, H_B0, 0, par);
-      stage_half(cur, H_B1, 0, par);
-      stage_half(cur, H_A1, 0, par);
-      if (nk >= 2) {
-        stage_half(cur, H_A0, 1, par ^ GEMM_BUFBYTES);
-        stage_half(cur, H_B0, 1, par ^ GEMM_BUFBYTES);
-        GEMM_WAIT_VM(6);  // A0, B0, B1 of K-tile 0 have landed
-      } else {
-        GEMM_WAIT_VM(2);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (EPI 3: the LayerNorm parameters written above)
-      __builtin_amdgcn_s_barrier();
+      cur_bv = *reinterpret_cast<const float4 *>(bias + cur.n0 + lane * 4);
+      stage_tile(cur, 0, 0);
     }
     const int m0 = __builtin_amdgcn_readfirstlane(cur.m0), n0 = __builtin_amdgcn_readfirstlane(cur.n0);
     cur.rot = __builtin_amdgcn_readfirstlane(cur.rot);
-    const bool more = can_stream && ti + nslots < chunk_len;
-    TileP nxt;
 
-    // the accumulators start at the bias (EPI 3 adds it in its LayerNorm epilogue): the bias slice landed with an earlier wait of
-    // the stream (it is the OLDEST load of a fresh pipeline; in a continuing stream it was issued 6 phases before this point)
-    const float *bias_lds = reinterpret_cast<const float *>(smem + GEMM_LDS_BIAS + bsel * 1024);
     f32x16 acc[2][4];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bv = EPI == 3 || GEMM_EABL == 3 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(bias_lds + wn * 64 + nb * 32 + 8 * g + 4 * hi);
+      for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-          acc[nb][mb][4 * g + 0] = bv.x;
-          acc[nb][mb][4 * g + 1] = bv.y;
-          acc[nb][mb][4 * g + 2] = bv.z;
-          acc[nb][mb][4 * g + 3] = bv.w;
-        }
-      }
+        for (int r = 0; r < 16; ++r) acc[nb][mb][r] = 0.f;
 
-    bf16x8 af[2][4], wf0[4], wf1[4];  // A half (2 row blocks x 4 k-substeps), B0, B1
-    auto read_a = [&](const char *lb, int ah) {
+    auto read_frags = [&](const char *lb, int ks, bf16x8(&wf)[2], bf16x8(&af)[4]) {
       if (!kFrag) return;
 #pragma unroll
-      for (int mbl = 0; mbl < 2; ++mbl)
+      for (int nb = 0; nb < 2; ++nb) wf[nb] = *reinterpret_cast<const bf16x8 *>(lb + w_base + nb * 4096 + fr_off[ks]);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) af[mbl][ks] = *reinterpret_cast<const bf16x8 *>(lb + a_base + ah * 8192 + mbl * 4096 + fr_off[ks]);
+      for (int mb = 0; mb < 4; ++mb) af[mb] = *reinterpret_cast<const bf16x8 *>(lb + a_base + mb * 4096 + fr_off[ks]);
     };
-    auto read_b = [&](const char *lb, int bh, bf16x8(&wf)[4]) {
-      if (!kFrag) return;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const bf16x8 *>(lb + w_base + bh * 4096 + fr_off[ks]);
-    };
-    // one quadrant: 2 row blocks (ah) x 1 column block (bh) x 4 k-substeps, the two accumulators alternating
-    auto mfma_q = [&](int ah, int bh, const bf16x8(&wf)[4]) {
+    auto mfma8 = [&](const bf16x8(&wf)[2], const bf16x8(&af)[4]) {
       if (!kMfma) {
-        asm volatile("" ::"v"(wf[0]), "v"(wf[1]), "v"(wf[2]), "v"(wf[3]), "v"(af[0][0]), "v"(af[0][1]), "v"(af[0][2]), "v"(af[0][3]), "v"(af[1][0]),
-                     "v"(af[1][1]), "v"(af[1][2]), "v"(af[1][3]));
+        asm volatile("" ::"v"(wf[0]), "v"(wf[1]), "v"(af[0]), "v"(af[1]), "v"(af[2]), "v"(af[3]));
         return;
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int mbl = 0; mbl < 2; ++mbl)
-          acc[bh][2 * ah + mbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], af[mbl][ks], acc[bh][2 * ah + mbl], 0, 0, 0);
+        for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], af[mb], acc[nb][mb], 0, 0, 0);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K-tile 0 (staged above or prefetched under the previous epilogue)
+    if (wave == 0) *reinterpret_cast<float4 *>(bias_lds + lane * 4) = cur_bv;  // read after the K loop's barriers
+    __syncthreads();
+    bf16x8 wf0[2], af0[4], wf1[2], af1[4];
+#if GEMM_PP
+    // ---- ping-pong K loop (GEMM_PP): the two wave groups of the workgroup (wm = 0: waves 0-3, wm = 1: waves 4-7 -- one wave of each
+    // per SIMD) run ONE BARRIER apart, so that while one group issues the 8 MFMAs of a k-substep (256 matrix-pipe cycles, s_setprio 1)
+    // the other issues its LDS fragment reads and its LDS-DMA pieces, and vice versa: a K-tile is 4 phases of
+    //     [6 ds_read_b128 (+ DMA pieces of K-tile kt + 1 in phases 0 / 1)]  barrier  [lgkmcnt(0), 8 MFMAs]  barrier
+    // Ordering rules (a reader may be one barrier ahead of an issuer): the wave's own DMA of K-tile kt + 1 is waited for (vmcnt 0)
+    // BEFORE the first barrier of phase 3 -- every wave of the other group has then passed that barrier before anybody reads the
+    // buffer in phase 0 of K-tile kt + 1; the fragment reads of phase 3 are retired (lgkmcnt 0) before that same barrier, so the
+    // DMA of K-tile kt + 2 -- issued after the NEXT barrier at the earliest -- cannot overtake a read of the buffer it overwrites.
+    auto phase_mfma = [&](const bf16x8(&wf)[2], const bf16x8(&af)[4], bool wait_reads) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      if (wait_reads) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+      mfma8(wf, af);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stage_part = [&](const TileP &p, int buf, int kt, int i0, int i1) {  // pieces i0 .. i1-1 (A and W) of the wave's 4 + 4
+      kt += p.rot;
+      if (kt >= nk) kt -= nk;
+      const uint32_t la = lds0 + (uint32_t)(buf * GEMM_BUFBYTES + wave * 4096);
+      for (int i = i0; i < i1; ++i) {
+        gemm_dma16(la + i * 1024, p.a_off[i], a_rs, kt * (GEMM_BK * 2));
+        gemm_dma16(la + i * 1024 + GEMM_OPBYTES, p.w_off[i], w_rs, kt * (GEMM_BK * 2));
+      }
     };
     if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
-    // ---- K loop: two phases per K-tile, 16 MFMAs each.  X(t) = (A0 x B0, A0 x B1) reads A0, B0, B1 of K-tile t and issues A1 of
-    // K-tile t + 1 (the first X of a tile also B1 of K-tile 1, which the epilogue before it kept out of its staging slot);
-    // Y(t) = (A1 x B1, A1 x B0) reads A1 and issues A0, B0, B1 of K-tile t + 2.  Each phase is
-    //     [reads | DMA pieces | vmcnt(8) | lgkmcnt(0)]  s_barrier  [16 MFMAs]  s_barrier
-    // A slot is refilled ONE phase after its last read, which is why the reads are retired BEFORE the phase's first barrier;
-    // a half-tile is read one phase after the wait that covers it.  Every wait leaves 4 half-tiles (8 loads) in flight; near the
-    // end of a tile the stream either continues with the NEXT tile's half-tiles (`more`) or ends, the waits counting down 2 / 0.
-    // One loop body (uniform scalar branches around DMA issue and waits only), so the 32 MFMAs accumulate in place.
-    auto phase = [&](auto compute) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      const char *lb = smem + buf * GEMM_BUFBYTES;
+      const bool more_k = kt + 1 < nk && kDma;
+      read_frags(lb, 0, wf0, af0);
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      if (more_k) stage_part(cur, buf ^ 1, kt + 1, 0, GEMM_PP == 2 ? 4 : 2);
+      phase_mfma(wf0, af0, true);
+      read_frags(lb, 1, wf1, af1);
       __builtin_amdgcn_sched_barrier(0);
-      if (GEMM_PRIO) __builtin_amdgcn_s_setprio(1);
-      compute();
-      if (GEMM_PRIO) __builtin_amdgcn_s_setprio(0);
+      if (more_k && GEMM_PP != 2) stage_part(cur, buf ^ 1, kt + 1, 2, 4);
+      phase_mfma(wf1, af1, true);
+      read_frags(lb, 2, wf0, af0);
+      phase_mfma(wf0, af0, true);
+      read_frags(lb, 3, wf1, af1);
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    for (int t = 0; t < nk; ++t) {
-      const bool last = t + 1 == nk, last2 = t + 2 >= nk;  // K-tile t + 1 / t + 2 belongs to the next tile (or to nobody)
-      if (more && t + 2 == nk) tile_params(ti + nslots, step + 1, nxt);
-      const char *lb = smem + par;
-      const uint32_t bnext = par ^ GEMM_BUFBYTES;  // buffer of K-tile t + 1; K-tile t + 2 goes where K-tile t is
-      // X
-      read_b(lb, 0, wf0);
-      read_b(lb, 1, wf1);
-      read_a(lb, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t == 0 && !last) stage_half(cur, H_B1, 1, bnext);
-      if (!last)
-        stage_half(cur, H_A1, t + 1, bnext);
-      else if (more)
-        stage_half(nxt, H_A1, 0, bnext);
-      if (last && !more)
-        GEMM_WAIT_VM(0);  // the stream ends: A1 of this K-tile is its last half-tile
-      else
-        GEMM_WAIT_VM(8);  // A1 of this K-tile has landed
-      phase([&] {
-        mfma_q(0, 0, wf0);
-        mfma_q(0, 1, wf1);
-      });
-      // Y
-      read_a(lb, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!last2) {
-        stage_half(cur, H_A0, t + 2, par);
-        stage_half(cur, H_B0, t + 2, par);
-        stage_half(cur, H_B1, t + 2, par);
-        GEMM_WAIT_VM(8);  // A0, B0, B1 of K-tile t + 1 have landed
-      } else if (more) {
-        if (!last) {
-          stage_bias(nxt, bsel ^ 1);
-          stage_half(nxt, H_A0, 0, par);
-          stage_half(nxt, H_B0, 0, par);
-          stage_half(nxt, H_B1, 0, par);
-          GEMM_WAIT_VM(8);
-        } else {
-          stage_half(nxt, H_A0, 1, par);
-          stage_half(nxt, H_B0, 1, par);
-          GEMM_WAIT_VM(6);  // A0, B0, B1 of the next tile's K-tile 0 (B1 of its K-tile 1 follows after the epilogue)
-        }
-      } else if (!last) {
-        GEMM_WAIT_VM(2);  // only A1 of the last K-tile is still in flight
-      }
-      phase([&] {
-        mfma_q(1, 1, wf1);
-        mfma_q(1, 0, wf0);
-      });
-      par ^= GEMM_BUFBYTES;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      phase_mfma(wf1, af1, false);
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();  // both groups have executed the same number of barriers again
-    par ^= GEMM_BUFBYTES;                       // back to the LAST K-tile's buffer: its A1 / B1 slots stage C (restored below)
+#else
+    read_frags(smem, 0, wf0, af0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      const char *lb = smem + buf * GEMM_BUFBYTES;
+      // (entry: the fragments of substep 0 of this K-tile are being read into set 0; set 1 holds substep 3 of the previous one)
+      if (kt > 0) mfma8(wf1, af1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk && kDma) stage_tile(cur, buf ^ 1, kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(lb, 1, wf1, af1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(wf0, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(lb, 2, wf0, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(wf1, af1);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(lb, 3, wf1, af1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(wf0, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      // every read of this K-tile has landed (the DMA of K-tile kt + 2 may overwrite it after the barrier), the wave's own
+      // pieces of K-tile kt + 1 have landed
+#if GEMM_STAMP
+      const bool st_on = blockIdx.x == 16 && step == 2;
+      unsigned long long tB = 0, tC = 0, tA = 0;
+      if (st_on) { tB = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (st_on) { tC = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      __builtin_amdgcn_s_barrier();
+      if (st_on) {
+        tA = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) { unsigned long long *sp = g_stamps + ((size_t)wave * 64 + kt) * 4; sp[0] = tB; sp[1] = tC; sp[2] = tA; }
+      }
+#else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) read_frags(smem + (buf ^ 1) * GEMM_BUFBYTES, 0, wf0, af0);
+    }
+
+#endif
+    // ---- next tile's first K-tile in flight under this tile's epilogue; then the pending MFMA group of the last K-tile
+    const bool more = EPI != 3 && can_prefetch && ti + nslots < chunk_len;  // (EPI 3: the LayerNorm epilogue needs the registers)
+    TileP nxt;
+    float4 nxt_bv;
+    if (more) {
+      tile_params(ti + nslots, step + 1, nxt);
+      nxt_bv = *reinterpret_cast<const float4 *>(bias + nxt.n0 + lane * 4);
+      stage_tile(nxt, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#if !GEMM_PP
+    mfma8(wf1, af1);
+#endif
     if (EPI == 3) {
       // v = acc + bias + residual; row statistics across the 4 column waves through LDS; normalise in place
 #pragma unroll
@@ -397,74 +367,75 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
       }
     }
     // ---- epilogue: acc[nb][mb][4g + e] = C[m = wm*128 + mb*32 + l31][n = wn*64 + nb*32 + 8g + 4hi + e]
-    //      four passes of 32 rows per wave through a 4-KiB slot of the last K-tile's buffer (16-byte slots XOR-swizzled by
-    //      row): waves 0-3 use the A1 half-tile slots, waves 4-7 the B1 slots -- the two the stream refills after the epilogue
-    char *cw = smem + par + (wave < 4 ? 8192 + (wave & 1) * 4096 + (wave >> 1) * 16384 : GEMM_OPBYTES + 4096 + (wave - 4) * 8192);
+    //      two passes of 64 rows per wave through buffer 1 (8 KiB per wave, 16-byte slots XOR-swizzled by row)
+    char *cw = smem + GEMM_BUFBYTES + wave * (64 * 128);
+    char *Cb = reinterpret_cast<char *>(C);
     if (GEMM_EABL == 2) {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) asm volatile("" ::"v"(acc[nb][mb]));
     }
-    // stores go through a buffer descriptor: rows past M (ragged last tile) fall outside it and are dropped -- no branches
-    const uint32_t c_v0 = GATHER ? (uint32_t)((((size_t)m0 + wm * 128 + (lane >> 3)) * GEMM_BN + wn * 64 + (lane & 7) * 8) * 2)
-                                 : (uint32_t)((((size_t)m0 + wm * 128 + (lane >> 3)) * LDC + n0 + wn * 64 + (lane & 7) * 8) * 2);
-    const uint32_t c_rowb = (uint32_t)((GATHER ? GEMM_BN : LDC) * 2);
 #pragma unroll
-    for (int mb = 0; mb < (GEMM_EABL == 2 ? 0 : 4); ++mb) {
+    for (int ps = 0; ps < (GEMM_EABL == 2 ? 0 : 2); ++ps) {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int nl = nb * 32 + 8 * g + 4 * hi;  // local column of the 4 values
-          float v0 = acc[nb][mb][4 * g + 0], v1 = acc[nb][mb][4 * g + 1], v2 = acc[nb][mb][4 * g + 2], v3 = acc[nb][mb][4 * g + 3];
-          if (EPI == 1 && GEMM_EABL != 3) {
-            v0 = gelu_bf16_class(v0);
-            v1 = gelu_bf16_class(v1);
-            v2 = gelu_bf16_class(v2);
-            v3 = gelu_bf16_class(v3);
+          const float4 bv = EPI == 3 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(bias_lds + wn * 64 + nl);
+#pragma unroll
+          for (int mh = 0; mh < 2; ++mh) {
+            const int mb = ps * 2 + mh;
+            float v0 = acc[nb][mb][4 * g + 0] + bv.x, v1 = acc[nb][mb][4 * g + 1] + bv.y;
+            float v2 = acc[nb][mb][4 * g + 2] + bv.z, v3 = acc[nb][mb][4 * g + 3] + bv.w;
+            if (EPI == 1) {
+              v0 = gelu_bf16_class(v0);
+              v1 = gelu_bf16_class(v1);
+              v2 = gelu_bf16_class(v2);
+              v3 = gelu_bf16_class(v3);
+            }
+            if (EPI == 2) {
+              v0 = fmaxf(v0, 0.f);
+              v1 = fmaxf(v1, 0.f);
+              v2 = fmaxf(v2, 0.f);
+              v3 = fmaxf(v3, 0.f);
+            }
+            const int row = mh * 32 + l31;
+            const int slot16 = (nl >> 3) ^ (row & 7);
+            *reinterpret_cast<uint2 *>(cw + row * 128 + slot16 * 16 + (nl & 4) * 2) = make_uint2(cvt_pk_bf16_f32(v0, v1), cvt_pk_bf16_f32(v2, v3));
           }
-          if (EPI == 2) {
-            v0 = fmaxf(v0, 0.f);
-            v1 = fmaxf(v1, 0.f);
-            v2 = fmaxf(v2, 0.f);
-            v3 = fmaxf(v3, 0.f);
-          }
-          const int slot16 = (nl >> 3) ^ (l31 & 7);
-          *reinterpret_cast<uint2 *>(cw + l31 * 128 + slot16 * 16 + (nl & 4) * 2) = make_uint2(cvt_pk_bf16_f32(v0, v1), cvt_pk_bf16_f32(v2, v3));
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      u32x4 cv[4];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
+      for (int it = 0; it < 8; ++it) {
         const int row = it * 8 + (lane >> 3), q = lane & 7;
-        cv[it] = *reinterpret_cast<const u32x4 *>(cw + row * 128 + ((q ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const uint32_t off = c_v0 + (uint32_t)(mb * 32 + it * 8) * c_rowb;
-        if (GEMM_EABL == 1)
-          asm volatile("" ::"v"(cv[it]));
-        else if (nt_store)
-          __builtin_amdgcn_raw_buffer_store_b128(cv[it], c_rs, off, 0, 2);  // aux 2 = nt
-        else
-          __builtin_amdgcn_raw_buffer_store_b128(cv[it], c_rs, off, 0, 0);
+        const uint4 v = *reinterpret_cast<const uint4 *>(cw + row * 128 + ((q ^ (row & 7)) << 4));
+        const int m = m0 + wm * 128 + ps * 64 + row;
+        const size_t off = GATHER ? ((size_t)m * GEMM_BN + wn * 64 + q * 8) * 2 : ((size_t)m * LDC + n0 + wn * 64 + q * 8) * 2;
+        if (GEMM_EABL == 1) {
+          asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+        } else if (GATHER || m < M) {
+          if (nt_store) {
+            const u32x4 vv = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(vv, reinterpret_cast<u32x4 *>(Cb + off));
+          } else {
+            *reinterpret_cast<uint4 *>(Cb + off) = v;
+          }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    par ^= GEMM_BUFBYTES;
-    // every wave has read its staged outputs: the next tile's first phases may refill the slots
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __syncthreads();  // every wave has read its staged outputs: the next tile's K loop may overwrite buffer 1
     have = more;
     if (more) {
       cur = nxt;
-      bsel ^= 1;
+      cur_bv = nxt_bv;
     }
   }  // tile loop
 }
@@ -486,7 +457,7 @@ int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C
   UNOPOSE_REQUIRE(A && W && bias && C, "linear_bf16: null pointer");
   UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && K >= GEMM_BK && K % GEMM_BK == 0,
                   "linear_bf16: needs N %% 256 == 0 and K %% 64 == 0 (got M=%ld N=%d K=%d)", M, N, K);
-  UNOPOSE_REQUIRE((size_t)M * K * 2 < (1UL << 32) && (size_t)N * K * 2 < (1UL << 32) && (size_t)M * N * 2 < (1UL << 32), "linear_bf16: operand larger than 4 GiB");
+  UNOPOSE_REQUIRE((size_t)M * K * 2 < (1UL << 32) && (size_t)N * K * 2 < (1UL << 32), "linear_bf16: operand larger than 4 GiB");
   UNOPOSE_REQUIRE(epilogue >= 0 && epilogue <= 2, "linear_bf16: epilogue must be 0 (bias), 1 (bias + GELU) or 2 (bias + ReLU)");
   const int tiles_m = cdiv(M, GEMM_BM), tiles_n = N / GEMM_BN, tiles = tiles_m * tiles_n;
   hipStream_t s = (hipStream_t)stream;
@@ -512,7 +483,7 @@ int unopose_linear_bf16_ld(const void *A, int lda, const void *W, int ldw, const
                   "linear_bf16_ld: needs N %% 256 == 0 and K %% 64 == 0 (got M=%ld N=%d K=%d)", M, N, K);
   UNOPOSE_REQUIRE(lda >= K && ldw >= K && ldc >= N && lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0,
                   "linear_bf16_ld: row strides must cover the rows and be multiples of 8 elements (lda=%d ldw=%d ldc=%d)", lda, ldw, ldc);
-  UNOPOSE_REQUIRE((size_t)M * lda * 2 < (1UL << 32) && (size_t)N * ldw * 2 < (1UL << 32) && (size_t)M * ldc * 2 < (1UL << 32), "linear_bf16_ld: operand larger than 4 GiB");
+  UNOPOSE_REQUIRE((size_t)M * lda * 2 < (1UL << 32) && (size_t)N * ldw * 2 < (1UL << 32), "linear_bf16_ld: operand larger than 4 GiB");
   UNOPOSE_REQUIRE(epilogue >= 0 && epilogue <= 2, "linear_bf16_ld: epilogue must be 0 (bias), 1 (bias + GELU) or 2 (bias + ReLU)");
   const int tiles_m = cdiv(M, GEMM_BM), tiles_n = N / GEMM_BN, tiles = tiles_m * tiles_n;
   hipStream_t s = (hipStream_t)stream;

@@ -13,16 +13,18 @@
 //     (rows of the MFMA result = output columns n): a lane then owns 4 consecutive n of one output row, which
 //     packs to 8-byte LDS writes in the epilogue;
 //   * ROUND 4 -- the K loop is a HALF-TILE STREAM with COUNTED waits (never vmcnt(0) inside the stream).  A K-tile is four
-//     16-KiB half-tiles in stream order  A0 (rows 0-63 of each wave row-block), B0 (columns 0-31 of each wave column-block),
-//     B1, A1;  the ring is 2 K-tiles x 4 half-tile slots = 128 KiB.  A K-tile is computed in two PHASES of two 64 x 32 output
-//     quadrants over the whole K-step each (16 MFMAs):  X = (A0 x B0, A0 x B1),  Y = (A1 x B1, A1 x B0),  and every phase is
-//         [fragment reads of the phase | LDS-DMA pieces (X: one half-tile, Y: three) | s_waitcnt vmcnt(8) | lgkmcnt(0)]
-//         s_barrier   [16 MFMAs]   s_barrier
-//     Four half-tiles (8 loads per wave) stay in flight ACROSS the barriers; a half-tile is read one phase after the wait
-//     that covers it and its slot is refilled one phase after its last read (reads retired before the barrier).
+//     16-KiB half-tiles in consumption order  A0 (rows 0-63 of each wave row-block), B0 (columns 0-31 of each wave
+//     column-block), B1, A1;  the ring is 2 K-tiles x 4 half-tile slots = 128 KiB.  A K-tile is computed in four PHASES, one
+//     64 x 32 quadrant of the wave's outputs over the whole K-step each (8 MFMAs):
+//         q0 = A0 x B0 (reads A0, B0 -> registers)   q1 = A0 x B1 (reads B1)   q2 = A1 x B1 (reads A1)   q3 = A1 x B0 (no reads)
+//     and every phase is
+//         [fragment reads of the phase | 2 LDS-DMA pieces = this wave's share of ONE half-tile | s_waitcnt vmcnt(8)]
+//         s_barrier   [lgkmcnt(0); s_setprio 1; 8 MFMAs; s_setprio 0]   s_barrier
+//     Phase P issues half-tile P + 6 of the stream and waits until half-tile P + 2 has landed (4 half-tiles = 8 loads per
+//     wave stay in flight ACROSS the barriers); the reads of phase P + 1 need exactly half-tiles <= P + 2, and the slot that
+//     half-tile P + 6 overwrites was last read in phase <= P - 2 (B0 stays in registers for q3, so no slot is read twice).
 //     The two wave groups (wm = 0 / 1: one wave of each per SIMD) run ONE BARRIER apart, so one group's MFMA segment sits
-//     beside the other group's read / DMA segment on every SIMD (ping-pong).  The guide's 4-phase form (8 MFMAs per phase, 8
-//     barriers per K-tile) was built first and measured 12-16 % slower on every shape: scripts/ubench/gemm_r04_variants.hip;
+//     beside the other group's read / DMA segment on every SIMD (the guide's 8-phase ping-pong);
 //   * the stream does not stop at a tile boundary: while the last two K-tiles of a tile are computed the first six
 //     half-tiles of the NEXT tile (and its bias slice, also by LDS-DMA) are issued, the epilogue stages C through the two slots
 //     of the ring the stream refills last (A1 / B1 of the last K-tile's buffer, 4 KiB per wave), and the next tile's
@@ -47,7 +49,19 @@ namespace unopose {
 #define GEMM_SAME 0  // probe: every tile streams the operands of tile (0, 0) -- an all-hit L2 stream under the full K loop
 #endif
 #ifndef GEMM_PRIO
-#define GEMM_PRIO 0  // 1 = s_setprio 1 around the MFMA segment (measured: -1..2 % with 16-MFMA segments; scripts/ubench/gemm_r04_variants.hip)
+#define GEMM_PRIO 1  // s_setprio 1 around the MFMA segment
+#endif
+#ifndef GEMM_PH
+#define GEMM_PH 2  // phases per K-tile: 4 = one quadrant (8 MFMAs) per phase; 2 = two quadrants (16 MFMAs) per phase, half the barriers
+#endif
+#ifndef GEMM_BAL
+#define GEMM_BAL 0  // PH 2 only: 1 = four DMA pieces in each phase (X: B1, A1 of K-tile t + 1; Y: A0, B0 of K-tile t + 2)
+#endif
+#ifndef GEMM_DMAFIRST
+#define GEMM_DMAFIRST 0  // PH 2 only: issue the phase's DMA pieces before its fragment reads
+#endif
+#ifndef GEMM_INFLIGHT
+#define GEMM_INFLIGHT 8  // loads left in flight by the steady-state wait (8 = the 4 half-tiles the schedule allows)
 #endif
 #define GEMM_BK 64
 constexpr bool kMfma = GEMM_ABL != 2, kFrag = GEMM_ABL != 3, kDma = GEMM_ABL != 1;
@@ -215,9 +229,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
       if (nk >= 2) {
         stage_half(cur, H_A0, 1, par ^ GEMM_BUFBYTES);
         stage_half(cur, H_B0, 1, par ^ GEMM_BUFBYTES);
-        GEMM_WAIT_VM(6);  // A0, B0, B1 of K-tile 0 have landed
+        if (GEMM_PH == 2)
+          GEMM_WAIT_VM(6);  // A0, B0, B1 of K-tile 0 have landed
+        else
+          GEMM_WAIT_VM(8);  // A0, B0 of K-tile 0 have landed
       } else {
-        GEMM_WAIT_VM(2);
+        if (GEMM_PH == 2)
+          GEMM_WAIT_VM(2);
+        else
+          GEMM_WAIT_VM(4);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (EPI 3: the LayerNorm parameters written above)
       __builtin_amdgcn_s_barrier();
@@ -271,16 +291,30 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
         for (int mbl = 0; mbl < 2; ++mbl)
           acc[bh][2 * ah + mbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], af[mbl][ks], acc[bh][2 * ah + mbl], 0, 0, 0);
     };
+    // ---- one K-tile = 4 phases; phase P issues half-tile P + 6 of the stream and leaves 8 loads in flight (half-tiles <= P + 2
+    // have landed: what phase P + 1 reads).  Near the end of a tile the stream either continues with the NEXT tile's half-tiles
+    // (`more`) or ends, and the waits count down 4 / 2 / 0.  One loop body (uniform scalar branches around the DMA issue and the
+    // waits only), so the 32 MFMAs accumulate in place.
+    [[maybe_unused]] auto phase_sync = [&](auto compute) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (GEMM_PRIO) __builtin_amdgcn_s_setprio(1);
+      compute();
+      if (GEMM_PRIO) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#if GEMM_PH == 2
     if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
-    // ---- K loop: two phases per K-tile, 16 MFMAs each.  X(t) = (A0 x B0, A0 x B1) reads A0, B0, B1 of K-tile t and issues A1 of
-    // K-tile t + 1 (the first X of a tile also B1 of K-tile 1, which the epilogue before it kept out of its staging slot);
-    // Y(t) = (A1 x B1, A1 x B0) reads A1 and issues A0, B0, B1 of K-tile t + 2.  Each phase is
-    //     [reads | DMA pieces | vmcnt(8) | lgkmcnt(0)]  s_barrier  [16 MFMAs]  s_barrier
-    // A slot is refilled ONE phase after its last read, which is why the reads are retired BEFORE the phase's first barrier;
-    // a half-tile is read one phase after the wait that covers it.  Every wait leaves 4 half-tiles (8 loads) in flight; near the
-    // end of a tile the stream either continues with the NEXT tile's half-tiles (`more`) or ends, the waits counting down 2 / 0.
-    // One loop body (uniform scalar branches around DMA issue and waits only), so the 32 MFMAs accumulate in place.
-    auto phase = [&](auto compute) {
+    // ---- two phases per K-tile: X = (A0 x B0, A0 x B1), Y = (A1 x B1, A1 x B0), 16 MFMAs each.  X(t) issues A1 of K-tile t + 1
+    // (the first X of a tile also B1 of K-tile 1, which the previous tile's epilogue kept out of its staging slot); Y(t) issues
+    // A0, B0, B1 of K-tile t + 2.  A slot is refilled ONE phase after its last read, so the reads are retired (lgkmcnt 0) BEFORE
+    // the phase's first barrier; every wait leaves 4 half-tiles (8 loads) in flight.
+    auto phase2 = [&](auto compute) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -299,52 +333,145 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
       const char *lb = smem + par;
       const uint32_t bnext = par ^ GEMM_BUFBYTES;  // buffer of K-tile t + 1; K-tile t + 2 goes where K-tile t is
       // X
-      read_b(lb, 0, wf0);
-      read_b(lb, 1, wf1);
-      read_a(lb, 0);
+      auto x_reads = [&] {
+        read_b(lb, 0, wf0);
+        read_b(lb, 1, wf1);
+        read_a(lb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      if (!GEMM_DMAFIRST) x_reads();
+      if ((GEMM_BAL == 1 || t == 0) && !last) stage_half(cur, H_B1, t + 1, bnext);
+      if (GEMM_BAL == 1 && last && more) stage_half(nxt, H_B1, 0, bnext);
+      if (GEMM_BAL != 2) {
+        if (!last)
+          stage_half(cur, H_A1, t + 1, bnext);
+        else if (more)
+          stage_half(nxt, H_A1, 0, bnext);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      if (t == 0 && !last) stage_half(cur, H_B1, 1, bnext);
-      if (!last)
-        stage_half(cur, H_A1, t + 1, bnext);
-      else if (more)
-        stage_half(nxt, H_A1, 0, bnext);
+      if (GEMM_DMAFIRST) x_reads();
       if (last && !more)
-        GEMM_WAIT_VM(0);  // the stream ends: A1 of this K-tile is its last half-tile
+        GEMM_WAIT_VM(0);
+      else if (GEMM_BAL == 2)
+        GEMM_WAIT_VM(6);
       else
-        GEMM_WAIT_VM(8);  // A1 of this K-tile has landed
-      phase([&] {
+        GEMM_WAIT_VM_(GEMM_INFLIGHT);
+      phase2([&] {
         mfma_q(0, 0, wf0);
         mfma_q(0, 1, wf1);
       });
       // Y
-      read_a(lb, 1);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!GEMM_DMAFIRST) {
+        read_a(lb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (GEMM_BAL == 2) {  // A1 of K-tile t + 1 leads the phase's burst
+        if (!last)
+          stage_half(cur, H_A1, t + 1, bnext);
+        else if (more)
+          stage_half(nxt, H_A1, 0, bnext);
+      }
       if (!last2) {
         stage_half(cur, H_A0, t + 2, par);
         stage_half(cur, H_B0, t + 2, par);
-        stage_half(cur, H_B1, t + 2, par);
-        GEMM_WAIT_VM(8);  // A0, B0, B1 of K-tile t + 1 have landed
+        if (GEMM_BAL != 1) stage_half(cur, H_B1, t + 2, par);
       } else if (more) {
         if (!last) {
           stage_bias(nxt, bsel ^ 1);
           stage_half(nxt, H_A0, 0, par);
           stage_half(nxt, H_B0, 0, par);
-          stage_half(nxt, H_B1, 0, par);
-          GEMM_WAIT_VM(8);
+          if (GEMM_BAL != 1) stage_half(nxt, H_B1, 0, par);
         } else {
           stage_half(nxt, H_A0, 1, par);
           stage_half(nxt, H_B0, 1, par);
-          GEMM_WAIT_VM(6);  // A0, B0, B1 of the next tile's K-tile 0 (B1 of its K-tile 1 follows after the epilogue)
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (GEMM_DMAFIRST) {
+        read_a(lb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!last2) {
+        if (GEMM_BAL == 1)
+          GEMM_WAIT_VM(6);
+        else
+          GEMM_WAIT_VM_(GEMM_INFLIGHT);
+      } else if (more) {
+        if (!last) {
+          if (GEMM_BAL == 1)
+            GEMM_WAIT_VM(6);
+          else
+            GEMM_WAIT_VM_(GEMM_INFLIGHT);
+        } else {
+          GEMM_WAIT_VM(6);  // (B1 of the next tile's K-tile 1 follows after the epilogue)
         }
       } else if (!last) {
-        GEMM_WAIT_VM(2);  // only A1 of the last K-tile is still in flight
+        GEMM_WAIT_VM(2);
       }
-      phase([&] {
+      phase2([&] {
         mfma_q(1, 1, wf1);
         mfma_q(1, 0, wf0);
       });
       par ^= GEMM_BUFBYTES;
     }
+#else
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+    for (int t = 0; t < nk; ++t) {
+      const bool last = t + 1 == nk, last2 = t + 2 >= nk;  // K-tile t + 1 / t + 2 belongs to the next tile (or to nobody)
+      const bool drain = last && !more;
+      if (more && t + 2 == nk) tile_params(ti + nslots, step + 1, nxt);
+      const char *lb = smem + par;
+      const uint32_t bnext = par ^ GEMM_BUFBYTES;  // buffer of K-tile t + 1; K-tile t + 2 goes where K-tile t is
+      // q0 = A0 x B0
+      read_b(lb, 0, wf0);
+      read_a(lb, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last)
+        stage_half(cur, H_B1, t + 1, bnext);
+      else if (more)
+        stage_half(nxt, H_B1, 0, bnext);
+      if (drain)
+        GEMM_WAIT_VM(2);
+      else
+        GEMM_WAIT_VM_(GEMM_INFLIGHT);
+      phase_sync([&] { mfma_q(0, 0, wf0); });
+      // q1 = A0 x B1
+      read_b(lb, 1, wf1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last)
+        stage_half(cur, H_A1, t + 1, bnext);
+      else if (more)
+        stage_half(nxt, H_A1, 0, bnext);
+      if (drain)
+        GEMM_WAIT_VM(0);
+      else
+        GEMM_WAIT_VM_(GEMM_INFLIGHT);
+      phase_sync([&] { mfma_q(0, 1, wf1); });
+      // q2 = A1 x B1
+      read_a(lb, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last2) {
+        stage_half(cur, H_A0, t + 2, par);
+      } else if (more) {
+        if (!last) stage_bias(nxt, bsel ^ 1);
+        stage_half(nxt, H_A0, last ? 1 : 0, par);
+      }
+      phase_sync([&] { mfma_q(1, 1, wf1); });
+      // q3 = A1 x B0 (B0 still in registers: its slot was free for restaging after q0)
+      if (!last2)
+        stage_half(cur, H_B0, t + 2, par);
+      else if (more)
+        stage_half(nxt, H_B0, last ? 1 : 0, par);
+      if (!drain) {
+        if (last2 && !more)
+          GEMM_WAIT_VM(4);
+        else
+          GEMM_WAIT_VM_(GEMM_INFLIGHT);
+      }
+      phase_sync([&] { mfma_q(1, 0, wf0); });
+      par ^= GEMM_BUFBYTES;
+    }
+#endif
     if (wm == 0) __builtin_amdgcn_s_barrier();  // both groups have executed the same number of barriers again
     par ^= GEMM_BUFBYTES;                       // back to the LAST K-tile's buffer: its A1 / B1 slots stage C (restored below)
     if (EPI == 3) {

@@ -60,7 +60,7 @@ __device__ __forceinline__ void gemm_dma16(uint32_t lds_byte, uint32_t vo, __amd
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
-               : "s"(lds_byte), "v"(vo), "s"(rs), "s"(so)
+               : "s"(__builtin_amdgcn_readfirstlane(lds_byte)), "v"(vo), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(so))
                : "memory");
 }
 
