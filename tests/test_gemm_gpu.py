@@ -10,7 +10,11 @@ pytestmark = pytest.mark.gpu
 
 @torch.no_grad()
 @pytest.mark.parametrize("M,K,N,gelu", [(1, 64, 256, False), (255, 128, 256, True), (256, 64, 512, False), (4173, 768, 768, True),
-                                        (8192, 3072, 768, False), (5000, 768, 2304, True), (64 * 261, 768, 3072, True)])
+                                        (8192, 3072, 768, False), (5000, 768, 2304, True), (64 * 261, 768, 3072, True),
+                                        # >= 256 tiles of 256 x 256: the persistent kernel (csrc/gemm.hip), below: 128 x 128 tiles (gemm_small.hip).
+                                        # One / two / three (odd) / many K-tiles, ragged last row panel, more tiles than CUs (stream continues)
+                                        (70000, 64, 256, False), (65536 + 37, 128, 256, True), (33000, 192, 512, False), (64 * 1374, 768, 768, False),
+                                        (40000, 3072, 768, True)])
 def test_linear_bf16_vs_fp32_reference(M, K, N, gelu):
     from unopose_amd import ops
 

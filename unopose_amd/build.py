@@ -31,7 +31,7 @@ FLAGS = [*os.environ.get("UNOPOSE_EXTRA_HIPCC_FLAGS", "").split(), "-O3", "-fno-
 # loop had 288 v_max for 112 logical maxima).  Not applied to the index-producing files (pointnet2, geom,
 # posehead), whose NaN behaviour follows the reference's fminf / fmaxf semantics.
 EXTRA_FLAGS = {f: ["-fno-honor-nans"] for f in
-               ("pe.hip", "embed.hip", "attn.hip", "attn_f32.hip", "vit_attn.hip", "linattn.hip", "fused.hip", "gemm.hip", "fineassign.hip")}
+               ("pe.hip", "embed.hip", "attn.hip", "attn_f32.hip", "vit_attn.hip", "linattn.hip", "fused.hip", "gemm.hip", "gemm_small.hip", "fineassign.hip")}
 
 
 def _hipcc():

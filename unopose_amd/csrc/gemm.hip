@@ -31,7 +31,7 @@
 //     tiles then touch different 128-byte columns of their panels at any instant;
 //   * epilogue on the fp32 accumulators: + bias, optional GELU / ReLU / residual + LayerNorm, bf16, staged through LDS
 //     (XOR-swizzled) and written as whole 128-byte row segments with NON-TEMPORAL stores when the output exceeds the L2s.
-#include <type_traits>
+#include <stdlib.h>
 
 #include "gemm_common.h"
 
@@ -477,45 +477,24 @@ using namespace unopose;
 // next launch reads them, and a round of tiles would otherwise push the operand panels out of L2.
 static inline int use_nt_store(long M, int N) { return (size_t)M * N * 2 > (32u << 20) ? 1 : 0; }
 
-extern "C" {
-
-int unopose_gemm_bf16_tile(void) { return GEMM_BM; }
-
-int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C, long M, int N, int K, int epilogue,
-                        unopose_stream_t stream) {
-  UNOPOSE_REQUIRE(A && W && bias && C, "linear_bf16: null pointer");
-  UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && K >= GEMM_BK && K % GEMM_BK == 0,
-                  "linear_bf16: needs N %% 256 == 0 and K %% 64 == 0 (got M=%ld N=%d K=%d)", M, N, K);
-  UNOPOSE_REQUIRE((size_t)M * K * 2 < (1UL << 32) && (size_t)N * K * 2 < (1UL << 32) && (size_t)M * N * 2 < (1UL << 32), "linear_bf16: operand larger than 4 GiB");
-  UNOPOSE_REQUIRE(epilogue >= 0 && epilogue <= 2, "linear_bf16: epilogue must be 0 (bias), 1 (bias + GELU) or 2 (bias + ReLU)");
-  const int tiles_m = cdiv(M, GEMM_BM), tiles_n = N / GEMM_BN, tiles = tiles_m * tiles_n;
-  hipStream_t s = (hipStream_t)stream;
-  const int n_cu = gemm_cu_count();
-  const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
-  const int nt = use_nt_store(M, N);
-  if (epilogue == 1)
-    hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
-                       K, tiles_n, tiles, nt);
-  else if (epilogue == 2)
-    hipLaunchKernelGGL(gemm_bf16_kernel<2>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
-                       K, tiles_n, tiles, nt);
-  else
-    hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N,
-                       K, tiles_n, tiles, nt);
-  return check_launch("linear_bf16");
+// Shape policy: when the 256 x 256 tiles cannot give every CU one (`UNOPOSE_GEMM_SMALL_TILES` overrides the limit for A/Bs:
+// scripts/gemm_policy_ab.sh), the GEMM runs on gemm_small.hip's 128 x 128 (64 x 256 with the LayerNorm epilogue) tiles.
+// (Measured and not kept: giving the 256-tile kernel only whole rounds of tiles and the last row panels to the small kernel --
+// fc2 at M = 87 936 is 1032 tiles on 256 CUs -- gains 0 - 3 % per shape, 0.07 ms per forward: the few tiles of a last round
+// already run faster than those of a full one.)
+static int small_tiles_limit() {
+  static const int v = [] {
+    const char *e = getenv("UNOPOSE_GEMM_SMALL_TILES");
+    return e && *e ? atoi(e) : -1;
+  }();
+  return v >= 0 ? v : gemm_cu_count();
 }
 
-int unopose_linear_bf16_ld(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, long M, int N, int K,
-                           int epilogue, unopose_stream_t stream) {
-  UNOPOSE_REQUIRE(A && W && bias && C, "linear_bf16_ld: null pointer");
-  UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && K >= GEMM_BK && K % GEMM_BK == 0,
-                  "linear_bf16_ld: needs N %% 256 == 0 and K %% 64 == 0 (got M=%ld N=%d K=%d)", M, N, K);
-  UNOPOSE_REQUIRE(lda >= K && ldw >= K && ldc >= N && lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0,
-                  "linear_bf16_ld: row strides must cover the rows and be multiples of 8 elements (lda=%d ldw=%d ldc=%d)", lda, ldw, ldc);
-  UNOPOSE_REQUIRE((size_t)M * lda * 2 < (1UL << 32) && (size_t)N * ldw * 2 < (1UL << 32) && (size_t)M * ldc * 2 < (1UL << 32), "linear_bf16_ld: operand larger than 4 GiB");
-  UNOPOSE_REQUIRE(epilogue >= 0 && epilogue <= 2, "linear_bf16_ld: epilogue must be 0 (bias), 1 (bias + GELU) or 2 (bias + ReLU)");
-  const int tiles_m = cdiv(M, GEMM_BM), tiles_n = N / GEMM_BN, tiles = tiles_m * tiles_n;
-  hipStream_t s = (hipStream_t)stream;
+static int linear_bf16_dispatch(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, long M, int N, int K,
+                                int epilogue, hipStream_t s, const char *what) {
+  const int tiles_n = N / GEMM_BN;
+  const int tiles = cdiv(M, GEMM_BM) * tiles_n;
+  if (tiles < small_tiles_limit()) return gemm_small_linear(A, W, bias, C, M, N, K, lda, ldw, ldc, epilogue, s);
   const int n_cu = gemm_cu_count();
   const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
   const int nt = use_nt_store(M, N);
@@ -530,7 +509,33 @@ int unopose_linear_bf16_ld(const void *A, int lda, const void *W, int ldw, const
   else
     UNOPOSE_LD_LAUNCH(0);
 #undef UNOPOSE_LD_LAUNCH
-  return check_launch("linear_bf16_ld");
+  return check_launch(what);
+}
+
+extern "C" {
+
+int unopose_gemm_bf16_tile(void) { return GEMM_BM; }
+
+int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C, long M, int N, int K, int epilogue,
+                        unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(A && W && bias && C, "linear_bf16: null pointer");
+  UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && K >= GEMM_BK && K % GEMM_BK == 0,
+                  "linear_bf16: needs N %% 256 == 0 and K %% 64 == 0 (got M=%ld N=%d K=%d)", M, N, K);
+  UNOPOSE_REQUIRE((size_t)M * K * 2 < (1UL << 32) && (size_t)N * K * 2 < (1UL << 32) && (size_t)M * N * 2 < (1UL << 32), "linear_bf16: operand larger than 4 GiB");
+  UNOPOSE_REQUIRE(epilogue >= 0 && epilogue <= 2, "linear_bf16: epilogue must be 0 (bias), 1 (bias + GELU) or 2 (bias + ReLU)");
+  return linear_bf16_dispatch(A, K, W, K, bias, C, N, M, N, K, epilogue, (hipStream_t)stream, "linear_bf16");
+}
+
+int unopose_linear_bf16_ld(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, long M, int N, int K,
+                           int epilogue, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(A && W && bias && C, "linear_bf16_ld: null pointer");
+  UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && K >= GEMM_BK && K % GEMM_BK == 0,
+                  "linear_bf16_ld: needs N %% 256 == 0 and K %% 64 == 0 (got M=%ld N=%d K=%d)", M, N, K);
+  UNOPOSE_REQUIRE(lda >= K && ldw >= K && ldc >= N && lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0,
+                  "linear_bf16_ld: row strides must cover the rows and be multiples of 8 elements (lda=%d ldw=%d ldc=%d)", lda, ldw, ldc);
+  UNOPOSE_REQUIRE((size_t)M * lda * 2 < (1UL << 32) && (size_t)N * ldw * 2 < (1UL << 32) && (size_t)M * ldc * 2 < (1UL << 32), "linear_bf16_ld: operand larger than 4 GiB");
+  UNOPOSE_REQUIRE(epilogue >= 0 && epilogue <= 2, "linear_bf16_ld: epilogue must be 0 (bias), 1 (bias + GELU) or 2 (bias + ReLU)");
+  return linear_bf16_dispatch(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, (hipStream_t)stream, "linear_bf16_ld");
 }
 
 int unopose_linear_add_layernorm_bf16(const void *A, const void *W, const float *bias, const void *resid, const float *ln_w,
@@ -539,6 +544,7 @@ int unopose_linear_add_layernorm_bf16(const void *A, const void *W, const float 
   UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && K >= GEMM_BK && K % GEMM_BK == 0, "linear_add_layernorm_bf16: needs K %% 64 == 0 (got M=%ld K=%d)", M, K);
   UNOPOSE_REQUIRE((size_t)M * K * 2 < (1UL << 32), "linear_add_layernorm_bf16: operand larger than 4 GiB");
   const int tiles = cdiv(M, GEMM_BM);
+  if (tiles < small_tiles_limit()) return gemm_small_linear_ln(A, W, bias, resid, ln_w, ln_b, eps, C, M, K, (hipStream_t)stream);
   const int n_cu = gemm_cu_count();
   const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
   hipLaunchKernelGGL((gemm_bf16_kernel<3, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, (const u16 *)A, (const u16 *)W, bias,
