@@ -234,7 +234,8 @@ def roofline_leg(model, batch, img):
     t = hip_event_time(lambda: _ext.group_points(xt, idx), 20, stream)
     row("group_points_lds_kernel(S=256)", "hbm", 4.0 * B * (N * 256 + 3 * N * 256 + 3 * N), 1e9, 8000.0, "GB/s", t)
     t = hip_event_time(lambda: _ext.ball_query(x, x, 0.2, 256), 20, stream)
-    row("ball_query_kernel(S=256)", "hbm", 4.0 * B * (3 * N + 3 * N + N * 256), 1e9, 8000.0, "GB/s", t)
+    rows.append(dict(kernel="ball_query_kernel(S=256)", bound="latency", us=t * 1e6, ns_per_centre=t * 1e9 / (B * N),
+                     note="one wave per centre scans the cloud's LDS tile (ballot + mbcnt compaction): LDS / latency-bound, not an HBM stream"))
     tem = batch["tem1_pts"].float().contiguous()
     t = hip_event_time(lambda: _ext.furthest_point_sampling(tem, 2048), 3, stream)
     rows.append(dict(kernel="fps_kernel(5000->2048)", bound="latency", us=t * 1e6, us_per_iteration=t * 1e6 / 2047))
@@ -242,7 +243,7 @@ def roofline_leg(model, batch, img):
 
 
 def _pmc_summary():
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd + "_pmc_summary.json")
         if os.path.exists(path):
             return json.load(open(path)), "profiles/%s_pmc_summary.json" % rnd
@@ -575,7 +576,7 @@ def main():
                    "sharding": f"dp{world} (independent pairs, weights broadcast, poses gathered)"},
         "launch": "hipGraph replay" if graphed is not None else "eager",
         "forwards_in_flight": args.inflight,
-        "pipeline": None if pipe is None or pipe.depth == 1 else ("ViT half of step i+1 beside the matcher half of step i (two streams)" if pipe.stages is True else "two whole forwards side by side (two streams)"),
+        "pipeline": None if pipe is None or pipe.depth == 1 else ("ViT half of step i+1 beside the matcher half of step i (two streams)" if pipe.last_mode == "stages" else "two whole forwards side by side (two streams)"),
         "sanity": {"median_rot_err_vs_gt": rot_err.median().item(),
                    "frac_pairs_solved(<0.05)": (rot_err < 0.05).float().mean().item()},
     }
@@ -606,18 +607,26 @@ def main():
         res["forward_latency_ms"] = {"median": q(lat, 0.5), "p10": q(lat, 0.1), "p90": q(lat, 0.9)}
     if rank == 0 and world == 1 and not args.dry_run:
         if amp and not args.no_fp32 and graphed is None:
-            # the reference's default precision (configs/main_cfg.py:87-89: test.amp.enabled=False)
-            k = max(3, min(args.steps, 5))
-            step(False)
+            # the reference's default precision (configs/main_cfg.py:87-89: test.amp.enabled=False): 3 warm-ups, 20 steps one at a
+            # time on the current stream, HIP events around every step (median / p10 / p90) beside the wall-clock rate
+            k = 20 if args.steps >= 20 else max(3, args.steps)
+            for _ in range(3):
+                step(False)
             sync()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
             t1 = time.perf_counter()
-            for _ in range(k):
+            for a, b in evs:
+                a.record()
                 o32 = step(False)
+                b.record()
             sync()
             d32 = time.perf_counter() - t1
             e32 = (o32()["pred_R"] - R_gt).abs().amax(dim=(1, 2))
+            per = sorted(a.elapsed_time(b) for a, b in evs)
+            q32 = lambda f: per[min(len(per) - 1, int(round(f * (len(per) - 1))))]  # noqa: E731
             log("fp32 leg done")
-            res["fp32"] = {"value": B * k / d32, "unit": "pairs/s", "ms_per_step": d32 / k * 1e3, "steps": k,
+            res["fp32"] = {"value": B * k / d32, "unit": "pairs/s", "ms_per_step": d32 / k * 1e3, "steps": k, "warmup": 3,
+                           "step_ms_hip_events": {"median": q32(0.5), "p10": q32(0.1), "p90": q32(0.9)},
                            "median_rot_err_vs_gt": e32.median().item()}
         if not args.no_roofline:
             res.update(roofline_leg(model, batch, args.img))

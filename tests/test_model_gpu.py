@@ -556,55 +556,98 @@ def test_unsupported_shapes_fall_back_to_gpu_composites(model):
     assert ops.pe_group_mlp_max(x, 0.3, 16, mlp).shape == (1, 100, 128)  # nsample not a multiple of 32
 
 
+def _forward_with_given_reference_subset(model, ep_cpu, rand, ref_idx, dense_po, radius, init_R, init_t):
+    """The HIP forward on `ep_cpu` with (a) the reference cloud's 5000 -> 2048 subset GIVEN (through the keys `encode_reference`
+    produces: the subset's points / radius as supplied, its pixel features and the full cloud's frame from the HIP path) and (b) the fine
+    stage started from the GIVEN coarse pose (`model.fixed_init`) -- so nothing downstream depends on an ulp-level tie of the FPS
+    (its input is divided by a radius that torch reduces in a different order on the GPU) or of the hypothesis ranking.
+    Returns (outputs, model taps, coarse taps, fine taps)."""
+    from unopose_amd import ops
+
+    ep = {k: v.cuda() for k, v in ep_cpu.items()}
+    net = model.feature_extraction.rgb_net
+    z, (H, W), off = net.upprojected_tokens(ep["tem1_rgb"])
+    sel = torch.gather(ep["tem1_choose"], 1, ref_idx.cuda().long())
+    ep2 = {k: ep[k] for k in ("pts", "rgb", "rgb_choose")}
+    ep2.update(coarse_rand=rand.cuda(), ref_dense_po=dense_po.cuda(), ref_radius=radius.cuda(),
+               ref_dense_fo=ops.bilinear_sample_native(z, sel, H, W, tok_offset=off), ref_lrf=ops.lrf_global(ep["tem1_pts"], model.use_ref_rad))
+    taps, ctaps, ftaps = {}, {}, {}
+    model.taps, model.coarse_point_matching.taps, model.fine_point_matching.taps = taps, ctaps, ftaps
+    model.fixed_init = (init_R.cuda(), init_t.cuda())
+    try:
+        out = model(ep2)
+    finally:
+        model.taps = model.coarse_point_matching.taps = model.fine_point_matching.taps = None
+        model.fixed_init = None
+    return out, taps, ctaps, ftaps
+
+
 @torch.no_grad()
 def test_untamed_weights_end_to_end_intermediates_vs_oracle(model, oracle_ext):
-    """the end-to-end fixtures use tamed weights (random weights make the POSE degenerate).
-    This test drives the whole forward with UNTAMED random weights and compares every stage's tensors -- not the pose -- with the
-    oracle run on the same inputs on the CPU: sampling indices bit-exact, ViT pixel features, sparse subsets, coarse-stage token
-    features / similarity / scores (no local frames involved: tight), fine-stage token features given the SAME initial pose (PE rests
-    on local frames, implementation-defined where ill-conditioned: the bulk of the tokens must agree)."""
+    """the end-to-end fixtures use tamed weights (random weights make the POSE degenerate,
+    SURVEY.md 8(c)).  This test drives the whole forward with UNTAMED random weights and compares every stage's tensors -- not the
+    pose -- with the oracle run on the same inputs on the CPU: sampling indices bit-exact, ViT pixel features, coarse-stage token
+    features / similarity / scores, and ALWAYS the fine stage: it is started from the oracle's coarse pose, and the reference cloud's
+    FPS subset is the oracle's (`_forward_with_given_reference_subset`), so no seed search, no skip, no conditional branch."""
     from oracle import unopose_ref as R
+    from unopose_amd import ops
     from unopose_amd.synthetic import make_batch
 
     cfg = R.default_cfg()
     sd = R.random_state_dict(cfg, seed=0)  # untamed: the weights of the `model` fixture
     rand = torch.rand(1, 18000, generator=torch.Generator().manual_seed(4))
-    # The 5000 -> 2048 FPS runs on points divided by a radius that torch reduces in a different order on the GPU and on the CPU: an
-    # ulp there can flip a near-tie of the FPS.  That is outside what this test compares, so the first seed whose FPS subset agrees is
-    # used (the FPS itself is pinned bit for bit on identical inputs in test_pointnet2_gpu.py / the golden forwards).
-    for seed in range(321, 331):
-        ep_cpu, _, _ = make_batch(1, 2048, 5000, 224, seed=seed)
-        ep = {k: v.cuda() for k, v in ep_cpu.items()}
-        ep["coarse_rand"] = rand.cuda()
-        taps, ctaps, ftaps = {}, {}, {}
-        model.taps, model.coarse_point_matching.taps, model.fine_point_matching.taps = taps, ctaps, ftaps
-        try:
-            out = model(ep)
-        finally:
-            model.taps = model.coarse_point_matching.taps = model.fine_point_matching.taps = None
-        tem = ep_cpu["tem1_pts"]
-        tem_n = tem / (torch.norm(tem - tem.mean(1, keepdim=True), dim=2).max(1)[0].reshape(-1, 1, 1) + 1e-6)
-        idx = oracle_ext.furthest_point_sampling(tem_n.contiguous(), 2048).long()
-        if torch.equal(torch.gather(tem_n, 1, idx.unsqueeze(2).expand(-1, -1, 3)), taps["dense_po"].cpu()):
-            break
-    else:
-        pytest.skip("no seed with an ulp-stable FPS subset among ten")
+    ep_cpu, _, _ = make_batch(1, 2048, 5000, 224, seed=321)
     ref = R.unopose_forward({k: v.clone() for k, v in ep_cpu.items()}, sd, cfg, rand, oracle_ext, detail=True)
     c_ref = R.coarse_point_matching(ref["sparse_pm"], ref["sparse_fm"], ref["geo_m"], ref["sparse_po"], ref["sparse_fo"], ref["geo_o"], sd,
                                     "coarse_point_matching", cfg.coarse_point_matching, rand, detail=True)[-1]
     f_ref = R.fine_point_matching(ref["dense_pm"], ref["dense_fm"], ref["geo_m"], ref["fps_idx_m"], ref["dense_po"], ref["dense_fo"], ref["geo_o"],
                                   ref["fps_idx_o"], ref["init_R"], ref["init_t"], sd, "fine_point_matching", cfg.fine_point_matching, oracle_ext,
                                   detail=True)[-1]
+    tem = ep_cpu["tem1_pts"]
+    radius = torch.norm(tem - tem.mean(1, keepdim=True), dim=2).max(1)[0]
+    tem_n = (tem / (radius.reshape(-1, 1, 1) + 1e-6)).contiguous()
+    idx = oracle_ext.furthest_point_sampling(tem_n, 2048)
+    assert torch.equal(torch.gather(tem_n, 1, idx.long().unsqueeze(2).expand(-1, -1, 3)), ref["dense_po"])
+    # the HIP FPS on the SAME normalised points (identical bits): 5000 -> 2048 bit for bit
+    assert torch.equal(ops.furthest_point_sample(tem_n.cuda(), 2048).cpu().long(), idx.long())
+    out, taps, ctaps, ftaps = _forward_with_given_reference_subset(model, ep_cpu, rand, idx, ref["dense_po"], radius, ref["init_R"], ref["init_t"])
     rel = lambda a, b: float((a.float().cpu() - b.float()).abs().max() / b.float().abs().max())  # noqa: E731
     assert torch.equal(taps["fps_idx_m"].cpu().long(), ref["fps_idx_m"].long()) and torch.equal(taps["fps_idx_o"].cpu().long(), ref["fps_idx_o"].long())
     assert rel(taps["dense_pm"], ref["dense_pm"]) < 1e-6 and rel(taps["dense_po"], ref["dense_po"]) < 1e-6
     assert rel(taps["dense_fm"], ref["dense_fm"]) < 2e-4 and rel(taps["dense_fo"], ref["dense_fo"]) < 2e-4  # 12 untamed ViT blocks, fp32-class GEMMs
     for k in ("f1", "f2", "atten", "score"):
         assert rel(ctaps[k], c_ref[k]) < 2e-3, (k, rel(ctaps[k], c_ref[k]))  # three geometric transformer blocks on 197 tokens
-    # fine stage: same initial pose required -- the HIP coarse pose equals the oracle's when the hypothesis ranking does (untamed
-    # weights give near-ties); compare the fine stage only in that case, and always require finite outputs of the right shape
+    # the model's own coarse pose (untamed weights give near-ties in the hypothesis ranking, so it is reported, not compared)
+    print("own coarse pose vs oracle: R %.2e t %.2e" % (float((taps["own_init_R"].cpu() - ref["init_R"]).abs().max()),
+                                                         float((taps["own_init_t"].cpu() - ref["init_t"]).abs().max())))
+    # fine stage, unconditionally: PE rests on local frames, implementation-defined where ill-conditioned -- the bulk of the tokens agree
     assert torch.isfinite(out["pred_R"]).all() and out["pred_R"].shape == (1, 3, 3)
-    if float((out["init_R"].cpu() - ref["init_R"]).abs().max()) < 1e-4 and float((out["init_t"].cpu() - ref["init_t"]).abs().max()) < 1e-4:
-        for k in ("f1", "f2"):
-            d = (ftaps[k].float().cpu() - f_ref[k]).abs().amax(dim=2) / f_ref[k].abs().max()
-            assert float((d < 2e-3).float().mean()) > 0.9, (k, float((d < 2e-3).float().mean()))
+    for k in ("f1", "f2"):
+        d = (ftaps[k].float().cpu() - f_ref[k]).abs().amax(dim=2) / f_ref[k].abs().max()
+        assert float((d < 2e-3).float().mean()) > 0.9, (k, float((d < 2e-3).float().mean()))
+
+
+@torch.no_grad()
+def test_untamed_weights_forward_vs_reference_fixture(model):
+    """The same stage-by-stage comparison against the REFERENCE's own forward with untamed weights (fixture written by
+    tests/golden/make_forward_untamed_golden.py from the imported reference: forward hooks on its `out_proj` modules and feature
+    extractor): the reference's FPS subset and coarse pose are fed in, every stage is asserted."""
+    z = load("forward_untamed")
+    ep_cpu = {k: z[k].cpu() for k in ("pts", "tem1_pts", "rgb", "tem1_rgb", "rgb_choose", "tem1_choose")}
+    t = lambda k: (z[k].cpu() if torch.is_tensor(z[k]) else torch.from_numpy(np.asarray(z[k])))  # noqa: E731
+    out, taps, ctaps, ftaps = _forward_with_given_reference_subset(model, ep_cpu, t("rand"), t("ref_fps_idx"), t("dense_po"), t("radius"),
+                                                                    t("init_R"), t("init_t"))
+    assert torch.equal(taps["fps_idx_m"].cpu().long(), t("fps_idx_m").long()) and torch.equal(taps["fps_idx_o"].cpu().long(), t("fps_idx_o").long())
+    rows_d, rows_c, rows_f = t("rows_d").long(), t("rows_c").long(), t("rows_f").long()
+    relm = lambda a, b, m: float((a.float().cpu() - b.float()).abs().max() / float(m))  # noqa: E731
+    assert relm(taps["dense_fm"][:, rows_d], t("dense_fm_rows"), t("dense_fm_absmax")) < 2e-4
+    assert relm(taps["dense_fo"][:, rows_d], t("dense_fo_rows"), t("dense_fo_absmax")) < 2e-4
+    assert relm(ctaps["f1"][:, rows_c], t("coarse_f1_rows"), t("coarse_f1_absmax")) < 2e-3
+    assert relm(ctaps["f2"][:, rows_c], t("coarse_f2_rows"), t("coarse_f2_absmax")) < 2e-3
+    # fine stage (three sparse-to-dense blocks behind the PE, untamed weights, fp32-class = bf16 x 3 arithmetic against the reference's
+    # fp32): measured 1.3e-3 .. 2.3e-3 of the tensor's magnitude on EVERY token of this pair (a level, not outliers), so the bound is
+    # 5e-3 for at least 90 % of the tokens and a median below 3e-3; tokens resting on ill-conditioned local frames may reach 5e-2
+    for k, m in (("f1", "fine_f1"), ("f2", "fine_f2")):
+        d = (ftaps[k][:, rows_f].float().cpu() - t(m + "_rows")).abs().amax(dim=2) / float(t(m + "_absmax"))
+        assert float((d < 5e-3).float().mean()) > 0.9 and float(d.median()) < 3e-3 and float(d.max()) < 5e-2, (k, float(d.median()), float(d.max()))
+    assert torch.isfinite(out["pred_R"]).all()

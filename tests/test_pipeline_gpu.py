@@ -228,6 +228,7 @@ def test_stage_mode_at_bench_size_equals_one_at_a_time():
     pf.close()
 
 
+@torch.no_grad()  # like every eval entry point (runner, cli, bench, pipeline): with autograd recording, the fp32 fast paths step aside (ops._no_autograd)
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_no_library_gemm_on_the_eval_path(model, precision):
     """Regression guard for DESIGN.md section 7 (the library's stream-K bf16 GEMMs hang when forwards overlap; its fp32 SGEMM runs

@@ -25,8 +25,9 @@ ARCH = "gfx950"
 # Packed fp32 brings no throughput on gfx950, so the
 # flags cost nothing (898 vs 892 pairs/s, inside the run-to-run spread).  tests/test_abi.py compiles every source to ISA with
 # these flags and fails if a packed-fp32 instruction is left.
-FLAGS = [*os.environ.get("UNOPOSE_EXTRA_HIPCC_FLAGS", "").split(), "-O3", "-fno-slp-vectorize", "-fno-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# UNOPOSE_EXTRA_HIPCC_FLAGS come LAST (the last -O wins) and are part of the staleness key below: a changed value rebuilds everything.
+FLAGS = ["-O3", "-fno-slp-vectorize", "-fno-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", *os.environ.get("UNOPOSE_EXTRA_HIPCC_FLAGS", "").split()]
 # Dense-math kernels: `nnan` lets fmaxf lower to ONE v_max_f32 instead of canonicalise + max (the PE tile
 # loop had 288 v_max for 112 logical maxima).  Not applied to the index-producing files (pointnet2, geom,
 # posehead), whose NaN behaviour follows the reference's fminf / fmaxf semantics.
@@ -56,6 +57,11 @@ def build(force=False, verbose=False):
     hdrs.append(os.path.join(HERE, "..", "include", "unopose_hip.h"))
     jobs = []
     objs = []
+    # objects are only as fresh as the flags they were built with: the flag set is recorded beside them
+    key = " ".join(FLAGS) + " | " + repr(sorted(EXTRA_FLAGS.items()))
+    key_file = os.path.join(OBJ, "flags.txt")
+    if not os.path.exists(key_file) or open(key_file).read() != key:
+        force = True
     for f in srcs:
         src = os.path.join(CSRC, f)
         obj = os.path.join(OBJ, f[:-4] + ".o")
@@ -77,6 +83,8 @@ def build(force=False, verbose=False):
             os.remove(os.path.join(OBJ, f))
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
+    with open(key_file, "w") as fh:
+        fh.write(key)
     if jobs or not os.path.exists(SO):
         run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", SO, *objs])
     return SO

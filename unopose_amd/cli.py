@@ -13,6 +13,10 @@
   the sibling ``.json`` (runner.inference_and_save).
 * ``--num-gpus N`` > 1 starts N ranks (one per GPU, RCCL) before this process touches a GPU; images are sharded by the
   InferenceSampler rule and rows gathered to rank 0.
+* two deliberate differences from ``engine.do_save_results``: (1) ``test.amp.enabled=True`` selects **bf16** autocast here (the reference's
+  ``torch.cuda.amp.autocast`` is fp16; bf16 is what the MI355X kernels are built and parity-tested for), ``False`` = fp32 as in the
+  reference; (2) the reference goes on to call the BOP evaluation (``bop_eval_utils``) after saving -- this entry stops at the CSV
+  unless ``--eval`` is given, which scores it with ``unopose_amd.bop_eval`` (VSD + MSSD + MSPD -> AR, HIP depth renderer).
 * extras beyond the reference's line: ``--pipeline`` (two forwards in flight), ``--ref-cache`` (reference views encoded once),
   ``--print-plan`` (resolve config and paths, touch no GPU: used by the CPU tests)."""
 import argparse
@@ -75,19 +79,37 @@ def result_paths(cfg, iteration=None):
     return out_dir, osp.join(out_dir, name)
 
 
-def _launch_ranks(n, argv):
-    """N fresh interpreters with the torchrun environment contract; the parent has not initialised HIP."""
+def _launch_ranks(n, argv, poll_s=0.2):
+    """N fresh interpreters with the torchrun environment contract; the parent has not initialised HIP.  All children are polled:
+    when any one exits non-zero the others are terminated and that code is returned (as torchrun does) -- a rank that dies must not
+    leave the rest blocked in a collective until the watchdog fires."""
     import socket
+    import time
 
-    with socket.socket() as s:
+    with socket.socket() as s:  # a free port (bind-and-close: the window before rank 0 re-binds it is small; MASTER_PORT overrides)
         s.bind(("127.0.0.1", 0))
-        port = str(s.getsockname()[1])
+        port = os.environ.get("MASTER_PORT") or str(s.getsockname()[1])
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, "-m", "unopose_amd.cli"] + argv, env=env))
-    return max(abs(p.wait()) for p in procs)
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            return abs(bad[0])
+        if all(c == 0 for c in codes):
+            return 0
+        time.sleep(poll_s)
 
 
 def load_checkpoint(model, path):
@@ -103,7 +125,9 @@ def load_checkpoint(model, path):
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(prog="python -m unopose_amd.cli", description=__doc__.split("\n\n")[0])
+    ap = argparse.ArgumentParser(prog="python -m unopose_amd.cli", description=__doc__.split("\n\n")[0],
+                                 epilog="Differences from engine.do_save_results: test.amp.enabled=True means bf16 autocast (reference: fp16); "
+                                        "the BOP evaluation is not started after saving (see unopose_amd.bop_eval).")
     ap.add_argument("--config-file", required=True)
     ap.add_argument("--num-gpus", type=int, default=1)
     ap.add_argument("--eval-only", action="store_true", help="accepted for compatibility with main_unopose.py")
@@ -137,10 +161,19 @@ def main(argv=None):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        import datetime
+
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=10))
     torch.set_grad_enabled(False)
     model_cfg = cfg["model"].get("cfg", cfg["model"]) if isinstance(cfg.get("model"), dict) else cfg["model"]
-    model = load_checkpoint(UNOPose(model_cfg), c.misc.load_from).to(dev).eval()
+    model = UNOPose(model_cfg)
+    if world == 1 or int(os.environ.get("RANK", "0")) == 0:
+        load_checkpoint(model, c.misc.load_from)
+    model = model.to(dev).eval()
+    if world > 1:  # rank 0 read the checkpoint; the weights travel once over RCCL / xGMI (north_star: "RCCL broadcast of DINOv2 weights")
+        from .runner import broadcast_module_
+
+        broadcast_module_(model, src=0)
     dcfg = dict(cfg["dataloader"]["test"]["dataset"])
     name, det_path = dcfg.pop("eval_dataset_name"), dcfg.pop("detetion_path", None)
     dataset = BOPTestsetOneRef(dcfg.get("cfg", dcfg), name, det_path)

@@ -3,6 +3,8 @@
 // the same LDS image of an operand stage ([256 rows][128 B], 16-byte chunks XOR-swizzled by row on the SOURCE address of
 // the LDS-DMA) and the same persistent, lock-stepped tile walk.
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace unopose {
@@ -79,6 +81,8 @@ inline int gemm_cu_count() {
     int cu = 0;
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8) cu = 256;
     n_cu[dev] = cu & ~7;
+    const char *e = getenv("UNOPOSE_GEMM_CUS");  // probe: persistent grid capped below the CU count (leaves CUs to another stream)
+    if (e && *e && atoi(e) >= 8) n_cu[dev] = min(n_cu[dev], atoi(e) & ~7);
   }
   return n_cu[dev];
 }

@@ -392,12 +392,14 @@ int unopose_query_lrf_group(const float *xyz, int B, int N, float radius, int ns
   if (B == 0) return UNOPOSE_OK;
   size_t lds = ((size_t)3 * N + 4 * (size_t)nsample) * 4;
   UNOPOSE_REQUIRE(lds <= 64 * 1024, "query_lrf_group: N=%d nsample=%d exceed the 64 KiB LDS tile", N, nsample);
-  static const long lds_probe = getenv("UNOPOSE_QLG_LDS_PROBE") ? atol(getenv("UNOPOSE_QLG_LDS_PROBE")) : 0;  // co-residency probe
+#ifdef UNOPOSE_QLG_LDS_PROBE_BUILD  // co-residency probe: compiled only into probe builds (scripts/build_variant.py -D...)
+  static const long lds_probe = getenv("UNOPOSE_QLG_LDS_PROBE") ? atol(getenv("UNOPOSE_QLG_LDS_PROBE")) : 0;
   if (lds_probe > (long)lds) {
     static bool opt[64];
     if (lds_optin(opt, (const void *)query_lrf_group_kernel, (size_t)lds_probe, "query_lrf_group") != UNOPOSE_OK) return UNOPOSE_ELAUNCH;
     lds = (size_t)lds_probe;
   }
+#endif
   const long centres = (long)B * N;
   int cpw = centres >= 65536 ? 8 : centres >= 16384 ? 4 : centres >= 4096 ? 2 : 1;
   dim3 grid(cdiv(N, 4 * cpw), B);

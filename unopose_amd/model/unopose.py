@@ -233,6 +233,7 @@ class UNOPose(nn.Module):
         self.coarse_point_matching = CoarsePointMatchingOneRef(cfg.coarse_point_matching)
         self.fine_point_matching = FinePointMatchingOneRef(cfg.fine_point_matching)
         self.taps = None  # assign a dict to receive the sampling intermediates of the next forward (tests)
+        self.fixed_init = None  # assign (init_R, init_t) to start the fine stage of the next forwards from that coarse pose (tests)
         # side-stream overlaps INSIDE one forward (geometry under the ViT, reference-cloud PE under the coarse stage): +3 % when
         # forwards run one at a time; pipeline.PipelinedForward switches them off (another forward fills those gaps better)
         self.internal_overlap = True
@@ -482,6 +483,10 @@ class UNOPose(nn.Module):
                                                 end_points)
         if pe2 is not None:
             torch.cuda.current_stream().wait_stream(self._side_stream(dense_po.device))
+        if self.fixed_init is not None:  # test hook: the fine stage starts from a GIVEN coarse pose (the model's own one goes to `taps`)
+            if self.taps is not None:
+                self.taps.update(own_init_R=end_points["init_R"], own_init_t=end_points["init_t"])
+            end_points["init_R"], end_points["init_t"] = self.fixed_init
         if self.test_coarse_only:
             end_points["pred_R"] = end_points["init_R"]
             end_points["pred_t"] = end_points["init_t"] * (radius.reshape(-1, 1) + 1e-6)

@@ -94,12 +94,28 @@ import torch.nn.functional as F
 from .pointnet2 import _ext
 
 
-# Own bf16 GEMM (csrc/gemm.hip) for the large linears; UNOPOSE_GEMM=0 routes everything to the library (A/B switch).
-USE_HIP_GEMM = os.environ.get("UNOPOSE_GEMM", "1") == "1"
+# Module switches below are plain attributes (no environment routes in the product module): same-box A/B scripts under scripts/ set
+# them on the imported module (e.g. `ops.USE_HIP_GEMM = False` sends the linears to the library).
+# Own bf16 GEMM (csrc/gemm.hip + gemm_small.hip) for the linears.
+USE_HIP_GEMM = True
 # every ViT-sized linear on csrc/gemm.hip (no library stream-K kernels, i.e. no kernel with inter-workgroup waits, on the path)
 # (measured 0.6 % behind the library at one forward in flight; it is what makes two forwards in flight safe: pipeline.py)
-HIP_GEMM_ALL = os.environ.get("UNOPOSE_GEMM_ALL", "1") == "1"
+HIP_GEMM_ALL = True
 HIP_GEMM_MIN_ROWS = 4096  # below this a 256 x 256 tile grid cannot fill 256 CUs: library GEMM
+
+
+_fallbacks_seen = set()
+
+
+def note_fallback(site, why):
+    """A shape / configuration the hand-written kernels do not take runs the torch composite instead -- still on the GPU, never
+    silently: one RuntimeWarning per (site, reason) names it."""
+    key = (site, why)
+    if key not in _fallbacks_seen:
+        _fallbacks_seen.add(key)
+        import warnings
+
+        warnings.warn(f"unopose_amd.ops.{site}: {why} -> torch composite (not a hand-written kernel)", RuntimeWarning, stacklevel=3)
 
 
 def linear_backend():
@@ -182,8 +198,8 @@ def bf16_linear_2d(x2, w, bias_f32, bias_bf16=None, relu=False):
 
 
 # fp32 linears (the reference's default precision) on csrc/gemm_f32.hip: hi / lo-split bf16 operands, 3 MFMAs per product
-# (fp32-class accuracy); UNOPOSE_F32X3=0 routes them back to the library SGEMM (A/B switch).
-USE_F32X3 = os.environ.get("UNOPOSE_F32X3", "1") == "1"
+# (fp32-class accuracy); `ops.USE_F32X3 = False` routes them back to the library SGEMM (A/B attribute).
+USE_F32X3 = True
 
 
 def f32x3_ok(rows, N, K):
@@ -248,7 +264,7 @@ def linear_f32_raw(x, w, b, owner, tag):
 
 
 # ---- two-way InfoNCE loss of the matchers (loss_utils.py:181-187) on the streaming softmax statistics ---------------------------
-USE_FUSED_INFONCE = os.environ.get("UNOPOSE_FUSED_INFONCE", "1") == "1"  # A/B switch: 0 = two F.cross_entropy calls
+USE_FUSED_INFONCE = True  # A/B attribute: False = two F.cross_entropy calls
 
 
 class _InfoNCEFn(torch.autograd.Function):
@@ -295,11 +311,11 @@ def infonce_two_way(atten, label1, label2):
 
 
 # ---- trainable linears: forward and input gradient on the hand-written GEMMs, recorded by autograd ------
-TRAIN_OWN_GEMM = os.environ.get("UNOPOSE_TRAIN_OWN_GEMM", "1") == "1"  # A/B switch: 0 = nn.Linear through the library
+TRAIN_OWN_GEMM = True  # A/B attribute: False = nn.Linear through the library
 # The persistent 256 x 256-tile kernels pay off from a few tens of GFLOP per launch (measured at the training shapes: a
 # 32 776 x 256 x 256 linear takes 38 us on csrc/gemm_f32.hip and 17 us on the library, the 4096 x 3072 x 4096 up-projection
 # 0.31 vs 0.86 ms): below this many flops the training step keeps nn.Linear.
-TRAIN_OWN_GEMM_MIN_FLOP = float(os.environ.get("UNOPOSE_TRAIN_OWN_GEMM_MIN_FLOP", "2e10"))
+TRAIN_OWN_GEMM_MIN_FLOP = 2e10
 
 
 def _transposed_weights(lin, kind):
@@ -397,8 +413,16 @@ def _lin(x, lin):
     return linear_train(x, lin) if (_DIFF and torch.is_grad_enabled()) else lin(x)
 
 
+def _no_autograd():
+    """The hand-written fp32 fast paths return tensors WITHOUT a grad_fn: they are taken only where autograd is not recording
+    (no_grad / inference mode -- every eval entry point of this package).  With gradients enabled the call falls through to the
+    torch composite (or to `linear_train` in differentiable mode), so eval-mode gradient use (pose refinement, saliency) stays
+    correct instead of silently losing its graph."""
+    return not torch.is_grad_enabled()
+
+
 def _f32_path(x):
-    return x.is_cuda and x.dtype == torch.float32 and not _DIFF and not torch.is_autocast_enabled()
+    return x.is_cuda and x.dtype == torch.float32 and not _DIFF and not torch.is_autocast_enabled() and _no_autograd()
 
 
 def mlp(x, fc1, fc2):
@@ -446,6 +470,7 @@ def linear(x, lin, relu=False, gelu=False):
             raise RuntimeError(f"ops.linear: a {rows} x {K} -> {N} bf16 linear does not fit csrc/gemm.hip (N % 256, K % 64) and would go to "
                                "a library GEMM while several forwards are in flight (PipelinedForward, depth > 1): library stream-K "
                                "kernels of two streams can starve each other.  Use depth=1 for this model configuration")
+        note_fallback("linear", f"{rows} x {K} -> {N} bf16 (own GEMM: N % 256 == 0, K % 64 == 0): library GEMM")
         if relu and cache[2] is not None:
             x2 = xb.reshape(-1, xb.shape[-1])
             return torch._addmm_activation(cache[2], x2, cache[1].t()).reshape(*xb.shape[:-1], cache[1].shape[0])
@@ -462,7 +487,7 @@ def linear(x, lin, relu=False, gelu=False):
 # set by pipeline.PipelinedForward around every forward it enqueues with more than one in flight: the bf16 library fallback of
 # `linear` raises instead of dispatching silently (ops.py:202)
 FORBID_LIBRARY_BF16_GEMM = False
-USE_FUSED_LINEAR_LN = os.environ.get("UNOPOSE_FUSED_LINEAR_LN", "1") == "1"  # A/B switch
+USE_FUSED_LINEAR_LN = True  # A/B attribute
 
 
 def linear_add_layernorm(h, lin, x, norm):
@@ -585,7 +610,7 @@ def bmm_nt_f32(a, b, alpha=1.0):
 
 
 def _own_f32(x):
-    return x.is_cuda and not _DIFF and USE_F32X3
+    return x.is_cuda and not _DIFF and USE_F32X3 and _no_autograd()
 
 
 def rigid_rows(p, t, R):
@@ -685,6 +710,7 @@ def vit_attention(qkv, heads):
         with torch.cuda.device(qkv.device):
             call("unopose_vit_attention_f32", ptr(qkv), B, T, heads, ptr(out), stream_ptr())
         return out
+    note_fallback("vit_attention", f"head dim {qkv.shape[-1] // (3 * heads)} / dtype {qkv.dtype} (kernels: head dim 64, bf16 or fp32)")
     return vit_attention_torch(qkv, heads)
 
 
@@ -845,6 +871,8 @@ def geo_embedding(points, m, out_dtype=None):
     result is bf16 with plain bf16 operands (what proj_d / proj_a produce under autocast in the
     reference); otherwise fp32 with hi/lo-split operands (fp32-class accuracy)."""
     if _DIFF or m.proj_d.weight.shape != (256, 256) or m.angle_k != 3 or points.shape[1] < 4:
+        if not _DIFF:
+            note_fallback("geo_embedding", f"hidden_dim {tuple(m.proj_d.weight.shape)} / angle_k {m.angle_k} / {points.shape[1]} points (kernel: 256, 3, >= 4)")
         return geo_embedding_torch(points, m)  # other widths / k: op-by-op GPU composite
     points = _c(points.float())
     check_f32(points, "points")
@@ -918,6 +946,8 @@ def token_attention(x, mem, att, heads, embed=None):
                 return _token_attention_hip(x, mem, att, embed)
             if x.dtype == torch.float32:
                 return _token_attention_hip_f32(x, mem, att, embed)
+    if not _DIFF and x.is_cuda:
+        note_fallback("token_attention", f"heads {heads} x width {x.shape[-1]}, {mem.shape[1]} keys, dtype {x.dtype} (kernels: 4 x 64, up to the padded key count)")
     return token_attention_torch(x, mem, att, heads, embed)
 
 
@@ -1044,6 +1074,8 @@ def focused_linear_attention(xq, xkv, att, heads, focusing):
             return _focused_linear_attention_hip(xq, xkv, att, int(focusing))
         if xq.dtype == torch.float32 and xkv.dtype == torch.float32:
             return _focused_linear_attention_hip_f32(xq, xkv, att, int(focusing))
+    if not _DIFF and xq.is_cuda:
+        note_fallback("focused_linear_attention", f"heads {heads} x width {xq.shape[-1]}, focusing {focusing} (kernels: 4 x 64, 3)")
     return focused_linear_attention_torch(xq, xkv, att, heads, focusing)
 
 
@@ -1154,6 +1186,7 @@ def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None, cand_in=None, want_
     if bf16x3 is None:  # the hi/lo-split matrix-core form is the fp32-class arithmetic of every other contraction of the fp32 path too
         bf16x3 = torch.is_autocast_enabled() or USE_F32X3
     if [tuple(l.conv.weight.shape[:2]) for l in mlp.layers()] != [(32, 6), (64, 32), (128, 64)] or nsample % 32:
+        note_fallback("pe_group_mlp_max", f"MLP widths / nsample {nsample} (kernel: 6-32-64-128, nsample % 32 == 0)")
         return pe_group_mlp_max_unfused(pts, radius, nsample, mlp)  # other widths: grouping kernel + GEMMs
     pts = _c(pts.float())
     check_f32(pts, "pts")

@@ -75,6 +75,7 @@ class PipelinedForward:
         # every pipeline stream waits once for the completion event of the first forward (pipeline.py:116).
         self._warm = None
         self._warm_seen = set()
+        self.last_mode = None
         self._n = 0
         self._pending = collections.deque()
         self._limit = self.depth + max(0, int(run_ahead))  # forwards the host may have enqueued and not yet seen finish
@@ -107,14 +108,22 @@ class PipelinedForward:
             use_stages = bool(torch.is_tensor(rgb) and (rgb.shape[-1] // 14) * (rgb.shape[-2] // 14) + 5 >= 1024)
         if hasattr(self.model, "internal_overlap") and self.depth > 1:
             self.model.internal_overlap = bool(use_stages)
+        self.last_mode = "stages" if use_stages else "whole"  # what this submit chose (bench.py reports it)
         if use_stages:
             if self._stage_streams is None:
                 self._stage_streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device, priority=-1)]
+            for ss in self._stage_streams:  # the caches the very first forward built (in EITHER mode) are ordered before this stream's first use
+                if self._warm is not None and ss.cuda_stream not in self._warm_seen:
+                    ss.wait_event(self._warm)
+                    self._warm_seen.add(ss.cuda_stream)
             prev_forbid, ops.FORBID_LIBRARY_BF16_GEMM = ops.FORBID_LIBRARY_BF16_GEMM, True
             try:
                 t, start, done = self._submit_stages(end_points)
             finally:
                 ops.FORBID_LIBRARY_BF16_GEMM = prev_forbid
+            if self._warm is None:
+                self._warm = done
+                self._warm_seen.update(ss.cuda_stream for ss in self._stage_streams)
         elif s is None:
             start = torch.cuda.Event(enable_timing=True) if self.timing else None
             if start is not None:

@@ -183,17 +183,26 @@ def broadcast_module_(module, src=0):
     tensors = list(module.parameters()) + list(module.buffers())
     if not tensors:
         return module
-    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
-    if flat.is_cuda and dist.get_backend() != "nccl":  # host-memory backends (gloo in the tests)
-        host = flat.cpu()
-        dist.broadcast(host, src)
-        flat = host.to(flat.device)
-    else:
+
+    def bcast(flat):
+        if flat.is_cuda and dist.get_backend() != "nccl":  # host-memory backends (gloo in the tests)
+            host = flat.cpu()
+            dist.broadcast(host, src)
+            return host.to(flat.device)
         dist.broadcast(flat, src)
-    off = 0
-    with torch.no_grad():  # in-place copy on the parameter itself: bumps `_version`, which keys every derived-weight
-        for t in tensors:  # cache in ops.py (a `.data` alias would leave them stale)
-            n = t.numel()
-            t.copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
-            off += n
+        return flat
+
+    # one flat buffer per dtype class: floating-point tensors travel as fp32, integer / bool buffers (BatchNorm's int64
+    # `num_batches_tracked`) as int64 -- an fp32 round trip would corrupt counters above 2^24
+    for is_float, wire in ((True, torch.float32), (False, torch.int64)):
+        group = [t for t in tensors if t.is_floating_point() == is_float]
+        if not group:
+            continue
+        flat = bcast(torch.cat([t.detach().reshape(-1).to(wire) for t in group]))
+        off = 0
+        with torch.no_grad():  # in-place copy on the parameter itself: bumps `_version`, which keys every derived-weight
+            for t in group:    # cache in ops.py (a `.data` alias would leave them stale)
+                n = t.numel()
+                t.copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
+                off += n
     return module
