@@ -33,6 +33,8 @@
 //     (XOR-swizzled) and written as whole 128-byte row segments with NON-TEMPORAL stores when the output exceeds the L2s.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "gemm_common.h"
 
 namespace unopose {
@@ -65,7 +67,8 @@ constexpr bool kMfma = GEMM_ABL != 2, kFrag = GEMM_ABL != 3, kDma = GEMM_ABL != 
 // LDS map (ONE __shared__ object): [0, 128 Ki) the ring: buffer b at b * 64 Ki = A image (32 Ki) | W image (32 Ki);
 // then 2 x 1 Ki bias slices (tile parity); EPI 3 only: LayerNorm weight / bias (2 x 1 Ki) and the row-statistics exchange (8 Ki).
 #define GEMM_LDS_BIAS (2 * GEMM_BUFBYTES)
-#define GEMM_LDS_LNW (GEMM_LDS_BIAS + 2048)
+#define GEMM_LDS_MBOX (GEMM_LDS_BIAS + 2048)  // 16 bytes: the next tile's ticket (dynamic tile scheduling)
+#define GEMM_LDS_LNW (GEMM_LDS_MBOX + 16)
 #define GEMM_LDS_LNB (GEMM_LDS_LNW + 1024)
 #define GEMM_LDS_LNPART (GEMM_LDS_LNB + 1024)
 
@@ -74,19 +77,28 @@ constexpr bool kMfma = GEMM_ABL != 2, kFrag = GEMM_ABL != 3, kDma = GEMM_ABL != 
 // tile_info[0] = number of tiles, read on the device: the host never learns it); C is (tiles * 256, 256).
 // EPI 3 (N == 256 only: a row is one tile wide): C = LayerNorm(A W^T + bias + resid) * ln_w + ln_b, the post-LN glue of the
 // matcher's transformer layers (transformer.py:151-193) -- the residual add and the LayerNorm run on the fp32 accumulators.
+// `sched` (optional): DYNAMIC tile scheduling.  A persistent workgroup that is dispatched late -- its CU was held by a kernel of another
+// stream: the 5000 -> 2048 FPS keeps 32 CUs for 1.9 ms under the ViT -- would still own its full static share of the tiles and
+// double the launch's makespan (12 ViT GEMMs: 3.58 ms alone, 4.74 ms beside that FPS; scripts/ubench/gemm_beside_fps.py).  With
+// `sched`, tiles are TICKETS drawn from one counter per XCD chunk (sched[0..7]; sched[8] counts finished workgroups, the last one
+// zeroes the slot for its next use).  The ticket of the NEXT tile is drawn at the start of the current one by lane 0 of wave 0 with a
+// returning global atomic whose result lands in v255 -- a register the compiler never allocates (amdgpu_num_vgpr(127) below: on
+// gfx90a+ the attribute counts in units of 2 registers, so the compiler keeps to v0 .. v253) -- so that NO wait sits between issue and use: returning atomics retire in order
+// with the wave's LDS-DMA loads, and the counted waits of the next two K-tiles retire it.  Wave 0 then posts it in LDS; all waves read
+// it two K-tiles before the tile ends, when the stream needs the next tile's addresses.
 template <int EPI, bool GATHER = false>  // EPI 0: bias; 1: bias + GELU; 2: bias + ReLU; 3: bias + residual + LayerNorm
-__global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict__ A, const u16 *__restrict__ W,
+__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void gemm_bf16_kernel(const u16 *__restrict__ A, const u16 *__restrict__ W,
                                                            const float *__restrict__ bias, u16 *__restrict__ C, int M,
                                                            int N, int K, int tiles_n, int tiles_arg, int nt_store,
                                                            const int *__restrict__ row_list = nullptr,
                                                            const int *__restrict__ tile_info = nullptr,
                                                            const u16 *__restrict__ resid = nullptr, const float *__restrict__ ln_w = nullptr,
                                                            const float *__restrict__ ln_b = nullptr, float ln_eps = 0.f, int lda = 0,
-                                                           int ldw = 0, int ldc = 0) {
+                                                           int ldw = 0, int ldc = 0, int *__restrict__ sched = nullptr) {
   // row strides in elements (0 = dense; unopose_linear_bf16_ld)
   const int LDA = lda ? lda : K, LDW = ldw ? ldw : K, LDC = ldc ? ldc : N;
   const int tiles = GATHER ? __builtin_amdgcn_readfirstlane(tile_info[0]) : tiles_arg;
-  __shared__ __attribute__((aligned(1024))) char smem[GEMM_LDS_BIAS + 2048 + (EPI == 3 ? 2048 + 8192 : 0)];
+  __shared__ __attribute__((aligned(1024))) char smem[GEMM_LDS_BIAS + 2048 + 16 + (EPI == 3 ? 2048 + 8192 : 0)];
   float *const lnw_lds = reinterpret_cast<float *>(smem + GEMM_LDS_LNW), *const lnb_lds = reinterpret_cast<float *>(smem + GEMM_LDS_LNB);
   float2 *const ln_part = reinterpret_cast<float2 *>(smem + GEMM_LDS_LNPART);  // [wm][mb][row][wn]: (sum, sum of squares) of 64 columns
   if (EPI == 3 && threadIdx.x < GEMM_BN) {  // visible after the first barrier of the tile loop
@@ -199,11 +211,20 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
   // The stream continues across tiles when the tile has >= 2 K-tiles and the epilogue leaves the registers for the next
   // tile's offsets (EPI 3, the LayerNorm epilogue, does not: every tile then starts from an empty pipeline).
   const bool can_stream = EPI != 3 && nk >= 2;
+  const bool dyn = sched != nullptr && !GATHER && can_stream && nk >= 5;  // (the ticket needs two K-tiles of loads behind it: see above)
+  int *const mbox = reinterpret_cast<int *>(smem + GEMM_LDS_MBOX);
   TileP cur;
   bool have = false;
   uint32_t par = 0;  // byte offset of the buffer of the current K-tile (0 / GEMM_BUFBYTES), toggles per K-tile ACROSS tiles
   int bsel = 0;      // bias slice of the current tile
-  for (int ti = slot, step = 0; ti < chunk_len; ti += nslots, ++step) {
+  int ti = slot;
+  if (dyn) {  // first ticket: nothing is in flight yet, an ordinary atomic and a barrier
+    if (tid == 0) mbox[0] = atomicAdd(sched + xcd, 1);
+    __syncthreads();
+    ti = __builtin_amdgcn_readfirstlane(mbox[0]);
+  }
+  for (; ti < chunk_len;) {
+    const int step = dyn ? ti / nslots : (ti - slot) / nslots;  // tiles an XCD runs together share the K rotation
     if (!have) {
       // empty pipeline: bias + half-tiles 0..5 of the stream (K-tile 0 complete, A0 / B0 of K-tile 1)
       tile_params(ti, step, cur);
@@ -224,7 +245,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
     }
     const int m0 = __builtin_amdgcn_readfirstlane(cur.m0), n0 = __builtin_amdgcn_readfirstlane(cur.n0);
     cur.rot = __builtin_amdgcn_readfirstlane(cur.rot);
-    const bool more = can_stream && ti + nslots < chunk_len;
+    bool more = can_stream && ti + nslots < chunk_len;  // (dynamic scheduling: decided two K-tiles before the end, from the ticket)
+    int ti_next = ti + nslots;
     TileP nxt;
 
     // the accumulators start at the bias (EPI 3 adds it in its LayerNorm epilogue): the bias slice landed with an earlier wait of
@@ -295,7 +317,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
     };
     for (int t = 0; t < nk; ++t) {
       const bool last = t + 1 == nk, last2 = t + 2 >= nk;  // K-tile t + 1 / t + 2 belongs to the next tile (or to nobody)
-      if (more && t + 2 == nk) tile_params(ti + nslots, step + 1, nxt);
+      if (dyn) {
+        if (t == 2 && wave == 0) {  // the ticket drawn in Y(0) has landed (14 younger loads, the waits of Y(0), X(1), Y(1) behind it)
+          int tk;
+          asm volatile("v_readfirstlane_b32 %0, v255" : "=s"(tk)::"memory");
+          if (lane == 0) mbox[0] = tk;
+        }
+        if (t + 2 == nk) {  // (posted >= 2 barriers ago)
+          ti_next = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(mbox));
+          more = ti_next < chunk_len;
+        }
+      }
+      if (more && t + 2 == nk) tile_params(ti_next, dyn ? ti_next / nslots : step + 1, nxt);
       const char *lb = smem + par;
       const uint32_t bnext = par ^ GEMM_BUFBYTES;  // buffer of K-tile t + 1; K-tile t + 2 goes where K-tile t is
       // X
@@ -319,6 +352,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
       // Y
       read_a(lb, 1);
       __builtin_amdgcn_sched_barrier(0);
+      if (dyn && t == 0 && wave == 0) {  // next tile's ticket: lane 0 only, result into the reserved v255, no wait
+        unsigned long long keep;
+        const uint32_t zero = 0, one = 1;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\ts_nop 1\n\tglobal_atomic_add v255, %2, %3, %1 sc0\n\ts_mov_b64 exec, %0\n\ts_nop 1"
+                     : "=&s"(keep)
+                     : "s"(sched + xcd), "v"(zero), "v"(one)
+                     : "memory", "v255");
+      }
       if (!last2) {
         stage_half(cur, H_A0, t + 2, par);
         stage_half(cur, H_B0, t + 2, par);
@@ -466,7 +507,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(const u16 *__restrict
       cur = nxt;
       bsel ^= 1;
     }
+    ti = ti_next;
   }  // tile loop
+  if (dyn && tid == 0) {  // the last workgroup to finish zeroes the slot (tickets drawn past the end included) for its next launch
+    if (atomicAdd(sched + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(sched + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 }  // namespace unopose
@@ -490,6 +538,29 @@ static int small_tiles_limit() {
   return v >= 0 ? v : gemm_cu_count();
 }
 
+// Ticket slots of the dynamic tile scheduling: a ring of 1024 slots of 16 ints per device (zeroed once; every launch's last workgroup
+// re-zeroes its slot).  Consecutive launches take consecutive slots, so launches of different streams that run at the same time never
+// share one (a slot comes round again after 1024 launches: 20 forwards later).  `UNOPOSE_GEMM_DYN=0`: static tile lists (A/B).
+static int *sched_slot() {
+  static const bool on = [] {
+    const char *e = getenv("UNOPOSE_GEMM_DYN");
+    return !(e && *e == '0');
+  }();
+  if (!on) return nullptr;
+  static std::mutex mu;
+  static int *ring[64] = {nullptr};
+  static unsigned next_slot[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ring[dev]) {
+    int *p = nullptr;
+    if (hipMalloc(&p, 1024 * 16 * sizeof(int)) != hipSuccess || hipMemset(p, 0, 1024 * 16 * sizeof(int)) != hipSuccess) return nullptr;
+    ring[dev] = p;
+  }
+  return ring[dev] + (size_t)(next_slot[dev]++ & 1023u) * 16;
+}
+
 static int linear_bf16_dispatch(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, long M, int N, int K,
                                 int epilogue, hipStream_t s, const char *what) {
   const int tiles_n = N / GEMM_BN;
@@ -501,7 +572,8 @@ static int linear_bf16_dispatch(const void *A, int lda, const void *W, int ldw, 
 #define UNOPOSE_LD_LAUNCH(E)                                                                                                                \
   hipLaunchKernelGGL(gemm_bf16_kernel<E>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N, K, tiles_n, \
                      tiles, nt, (const int *)nullptr, (const int *)nullptr, (const u16 *)nullptr, (const float *)nullptr,                     \
-                     (const float *)nullptr, 0.f, lda, ldw, ldc)
+                     (const float *)nullptr, 0.f, lda, ldw, ldc, sched)
+  int *const sched = tiles > grid ? sched_slot() : nullptr;  // (one tile per workgroup: nothing to schedule)
   if (epilogue == 1)
     UNOPOSE_LD_LAUNCH(1);
   else if (epilogue == 2)
