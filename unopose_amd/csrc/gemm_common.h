@@ -72,6 +72,9 @@ int gemm_small_linear(const void *A, const void *W, const float *bias, void *C, 
 int gemm_small_linear_ln(const void *A, const void *W, const float *bias, const void *resid, const float *ln_w, const float *ln_b, float eps,
                          void *C, long M, int K, hipStream_t s);
 
+// A ticket slot for one launch of the persistent kernel with dynamic tile scheduling (gemm.hip), or nullptr (static tile lists).
+int *gemm_sched_slot();
+
 // One persistent workgroup per CU of the CURRENT device (a multiple of 8: the tile walk is per XCD).
 inline int gemm_cu_count() {
   static int n_cu[64] = {0};
