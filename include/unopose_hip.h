@@ -290,6 +290,10 @@ int unopose_vit_attention_f32(const float *qkv, int B, int T, int H, float *out,
 /* The same with the output in the split layout of unopose_linear_f32x3 ((B,T,2 H 64) bf16: the operand of the projection that
  * follows, timm Attention.proj). */
 int unopose_vit_attention_f32_split(const float *qkv, int B, int T, int H, void *out_split, unopose_stream_t stream);
+/* Split layout IN and OUT (csrc/vit_attn_f32s.hip): qkv_split = the (B*T, 3 H 64) qkv in the split layout, as unopose_linear_f32x3
+ * writes it (Cs); the kernel of the fp32 ViT blocks -- 8 waves x 32 queries, 128-key double-buffered chunks, no operand is split
+ * inside the kernel. */
+int unopose_vit_attention_f32_ss(const void *qkv_split, int B, int T, int H, void *out_split, unopose_stream_t stream);
 
 /* ViT attention core (timm Attention as driven by core/unopose/model/oneref_feature_extraction.py:38-41):
  * out (B,T,H*64) = softmax(q k^T / 8) v per head, flash-style.  qkv (B,T,3,H,64) = the fused qkv Linear

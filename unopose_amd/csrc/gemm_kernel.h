@@ -346,10 +346,13 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
       if (dyn && t == 0 && wave == 0) {  // next tile's ticket: lane 0 only, result into the reserved v255, no wait
         unsigned long long keep;
         const uint32_t zero = 0, one = 1;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // v255 is reserved (amdgpu_num_vgpr): naming it keeps the kernel's register count at 256
         asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\ts_nop 1\n\tglobal_atomic_add v255, %2, %3, %1 sc0\n\ts_mov_b64 exec, %0\n\ts_nop 1"
                      : "=&s"(keep)
                      : "s"(sched + xcd), "v"(zero), "v"(one)
                      : "memory", "v255");
+#pragma clang diagnostic pop
       }
       if (!last2) {
         stage_half(cur, H_A0, t + 2, par);

@@ -1,0 +1,263 @@
+// DINOv2 ViT patch attention on fp32-class data for gfx950 (C ABI part 2): the reference's default precision
+// (configs/main_cfg.py:87-89, no autocast; timm Attention core at core/unopose/model/oneref_feature_extraction.py:38-41).
+//
+// Input AND output are in the SPLIT layout of csrc/gemm_f32.hip (per token and 32-channel block one 128-byte line
+// [hi (32 bf16) | lo (32 bf16)], x = hi + lo to 2^-17): the qkv GEMM writes it in its epilogue and the projection GEMM reads it, so
+// this kernel never sees fp32 data and never splits an operand itself -- round 3's kernel (attn_f32.hip) read fp32 qkv and every one
+// of the 11 workgroups of an (image, head) re-split the whole K / V on its way into LDS, V^T through 2-byte LDS stores.
+// Structure = the bf16 kernel's skeleton (vit_attn.hip): 8 waves x 32 queries per workgroup, K / V of a 128-key chunk staged once
+// per workgroup by register prefetch into double-buffered LDS (hi and lo planes side by side, 141 KiB), S^T = K Q^T with the operands
+// swapped so that a lane holds 16 keys of ONE query, deferred reference point + end-of-tile fix-up, P from registers (split into
+// hi / lo there), V^T fragments by ds_read_b64_tr_b16, one barrier per chunk -- with three MFMAs per product
+// (hi.hi + hi.lo + lo.hi, fp32 accumulation) in both contractions.
+#include "common.h"
+
+namespace unopose {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int VS_CHUNK = 128;           // keys staged per LDS chunk
+constexpr int VS_LDK = 64 + 8;          // padded row of a K plane [key][channel]
+constexpr int VS_VSUB = 128 * 16 + 64;  // u16 per V sub-tile [128 keys][16 channels] (+ 128 B bank skew), 4 per plane
+constexpr int VS_PLANE = VS_CHUNK * VS_LDK + 4 * VS_VSUB;  // u16 per plane of a chunk buffer (K rows + V sub-tiles)
+constexpr int VS_BUF = 2 * VS_PLANE;                        // hi plane | lo plane
+constexpr float VS_DEFER = 8.f;  // log2 of the largest P the deferred rescale lets through
+
+struct HLf {
+  bf16x8 h, l;
+};
+#define VS_MFMA3(acc, a, b)                                          \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0); \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0); \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0)
+
+// qkv_s: (B, T) token rows of 3 * H * 64 values in the split layout (3 * H * 256 bytes per token: q blocks | k blocks | v blocks,
+// head h = blocks 2h, 2h + 1 of each third); out_s: (B, T) rows of H * 64 values in the split layout.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void vit_attn_f32s_kernel(const char *__restrict__ qkv_s, int T, int H,
+                                                                                                     int BH, int nq, float scale_log2e,
+                                                                                                     char *__restrict__ out_s) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  float (*Ot)[32][68] = reinterpret_cast<float (*)[32][68]>(smem);
+  static_assert(NW * 32 * 68 * 4 <= 2 * VS_BUF * 2, "output staging must fit the chunk buffers");
+  constexpr int NT = NW * 64;
+  static_assert(NT == 512, "8 wavefronts per workgroup");
+  // workgroup -> (image, head, query block): all query blocks of one (image, head) share id % 8 (one XCD's L2 holds its K / V)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bh = (slot / nq) * 8 + xcd, qblk = slot % nq;
+  if (bh >= BH) return;
+  const int b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q0 = (qblk * NW + wave) * 32;
+  const bool active = q0 < T;  // inactive waves still help staging and hit every barrier
+  const int col = lane & 31, hb = lane >> 5;
+  const size_t RB = (size_t)3 * H * 256;  // bytes per token row
+  const char *base = qkv_s + (size_t)b * T * RB;
+  const int qoff = h * 256, koff = (H + h) * 256, voff = (2 * H + h) * 256;  // the head's 2 blocks = 256 contiguous bytes [hi0 lo0 hi1 lo1]
+  HLf qf[4];
+  {
+    const char *qp = base + (size_t)min(q0 + col, T - 1) * RB + qoff;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks * 16 + hb * 8;  // channels c .. c + 7
+      const char *p = qp + (c >> 5) * 128 + (c & 31) * 2;
+      qf[ks].h = *reinterpret_cast<const bf16x8 *>(p);
+      qf[ks].l = *reinterpret_cast<const bf16x8 *>(p + 64);
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks].h), "+v"(qf[ks].l));  // the Q loads are complete HERE (see vit_attn.hip)
+  f32x16 o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -3e38f, l_run = 0.f;
+
+  // register-staged prefetch of a chunk: per key 256 B of K and 256 B of V, 16 pieces of 16 B each: 2048 + 2048 pieces, 4 + 4 per thread.
+  // piece e: key = e >> 4, sub = e & 15: block = sub >> 3, q8 = sub & 7: q8 < 4 -> hi channels block * 32 + q8 * 8 .., else lo
+  uint4 pk[4], pv[4];
+  auto chunk_load = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * NT, key = e >> 4, sub = e & 15;
+      const char *src = base + (size_t)min(c0 + key, T - 1) * RB + sub * 16;
+      pk[i] = *reinterpret_cast<const uint4 *>(src + koff);
+      pv[i] = *reinterpret_cast<const uint4 *>(src + voff);
+    }
+  };
+  auto chunk_store = [&](int c0, u16 *buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * NT, key = e >> 4, sub = e & 15;
+      const int plane = (sub >> 2) & 1, ch = (sub >> 3) * 32 + (sub & 3) * 8;  // 8 channels ch .. ch + 7 of the hi / lo plane
+      u16 *pl = buf + plane * VS_PLANE;
+      *reinterpret_cast<uint4 *>(pl + key * VS_LDK + ch) = pk[i];
+      // V image: sub-tile ch >> 4, row = key, 16-byte half (ch >> 3) & 1; keys beyond T contribute V = 0 (their P is 0 as well)
+      *reinterpret_cast<uint4 *>(pl + VS_CHUNK * VS_LDK + (ch >> 4) * VS_VSUB + key * 16 + ((ch >> 3) & 1) * 8) =
+          c0 + key < T ? pv[i] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  // this lane's slot in the transpose read: sub-tile (lane>>4)&1, key row 4 hb + ((lane&15)>>2), 8-byte chunk lane&3
+  const int vlane_off = VS_CHUNK * VS_LDK + ((lane >> 4) & 1) * VS_VSUB + (4 * hb + ((lane & 15) >> 2)) * 16 + (lane & 3) * 4;
+
+  auto tile = [&](const u16 *buf, int c0, int kt, bool partial) {
+    // S^T = K Q^T: rows = 32 keys, cols = 32 queries
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const u16 *kp = buf + (kt + col) * VS_LDK + ks * 16 + hb * 8;
+      const HLf kf{*reinterpret_cast<const bf16x8 *>(kp), *reinterpret_cast<const bf16x8 *>(kp + VS_PLANE)};
+      VS_MFMA3(s, kf, qf[ks]);
+    }
+    if (partial) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (c0 + kt + (r & 3) + 8 * (r >> 2) + 4 * hb >= T) s[r] = -3e38f;
+    }
+    // online softmax with the deferred reference point (vit_attn.hip): per-lane select, no branch before the P.V MFMAs
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    const auto sm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    mx = fmaxf(__uint_as_float(sm[0]), __uint_as_float(sm[1])) * scale_log2e;
+    const bool grow = mx > m_run + VS_DEFER;
+    const float m_use = grow ? mx : m_run;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+    m_run = m_use;
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_use));
+      ls += s[r];
+    }
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
+    l_run = fmaf(l_run, alpha, __uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+    // P = hi + lo, packed as the B operand of the two 16-key k-steps
+    union PF {
+      bf16x8 v;
+      uint32_t w[4];
+    } ph[2], pl[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = s[s2 * 8 + 2 * e], c = s[s2 * 8 + 2 * e + 1];
+        const uint32_t hw = cvt_pk_bf16_f32(a, c);
+        ph[s2].w[e] = hw;
+        pl[s2].w[e] = cvt_pk_bf16_f32(a - __uint_as_float(hw << 16), c - __uint_as_float(hw & 0xffff0000u));
+      }
+    const u16 *vlane = buf + vlane_off;
+    auto v_frag = [&](int s2, int t) {
+      const u16 *vp = vlane + t * 2 * VS_VSUB + (kt + s2 * 16) * 16;
+      union {
+        bf16x8 v;
+        s16x4 h4[2];
+      } vh, vl;
+      vh.h4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp));
+      vh.h4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp + 8 * 16));
+      vl.h4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp + VS_PLANE));
+      vl.h4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp + VS_PLANE + 8 * 16));
+      return HLf{vh.v, vl.v};
+    };
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const HLf vf = v_frag(s2, t);
+        const HLf pf{ph[s2].v, pl[s2].v};
+        VS_MFMA3(o[t], vf, pf);
+      }
+    if (__builtin_expect(__any(grow), 0)) {  // rare after the first tile: O = (O - D) alpha + D with D = this tile's P.V (vit_attn.hip)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x16 d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const HLf vf = v_frag(s2, t);
+          const HLf pf{ph[s2].v, pl[s2].v};
+          VS_MFMA3(d, vf, pf);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = fmaf(o[t][r] - d[r], alpha, d[r]);
+      }
+    }
+  };
+  auto chunk_compute = [&](int c0, const u16 *buf) {
+    const int nk = min(VS_CHUNK, T - c0);
+    int kt = 0;
+    for (; kt + 32 <= nk; kt += 32) tile(buf, c0, kt, false);
+    if (kt < nk) tile(buf, c0, kt, true);  // the one partial tile of the sequence: keys >= T are masked out
+  };
+
+  const int nchunks = (T + VS_CHUNK - 1) / VS_CHUNK;
+  chunk_load(0);
+  chunk_store(0, smem);
+  if (nchunks > 1) chunk_load(VS_CHUNK);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    if (active) chunk_compute(c * VS_CHUNK, smem + (c & 1) * VS_BUF);
+    if (c + 1 < nchunks) {  // the other buffer was last read before the previous barrier
+      chunk_store((c + 1) * VS_CHUNK, smem + ((c + 1) & 1) * VS_BUF);
+      if (c + 2 < nchunks) chunk_load((c + 2) * VS_CHUNK);
+    }
+    __syncthreads();
+  }
+  if (!active) return;
+  // ---- normalise, transpose through LDS, store token rows in the split layout
+  const float inv = 1.f / l_run;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ot[wave][col][t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb] = o[t][r] * inv;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // 32 rows x 64 channels: 16 lanes per row, 4 channels each -> 8 bytes of hi and 8 bytes of lo
+  const size_t ORB = (size_t)H * 256;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 4 + (lane >> 4), seg = lane & 15;
+    if (q0 + row < T) {
+      const float4 v = *reinterpret_cast<const float4 *>(&Ot[wave][row][seg * 4]);
+      uint2 hi, lo;
+      hi.x = cvt_pk_bf16_f32(v.x, v.y);
+      hi.y = cvt_pk_bf16_f32(v.z, v.w);
+      lo.x = cvt_pk_bf16_f32(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u));
+      lo.y = cvt_pk_bf16_f32(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u));
+      const int c = seg * 4;  // channel inside the head
+      char *line = out_s + ((size_t)b * T + q0 + row) * ORB + h * 256 + (c >> 5) * 128 + (c & 31) * 2;
+      *reinterpret_cast<uint2 *>(line) = hi;
+      *reinterpret_cast<uint2 *>(line + 64) = lo;
+    }
+  }
+}
+
+}  // namespace unopose
+
+using namespace unopose;
+
+extern "C" {
+
+int unopose_vit_attention_f32_ss(const void *qkv_split, int B, int T, int H, void *out_split, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(qkv_split && out_split, "vit_attention_f32_ss: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && T >= 1 && H >= 1 && (long)B * H * cdiv(T, 256) < (1L << 28), "vit_attention_f32_ss: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  constexpr int NW = 8;
+  static bool opt[64];
+  const size_t lds = (size_t)2 * VS_BUF * sizeof(u16);
+  if (lds_optin(opt, reinterpret_cast<const void *>(&vit_attn_f32s_kernel<NW>), lds, "vit_attention_f32_ss") != UNOPOSE_OK) return UNOPOSE_ELAUNCH;
+  const int BH = B * H, nq = cdiv(T, 32 * NW);
+  const long blocks = (long)cdiv(BH, 8) * nq * 8;
+  hipLaunchKernelGGL((vit_attn_f32s_kernel<NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, (hipStream_t)stream, (const char *)qkv_split, T, H, BH,
+                     nq, 0.125f * 1.4426950408889634f, (char *)out_split);
+  return check_launch("vit_attention_f32_ss");
+}
+
+}  // extern "C"

@@ -77,9 +77,10 @@ class _Block(nn.Module):
         rows = B * T
         a, m = self.attn, self.mlp
         cq = ops._f32x3_weights(a.qkv)
-        qkv = ops.linear_f32x3(n1s, cq[1], cq[2], rows, 3 * C, C).reshape(B, T, 3 * C)
+        # qkv, the attention core and the projection chained on split operands: no fp32 qkv / attention tensor exists
+        qkv_s = ops.linear_f32x3(n1s, cq[1], cq[2], rows, 3 * C, C, out="split")
         cp = ops._f32x3_weights(a.proj)
-        y = ops.linear_f32x3(ops.vit_attention_f32_split(qkv, a.heads), cp[1], cp[2], rows, C, C).reshape(B, T, C)
+        y = ops.linear_f32x3(ops.vit_attention_f32_ss(qkv_s, B, T, a.heads), cp[1], cp[2], rows, C, C).reshape(B, T, C)
         n2s = ops.scale_residual_layernorm_f32_(x, y, self.ls1.gamma, self.norm2)
         c1, c2 = ops._f32x3_weights(m.fc1), ops._f32x3_weights(m.fc2)
         hs = ops.linear_f32x3(n2s, c1[1], c1[2], rows, 4 * C, C, gelu=True, out="split")

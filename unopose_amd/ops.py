@@ -726,6 +726,17 @@ def vit_attention_f32_split(qkv, heads):
     return out
 
 
+def vit_attention_f32_ss(qkv_split, B, T, heads):
+    """qkv in the split layout ((B*T, 2 * 3C) bf16, as `linear_f32x3(..., out="split")` writes it) -> the attention output in the
+    split layout ((B*T, 2C) bf16): csrc/vit_attn_f32s.hip, the fp32 ViT block's attention core (no fp32 tensor in between)."""
+    C3 = qkv_split.shape[-1] // 2
+    assert qkv_split.dtype == torch.bfloat16 and qkv_split.is_cuda and qkv_split.is_contiguous() and C3 == 3 * heads * 64
+    out = torch.empty(B * T, 2 * (C3 // 3), dtype=torch.bfloat16, device=qkv_split.device)
+    with torch.cuda.device(qkv_split.device):
+        call("unopose_vit_attention_f32_ss", ptr(qkv_split), B, T, heads, ptr(out), stream_ptr())
+    return out
+
+
 def vit_attention_torch(qkv, heads):
     """Op-by-op composite of the same function."""
     B, T, C3 = qkv.shape
