@@ -119,7 +119,7 @@ def hip_event_time(fn, iters, stream, warm=1):
 
 def roofline_leg(model, batch, img):
     """Roofline of the dominant hand-written kernel of the step, timed live with HIP events on the stream it runs on:
-    `gemm_bf16_kernel` (csrc/gemm.hip), the linear layers of the ViT -- 48 launches per step, the largest share of
+    `gemm256_kernel` (csrc/gemm_kernel.h, launched by csrc/gemm.hip), the linear layers of the ViT -- 48 launches per step, the largest share of
     the step's GPU time.  `roofline` prices the four shapes of one ViT-B block (qkv, proj, fc1 + bias + GELU, fc2) at
     the step's row count M = 2B x T flop-weighted: achieved = (sum of their flops) / (sum of their launch times).
     The other rows BASELINE's north star prices follow in `roofline_other`.  Work models: DESIGN.md section 4."""
@@ -165,11 +165,11 @@ def roofline_leg(model, batch, img):
         alg_bytes += r["algorithmic_bytes"]
         del a, w, bias
     traffic = _pmc_traffic_gemm(B, T, alg_bytes)
-    gemm = dict(bound="mfma", kernel="gemm_bf16_kernel: the four linears of one ViT-B block at M=%d, flop-weighted" % M,
+    gemm = dict(bound="mfma", kernel="gemm256_kernel<EPI, false, false> (bf16): the four linears of one ViT-B block at M=%d, flop-weighted" % M,
                 achieved=flops / secs / 1e12, peak=2500.0, unit="TFLOP/s", frac=flops / secs / 1e12 / 2500.0, traffic=traffic,
                 launches=4, us=secs * 1e6, flop=flops, algorithmic_bytes=alg_bytes, shapes=shapes,
-                note="hand-written bf16 MFMA GEMM (256x256 tiles, LDS-DMA operand stages, persistent XCD-aware tile walk), bias / "
-                     "GELU in the epilogue; `achieved` = sum of the four shapes' flops / sum of their HIP-event launch times; "
+                note="hand-written bf16 MFMA GEMM (256x256 tiles, half-tile LDS-DMA stream with counted waits, ping-pong wave groups, "
+                     "persistent XCD-aware tile walk with dynamic tile tickets), bias / GELU in the epilogue; `achieved` = sum of the four shapes' flops / sum of their HIP-event launch times; "
                      "12 blocks x 4 launches per step")
     rows[:] = []
     # ViT patch attention: 4 T^2 64 flop per (image, head), 2B images x 12 heads
@@ -190,6 +190,12 @@ def roofline_leg(model, batch, img):
                 2.0 * M * K_ * N_, 1e12, 2500.0 / 3.0, "TFLOP/s", t,
                 "fp32-equivalent flops against 1/3 of the bf16 dense peak (3 bf16 MFMAs per product)")
             del a_s, w_s, bias
+        # the fp32-class ViT attention (split layout in and out, csrc/vit_attn_f32s.hip)
+        qs = ops.split_f32(torch.randn(2 * B * T, 2304, device=x.device))
+        t = hip_event_time(lambda: ops.vit_attention_f32_ss(qs, 2 * B, T, 12), 5, stream)
+        row("vit_attn_f32s_kernel(T=%d)" % T, "mfma", 2.0 * B * 12 * 4.0 * T * T * 64, 1e12, 2500.0 / 3.0, "TFLOP/s", t,
+            "fp32-equivalent flops against 1/3 of the bf16 dense peak (3 bf16 MFMAs per product in both contractions)")
+        del qs
     # PE, S=256, bf16 hi/lo-split matrix cores; 20864 flop per neighbour row
     t = hip_event_time(lambda: ops.pe_group_mlp_max(x, pe.r2, pe.ns2, pe.mlp2, bf16x3=True), 10, stream)
     r = row("pe_group_mlp_max_bf16x3_kernel(S=%d)" % pe.ns2, "mfma", B * N * pe.ns2 * 20864.0, 1e12, 2500.0,

@@ -8,7 +8,7 @@
 #  3. the bench lines themselves.
 # Summaries land in gpurun_out/ for copying to profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
 for img in 518 224; do

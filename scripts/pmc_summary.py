@@ -12,9 +12,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 SHORT = ["token_attn_kernel<true", "vit_attn_kernel", "group_points_lds_kernel", "pe_group_mlp_max_bf16x3_kernel",
-         "ball_query_kernel", "geo_embed_kernel", "geo_knn_kernel", "gemm_bf16_kernel<1", "gemm_bf16_kernel<0, false",
+         "ball_query_kernel", "geo_embed_kernel", "geo_knn_kernel", "gemm256_kernel<1, false, false>", "gemm256_kernel<0, false, false>",
          "fine_assign_kernel<0>", "fine_assign_kernel<1>", "fine_assign_kernel<2>"]
-# gemm_bf16_kernel<1>: fc1 + GELU (M = 87936, 768 -> 3072); gemm_bf16_kernel<0, false>: MEAN over the qkv / proj / fc2 launches of
+# gemm256_kernel<1, false, false>: fc1 + GELU (M = 87936, 768 -> 3072); <0, false, false>: MEAN over the qkv / proj / fc2 launches of
 # scripts/pmc_kernels.py (three shapes, three launches each); the per-shape numbers are under "gemm_shapes"
 
 
@@ -36,7 +36,7 @@ def gemm_shapes(fetch_csv, write_csv):
     from pmc_gemm import ORDER, REPS
 
     out = {}
-    f, w = load_dispatches(fetch_csv, "gemm_bf16_kernel"), load_dispatches(write_csv, "gemm_bf16_kernel")
+    f, w = load_dispatches(fetch_csv, ", false, false>("), load_dispatches(write_csv, ", false, false>(")  # gemm256_kernel<EPI, false, false>: bf16
     assert len(f) == len(w) == REPS * len(ORDER), (len(f), len(w))
     for i, (name, K, N, gelu) in enumerate(ORDER):
         fs, ws = f[i * REPS:(i + 1) * REPS], w[i * REPS:(i + 1) * REPS]
@@ -45,8 +45,8 @@ def gemm_shapes(fetch_csv, write_csv):
         out[name] = dict(M=M, K=K, N=N, fetch_KiB_raw=fk, write_KiB=wk, hbm_bytes_per_launch=(2.0 * fk + wk) * 1024.0,
                          algorithmic_bytes=2.0 * (M * K + N * K + M * N) + 4.0 * N,
                          mean_duration_us_under_pmc=sum(d for _, d in fs) / REPS / 1e3)
-    f3 = load_dispatches(fetch_csv, "gemm_f32x3_kernel")
-    w3 = load_dispatches(write_csv, "gemm_f32x3_kernel")
+    f3 = load_dispatches(fetch_csv, ", false, true>(")  # gemm256_kernel<EPI, false, true>: fp32-class
+    w3 = load_dispatches(write_csv, ", false, true>(")
     x3 = {}
     if len(f3) == len(w3) == 2 * REPS:
         for i, name in enumerate(("qkv", "fc1")):
