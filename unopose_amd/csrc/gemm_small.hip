@@ -7,9 +7,8 @@
 //     <128, 128>  waves 2 (M) x 2 (N)      <64, 256>  waves 1 x 4: a whole 256-wide row per tile, which the residual + LayerNorm
 //                                                     epilogue (EPI 3) needs
 // Operand stages are the LDS image of gemm.hip ([rows][128 B], 16-byte chunks XOR-swizzled on the SOURCE address of the
-// LDS-DMA), NST stages of K = 64: 2 stages (64 KiB: two workgroups per CU at 128 x 128, whose phases overlap each other) when
-// tiles outnumber CUs, 3 - 4 stages (one workgroup per CU) when they do not -- a matcher layer with K = 256 then has its whole K
-// in flight at once.
+// LDS-DMA), NST stages of K = 64 (template parameter; the launches use 2: 64 KiB, two workgroups per CU at 128 x 128 -- or one
+// beside a workgroup of another stream's kernel).
 // K loop per K-tile:  issue the DMA pieces of K-tile t + NST - 1  |  counted vmcnt -> K-tile t has landed  |  barrier  |
 // 16 fragment reads + 16 MFMAs  |  barrier.  Epilogue: bias / GELU / ReLU / residual + LayerNorm on the fp32 accumulators, bf16 staged
 // through the (now free) stage buffers, whole 128-byte row segments out through a buffer descriptor (rows past M dropped).
@@ -228,23 +227,20 @@ static int launch_small(const void *A, const void *W, const float *bias, void *C
   return check_launch("linear_bf16 (small tiles)");
 }
 
-// Entry points for gemm.hip's C ABI functions (N % 128 == 0, K % 64 == 0; epilogue 0 / 1 / 2).  Deep staging (one workgroup per CU)
-// when the tiles do not outnumber the CUs anyway, otherwise two stages and two workgroups per CU.
+// Entry points for gemm.hip's C ABI functions (N % 128 == 0, K % 64 == 0; epilogue 0 / 1 / 2).  Two stages (64 / 82 KiB of LDS): a
+// workgroup then fits on a CU BESIDE a workgroup of the positional-encoding kernel (76 KiB), which runs on a side stream under the
+// coarse stage -- with 3 - 4 stages (measured no faster per launch: 5.8 vs 5.5 us at 6304 x 256 x 256) every coarse-stage linear
+// waited for a whole CU, up to 1.3 ms behind the PE launch (profiles/r04_kernel_stats_isolated_b32_s518.csv, first collection).
 int gemm_small_linear(const void *A, const void *W, const float *bias, void *C, long M, int N, int K, int lda, int ldw, int ldc, int epilogue,
                       hipStream_t s) {
-  const bool deep = (long)cdiv(M, 128) * (N / 128) <= gemm_cu_count();
-#define GS_GO(E)                                                                                                                            \
-  return deep ? launch_small<128, 128, E, 4>(A, W, bias, C, M, N, K, lda, ldw, ldc, nullptr, nullptr, nullptr, 0.f, s)                     \
-              : launch_small<128, 128, E, 2>(A, W, bias, C, M, N, K, lda, ldw, ldc, nullptr, nullptr, nullptr, 0.f, s)
-  if (epilogue == 1) GS_GO(1);
-  if (epilogue == 2) GS_GO(2);
-  GS_GO(0);
-#undef GS_GO
+  if (epilogue == 1) return launch_small<128, 128, 1, 2>(A, W, bias, C, M, N, K, lda, ldw, ldc, nullptr, nullptr, nullptr, 0.f, s);
+  if (epilogue == 2) return launch_small<128, 128, 2, 2>(A, W, bias, C, M, N, K, lda, ldw, ldc, nullptr, nullptr, nullptr, 0.f, s);
+  return launch_small<128, 128, 0, 2>(A, W, bias, C, M, N, K, lda, ldw, ldc, nullptr, nullptr, nullptr, 0.f, s);
 }
 // N == 256: LayerNorm(A W^T + bias + resid) * ln_w + ln_b, 64-row tiles
 int gemm_small_linear_ln(const void *A, const void *W, const float *bias, const void *resid, const float *ln_w, const float *ln_b, float eps,
                          void *C, long M, int K, hipStream_t s) {
-  return launch_small<64, 256, 3, 3>(A, W, bias, C, M, 256, K, K, K, 256, resid, ln_w, ln_b, eps, s);
+  return launch_small<64, 256, 3, 2>(A, W, bias, C, M, 256, K, K, K, 256, resid, ln_w, ln_b, eps, s);
 }
 
 }  // namespace unopose
