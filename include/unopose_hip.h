@@ -193,6 +193,19 @@ int unopose_pe_group_mlp_max(const float *xyz, int B, int N, float radius, int n
 int unopose_softmax_stats(const float *x, int B, int R, int C, float *stats_ws, unopose_stream_t stream);
 int unopose_infonce_grad(const float *x, int B, int R, int C, const float *stats_ws, const long long *label1,
                          const long long *label2, const float *g, float *grad, unopose_stream_t stream);
+
+/* Training-mode BatchNorm2d + ReLU of the PE's SharedMLP (pytorch_utils.py:25-132 under train(): nn.BatchNorm2d with batch
+ * statistics followed by ReLU), x / y / dy / dx (B, C, L) fp32 with L = N * S a multiple of 4.  forward: batch mean / rstd (biased
+ * variance) into `mean`, `rstd`, running statistics updated as nn.BatchNorm2d does (unbiased variance; both NULL: not tracked),
+ * y = relu(bn(x)).  backward: dgamma, dbeta, dx from x, dy and the forward's mean / rstd (the ReLU mask is recomputed).
+ * workspace: 2 * B * C * ceil(L / unopose_bn_train_chunk()) floats. */
+int unopose_bn_train_chunk(void);
+int unopose_bn_relu_train_forward(const float *x, int B, int C, long L, const float *gamma, const float *beta, float eps, float momentum,
+                                  float *running_mean, float *running_var, float *workspace, float *mean, float *rstd, float *y,
+                                  unopose_stream_t stream);
+int unopose_bn_relu_train_backward(const float *x, const float *dy, int B, int C, long L, const float *gamma, const float *beta,
+                                   const float *mean, const float *rstd, float *workspace, float *dgamma, float *dbeta, float *dx,
+                                   unopose_stream_t stream);
 int unopose_assign_labels(const float *atten, int B, int R, int C, const float *score1,
                           const float *score2, float *stats_ws, float *w1, float *w2,
                           unopose_stream_t stream);

@@ -173,3 +173,39 @@ def test_fused_infonce_matches_cross_entropy_pair():
         assert torch.allclose(got.double(), want, rtol=2e-6, atol=1e-5), (got, want)
         scale = float(ad.grad.abs().max())
         assert float((ga.double() - ad.grad).abs().max()) < 1e-5 * scale + 1e-9, (float((ga.double() - ad.grad).abs().max()), scale)
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 50, 64), (2, 128, 33, 256), (1, 6, 7, 4), (4, 64, 1025, 64)])
+def test_fused_bn_relu_train_matches_torch(shape):
+    """csrc/bn_train.hip (relu(BatchNorm2d(x)) with batch statistics, forward + backward, running statistics) vs the torch modules in
+    float64: outputs / input gradient 2e-6 of the tensor's scale, parameter gradients 1e-5, running statistics 1e-6."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=g) * 1.7 + 0.4).cuda().requires_grad_(True)
+    dy = torch.randn(*shape, generator=g).cuda()
+    bn = torch.nn.BatchNorm2d(shape[1]).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(shape[1], generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(shape[1], generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(shape[1], generator=g))
+        bn.running_var.copy_(torch.rand(shape[1], generator=g) + 0.5)
+    ref_bn = torch.nn.BatchNorm2d(shape[1]).double().cuda().train()
+    ref_bn.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    xd = x.detach().double().requires_grad_(True)
+    yr = torch.relu(ref_bn(xd))
+    yr.backward(dy.double())
+    y = ops.bn_relu(x, bn)
+    assert y.grad_fn is not None and "BNReLUTrain" in type(y.grad_fn).__name__  # the fused path was taken
+    y.backward(dy)
+    sc = float(yr.abs().max())
+    assert float((y.double() - yr).abs().max()) < 2e-6 * sc
+    assert float((x.grad.double() - xd.grad).abs().max()) < 2e-6 * float(xd.grad.abs().max()) + 1e-9
+    assert float((bn.weight.grad.double() - ref_bn.weight.grad).abs().max()) < 1e-5 * float(ref_bn.weight.grad.abs().max())
+    assert float((bn.bias.grad.double() - ref_bn.bias.grad).abs().max()) < 1e-5 * float(ref_bn.bias.grad.abs().max())
+    assert float((bn.running_mean.double() - ref_bn.running_mean).abs().max()) < 1e-6
+    assert float((bn.running_var.double() - ref_bn.running_var).abs().max()) < 1e-6 * float(ref_bn.running_var.abs().max())
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+    # eval mode and half the switch: the modules themselves
+    bn.eval()
+    assert torch.equal(ops.bn_relu(x.detach(), bn), torch.relu(bn(x.detach())))

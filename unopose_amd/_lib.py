@@ -55,6 +55,9 @@ SIGNATURES = {
     "unopose_vit_attention_f32": [_P, _I, _I, _I, _P, _P],
     "unopose_vit_attention_f32_split": [_P, _I, _I, _I, _P, _P],
     "unopose_vit_attention_f32_ss": [_P, _I, _I, _I, _P, _P],
+    "unopose_bn_train_chunk": [],
+    "unopose_bn_relu_train_forward": [_P, _I, _I, ctypes.c_long, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    "unopose_bn_relu_train_backward": [_P, _P, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "unopose_vit_attention": [_P, _I, _I, _I, _P, _P],
     "unopose_add_layernorm": [_P, _I, _P, _I, _P, _P, ctypes.c_long, _I, _F, _P, _I, _P],
     "unopose_add_layernorm_strided": [_P, _I, _P, _I, _P, _P, ctypes.c_long, _I, _F, _P, _I, ctypes.c_long, _P],

@@ -32,7 +32,7 @@ FLAGS = ["-O3", "-fno-slp-vectorize", "-fno-vectorize", "-std=c++17", "-fPIC", "
 # loop had 288 v_max for 112 logical maxima).  Not applied to the index-producing files (pointnet2, geom,
 # posehead), whose NaN behaviour follows the reference's fminf / fmaxf semantics.
 EXTRA_FLAGS = {f: ["-fno-honor-nans"] for f in
-               ("pe.hip", "embed.hip", "attn.hip", "attn_f32.hip", "vit_attn.hip", "vit_attn_f32s.hip", "linattn.hip", "fused.hip", "gemm.hip", "gemm_small.hip", "fineassign.hip")}
+               ("pe.hip", "embed.hip", "attn.hip", "attn_f32.hip", "vit_attn.hip", "vit_attn_f32s.hip", "linattn.hip", "bn_train.hip", "fused.hip", "gemm.hip", "gemm_small.hip", "fineassign.hip")}
 
 
 def _hipcc():

@@ -503,7 +503,7 @@ class _SharedMLP(nn.Module):
         """(B,C,N,S) through the unfolded layers: 1x1 Conv2d -> BatchNorm2d (train or eval statistics per module mode) ->
         ReLU.  The inference path never calls this (csrc/pe.hip runs the BN-folded chain); training does."""
         for l in self.layers():
-            x = F.relu(l.normlayer.bn(l.conv(x)))
+            x = ops.bn_relu(l.conv(x), l.normlayer.bn)  # train mode on the GPU: csrc/bn_train.hip (batch statistics + ReLU, fwd + bwd)
         return x
 
 

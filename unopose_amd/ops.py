@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from ._lib import call, check_f32, ptr, stream_ptr
+from ._lib import call, check_f32, lib, ptr, stream_ptr
 
 
 def _c(x):
@@ -311,6 +311,62 @@ def infonce_two_way(atten, label1, label2):
 
 
 # ---- trainable linears: forward and input gradient on the hand-written GEMMs, recorded by autograd ------
+USE_FUSED_BN_RELU = True  # A/B attribute: False = nn.BatchNorm2d (MIOpen) + F.relu in the PE's SharedMLP under train()
+
+
+class _BNReLUTrain(torch.autograd.Function):
+    """relu(batch_norm(x)) with BATCH statistics (nn.BatchNorm2d in train mode + ReLU, pytorch_utils.py:25-132) on csrc/bn_train.hip:
+    forward = statistics pass + apply pass (running statistics updated in the statistics kernel), backward = reduction pass + apply
+    pass with the ReLU mask recomputed from x; saved for backward: x, mean, rstd (not y, not the mask)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn):
+        B, C = x.shape[:2]
+        L = x.numel() // (B * C)
+        x = _c(x)
+        chunk = lib().unopose_bn_train_chunk()
+        ws = torch.empty(2 * B * C * ((L + chunk - 1) // chunk), dtype=torch.float32, device=x.device)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        y = torch.empty_like(x)
+        track = bn.track_running_stats and bn.running_mean is not None
+        if track:
+            bn.num_batches_tracked.add_(1)
+            momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item())
+        else:
+            momentum = 0.0
+        w, b_ = _c(weight.detach().float()), _c(bias.detach().float())
+        with torch.cuda.device(x.device):
+            call("unopose_bn_relu_train_forward", ptr(x), B, C, L, ptr(w), ptr(b_), float(bn.eps), float(momentum),
+                 ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None, ptr(ws), ptr(mean), ptr(rstd), ptr(y), stream_ptr())
+        ctx.save_for_backward(x, w, b_, mean, rstd)
+        ctx.dims = (B, C, L)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b_, mean, rstd = ctx.saved_tensors
+        B, C, L = ctx.dims
+        dy = _c(dy.float())
+        chunk = lib().unopose_bn_train_chunk()
+        ws = torch.empty(2 * B * C * ((L + chunk - 1) // chunk), dtype=torch.float32, device=x.device)
+        dgamma, dbeta, dx = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            call("unopose_bn_relu_train_backward", ptr(x), ptr(dy), B, C, L, ptr(w), ptr(b_), ptr(mean), ptr(rstd), ptr(ws), ptr(dgamma), ptr(dbeta),
+                 ptr(dx), stream_ptr())
+        return dx, dgamma, dbeta, None
+
+
+def bn_relu(x, bn):
+    """F.relu(bn(x)) for an nn.BatchNorm2d: the fused training form (csrc/bn_train.hip) when `bn` is in train mode on fp32 CUDA data
+    with affine parameters, else the modules themselves (eval statistics, CPU, other dtypes)."""
+    L = x[0, 0].numel() if x.dim() >= 3 else 0
+    if (USE_FUSED_BN_RELU and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and L % 4 == 0 and L >= 4
+            and bn.weight is not None and bn.bias is not None and x.shape[0] <= 65535 and x.shape[1] <= 65535):
+        return _BNReLUTrain.apply(x, bn.weight, bn.bias, bn)
+    return F.relu(bn(x))
+
+
 TRAIN_OWN_GEMM = True  # A/B attribute: False = nn.Linear through the library
 # The persistent 256 x 256-tile kernels pay off from a few tens of GFLOP per launch (measured at the training shapes: a
 # 32 776 x 256 x 256 linear takes 38 us on csrc/gemm_f32.hip and 17 us on the library, the 4096 x 3072 x 4096 up-projection
