@@ -176,3 +176,49 @@ def test_strided_linear_matches_the_dense_path():
     cp = torch.zeros(M, N + 8, device="cuda", dtype=torch.bfloat16)
     call("unopose_linear_bf16_ld", ptr(ap), K + 64, ptr(wp), K + 128, ptr(b), ptr(cp), N + 8, M, N, K, 1, stream_ptr())
     assert torch.equal(cp[:, :N], want) and float(cp[:, N:].abs().max()) == 0.0  # pad columns of A / W never read, of C never written
+
+
+@torch.no_grad()
+def test_dynamic_tile_tickets_are_placement_independent():
+    """The persistent kernel draws its tiles as tickets (csrc/gemm_kernel.h): which workgroup computes which tile depends on when it is
+    dispatched.  The result must not: the same GEMM alone, beside a kernel of another stream that holds CUs for milliseconds (the
+    5000 -> 2048 FPS: one 512-thread workgroup per cloud) and beside another persistent GEMM of a third stream is bit-identical, launch
+    after launch -- including past the 1024-slot ring of ticket counters (every slot re-zeroed by its launch's last workgroup)."""
+    from unopose_amd import _lib
+    from unopose_amd.pointnet2 import _ext
+
+    g = torch.Generator().manual_seed(7)
+    M, K, N = 64 * 1374, 768, 768  # 1032 tiles on 256 CUs: several rounds of tickets per workgroup, ragged last row panel
+    a = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().cuda()
+    b = torch.randn(N, generator=g).cuda()
+    a2 = torch.randn(40000, 3072, generator=g).bfloat16().cuda()
+    w2 = (torch.randn(768, 3072, generator=g) / 55).bfloat16().cuda()
+    tem = torch.rand(32, 5000, 3, generator=g).cuda()
+    side, third = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def run(out, x=a, ww=w, n=N, k=K, gelu=False):
+        _lib.call("unopose_linear_bf16", _lib.ptr(x), _lib.ptr(ww), _lib.ptr(b), _lib.ptr(out), x.shape[0], n, k, 1 if gelu else 0, _lib.stream_ptr())
+
+    want = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    run(want)
+    torch.cuda.synchronize()
+    ref = (a[:2048].float() @ w.float().t() + b)
+    assert ((want[:2048].float() - ref).abs() <= ref.abs() * 2.0 ** -8 + 1e-3).all()
+    outs = [torch.empty_like(want) for _ in range(4)]
+    o2 = torch.empty(40000, 768, dtype=torch.bfloat16, device="cuda")
+    for rnd in range(3):
+        with torch.cuda.stream(side):
+            _ext.furthest_point_sampling(tem, 2048)  # 32 CUs held for ~1.9 ms
+        with torch.cuda.stream(third):
+            run(o2, a2, w2, 768, 3072, True)        # another ticketed launch in flight at the same time (its own slot)
+        for o in outs:
+            run(o)
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, want), rnd
+    for i in range(1100):  # the ring comes round: slot i % 1024 is reused
+        run(outs[i & 3])
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, want)
