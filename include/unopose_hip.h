@@ -117,6 +117,15 @@ int unopose_lrf_global(const float *pts, int B, int N, int use_ref_rad,
 int unopose_query_lrf_group(const float *xyz, int B, int N, float radius,
                             int nsample, float *out, unopose_stream_t stream);
 
+/* The general form of QueryAndLRFGroup.forward (new_xyz != xyz and/or sample_uniformly):
+ * the neighbour lists idx (B,N,S) int32 are given (ball_query around new_xyz (B,N,3));
+ * out (B,6,N,S): channels 0-2 = p_k - new_xyz[j], 3-5 = R^T (p_k - xyz[j]) / radius with
+ * the frame of LRF_batch(xyz, grouped) -- the reference passes xyz, not new_xyz, as the
+ * frame centres (core/unopose/model/pointnet2/pointnet2_utils.py:548-565), so npoint == N. */
+int unopose_lrf_group_idx(const float *xyz, const float *new_xyz, const int *idx,
+                          int B, int N, float radius, int nsample, float *out,
+                          unopose_stream_t stream);
+
 /* weighted_procrustes(src (M,N,3), ref (M,N,3), w (M,N) or NULL) -> R (M,3,3),
  * t (M,3) with ref ~ R src + t.  Replaces
  * core/unopose/utils/model_utils.py:667-743 (torch.svd -> register Jacobi). */

@@ -203,3 +203,94 @@ def test_procrustes_degenerate_inputs_are_rotations():
     assert torch.allclose(R[2], torch.tensor([[0., -1, 0], [1, 0, 0], [0, 0, 1]]), atol=1e-5)
     # rank 1: the correspondences themselves are still mapped exactly
     assert torch.allclose(src[1] @ R[1].T + t.cpu()[1], ref[1], atol=1e-5)
+
+
+# ---------------------------------------------------------------- the other QueryAndGroup / QueryAndLRFGroup options ------
+def _oracle_lrf_group(oracle_ext, x, new, r, ns, idx=None):
+    """P:548-565 step by step on the CPU oracle: (idx, grouped - new (B,3,N,S), lrf (B,3,N,S), grouped - xyz)."""
+    from oracle import unopose_ref as R
+
+    if idx is None:
+        idx = oracle_ext.ball_query(new.contiguous(), x.contiguous(), r, ns)
+    grouped = oracle_ext.group_points(x.transpose(1, 2).contiguous(), idx)
+    lrf = R.lrf_batch(x, grouped.transpose(1, 2), r).transpose(1, 2)
+    return idx, grouped - new.transpose(1, 2).unsqueeze(-1), lrf, grouped - x.transpose(1, 2).unsqueeze(-1)
+
+
+def test_query_and_lrf_group_centres_off_the_points_and_all_options(oracle_ext):
+    """new_xyz != xyz, normalize_xyz, ret_grouped_xyz, use_feature (P:484-584): the neighbour lists are the balls around
+    new_xyz, channels 0-2 are relative to new_xyz (divided by the radius), the frame stays centred on xyz (P:555)."""
+    from unopose_amd.pointnet2 import pointnet2_utils as P
+
+    r, ns = 0.2, 32
+    x = norm_clouds(1024, 2, seed=5, repl_every=9)
+    g = torch.Generator().manual_seed(6)
+    new = (x + 0.03 * torch.randn(x.shape, generator=g)).contiguous()
+    feats = torch.randn(2, 5, 1024, generator=g)
+    idx, rel_new, lrf, rel_x = _oracle_lrf_group(oracle_ext, x, new, r, ns)
+
+    m = P.QueryAndLRFGroup(r, ns, use_xyz=True, use_feature=True, normalize_xyz=True, ret_grouped_xyz=True)
+    out, grouped = m(x.cuda(), new.cuda(), feats.cuda())
+    out, grouped = out.cpu(), grouped.cpu()
+    assert out.shape == (2, 5 + 6, 1024, ns) and grouped.shape == (2, 3, 1024, ns)
+    assert torch.equal(out[:, :5], oracle_ext.group_points(feats, idx))
+    # `tensor / python_float` on the device is a multiply by the reciprocal (1 ulp from the host's true division), in the reference too
+    torch.testing.assert_close(grouped, rel_new / r, rtol=3e-7, atol=0)
+    assert torch.equal(out[:, 5:8], grouped)
+    err = (out[:, 8:] - lrf).abs().amax(dim=(1, 3))
+    well = _well_conditioned(torch.cat([rel_x, lrf], 1), r)
+    assert well.float().mean() > 0.85, well.float().mean()
+    assert err[well].max() < 2e-3, err[well].max()
+    # not normalised, lrf only (use_xyz=False needs features, P:561-566) and the features=None form
+    only = P.QueryAndLRFGroup(r, ns, use_xyz=False)(x.cuda(), new.cuda(), feats.cuda()).cpu()
+    assert torch.equal(only, out[:, 8:])
+    both = P.QueryAndLRFGroup(r, ns, use_xyz=True)(x.cuda(), new.cuda(), feats.cuda()).cpu()
+    assert torch.equal(both[:, :3], rel_new) and torch.equal(both[:, 3:], only)
+    assert torch.equal(P.QueryAndLRFGroup(r, ns, use_xyz=True)(x.cuda(), new.cuda()).cpu(), only)
+    # centres == points through the general route is the fused kernel's answer, bit for bit
+    xc = x.cuda()
+    fused = P.QueryAndLRFGroup(r, ns, use_xyz=True)(xc, xc, feats.cuda())
+    general = P.QueryAndLRFGroup(r, ns, use_xyz=True)(xc, xc.clone(), feats.cuda())
+    assert torch.equal(fused, general)
+    with pytest.raises(ValueError, match="npoint == N"):
+        P.QueryAndLRFGroup(r, ns, use_xyz=True)(xc, xc[:, :512].contiguous(), feats.cuda())
+
+
+@pytest.mark.parametrize("cls", ["QueryAndGroup", "QueryAndLRFGroup"])
+def test_sample_uniformly_redraws_every_neighbour_list_from_its_distinct_members(oracle_ext, cls):
+    """sample_uniformly / ret_unique_cnt (P:343-351, 536-544): every list becomes its distinct indices (ascending) followed by
+    uniform draws from them, unique_cnt counts them; everything downstream is computed from the re-drawn lists."""
+    from unopose_amd.pointnet2 import pointnet2_utils as P
+
+    r, ns = 0.15, 32
+    x = norm_clouds(512, 2, seed=8, repl_every=9)
+    xc = x.cuda()
+    torch.manual_seed(0)
+    m = getattr(P, cls)(r, ns, use_xyz=True, ret_grouped_xyz=True, sample_uniformly=True, ret_unique_cnt=True)
+    out, grouped, cnt = m(xc, xc, None if cls == "QueryAndGroup" else torch.zeros(2, 1, 512, device="cuda"))
+    assert cnt.shape == (2, 512) and cnt.dtype == torch.float32 and cnt.device.type == "cpu"
+    base = oracle_ext.ball_query(x, x, r, ns)
+    # recover the re-drawn lists from the grouped coordinates (the clouds hold no duplicate points) and check them row by row
+    got = grouped.cpu().permute(0, 2, 3, 1) + x.unsqueeze(2)  # (B,N,S,3) absolute coordinates
+    redrawn = torch.cdist(got.reshape(2, -1, 3), x).argmin(-1).reshape(2, 512, ns)
+    back = x.gather(1, redrawn.reshape(2, -1, 1).expand(-1, -1, 3)).reshape(2, 512, ns, 3)
+    assert (back - got).abs().max() < 1e-5  # (p - c) + c is p up to rounding
+    multi = 0
+    for b in range(2):
+        for j in range(512):
+            u = torch.unique(base[b, j].long())
+            n = len(u)
+            assert cnt[b, j] == n
+            assert torch.equal(redrawn[b, j, :n], u)
+            assert torch.isin(redrawn[b, j, n:], u).all()
+            multi += int(len(torch.unique(redrawn[b, j, n:])) > 1)
+    assert multi > 100  # the tails are draws, not one repeated index
+    if cls == "QueryAndLRFGroup":
+        _, rel_new, lrf, rel_x = _oracle_lrf_group(oracle_ext, x, x, r, ns, idx=redrawn.int())
+        out = out.cpu()
+        assert torch.equal(out[:, :3], rel_new)
+        well = _well_conditioned(torch.cat([rel_x, lrf], 1), r)
+        err = (out[:, 3:] - lrf).abs().amax(dim=(1, 3))
+        assert well.float().mean() > 0.5 and err[well].max() < 2e-3, (well.float().mean(), err[well].max())
+    else:
+        assert torch.equal(out, grouped)

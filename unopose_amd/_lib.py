@@ -33,6 +33,7 @@ SIGNATURES = {
     "unopose_three_interpolate_grad": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "unopose_lrf_global": [_P, _I, _I, _I, _P, _P],
     "unopose_query_lrf_group": [_P, _I, _I, _F, _I, _P, _P],
+    "unopose_lrf_group_idx": [_P, _P, _P, _I, _I, _F, _I, _P, _P],
     "unopose_weighted_procrustes": [_P, _P, _P, _I, _I, _F, _F, _P, _P, _P],
     "unopose_assign_labels": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "unopose_linear_bf16_ld": [_P, _I, _P, _I, _P, _P, _I, ctypes.c_long, _I, _I, _I, _P],

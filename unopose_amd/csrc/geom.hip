@@ -121,8 +121,13 @@ __device__ float *g_lrf_dbg;
 // One wavefront per centre.  LDS: SoA copy of the cloud + one neighbour list per wave.
 // out (B,6,N,S): channels 0-2 = p_k - c (un-normalised), 3-5 = R^T (p_k - c) / radius
 // (pointnet2_utils.py:567 channel order).
+// IDX (the general form of QueryAndLRFGroup.forward, pointnet2_utils.py:548-565): the neighbour lists come from `idx_in` (B,N,S) --
+// ball_query around `new_xyz`, optionally re-drawn by sample_uniformly -- channels 0-2 are relative to new_xyz[j] while the frame and
+// channels 3-5 stay relative to xyz[j] (P:555 passes `xyz`, not `new_xyz`, to LRF_batch).
+template <bool IDX>
 __global__ __launch_bounds__(256) void query_lrf_group_kernel(const float *__restrict__ xyz, int N, float radius,
-                                                              int S, int cpw, float *__restrict__ out) {
+                                                              int S, int cpw, float *__restrict__ out,
+                                                              const float *__restrict__ new_xyz, const int *__restrict__ idx_in) {
   extern __shared__ float4 smem4[];
   float *sx = reinterpret_cast<float *>(smem4);
   float *sy = sx + N, *sz = sy + N;
@@ -146,9 +151,20 @@ __global__ __launch_bounds__(256) void query_lrf_group_kernel(const float *__res
     const int j = (blockIdx.x * 4 + wave) * cpw + ci;
     if (j >= N) break;  // wave-uniform
     const float cx = sx[j], cy = sy[j], cz = sz[j];
-    // ---- ball query: first S hits in index order, tail padded with the first hit
+    float qx = cx, qy = cy, qz = cz;  // the centre channels 0-2 are relative to
     int cnt = 0, first = 0;
-    for (int k0 = 0; k0 < N && cnt < S; k0 += 64) {
+    if constexpr (IDX) {
+      const float *q = new_xyz + ((size_t)b * N + j) * 3;
+      qx = q[0]; qy = q[1]; qz = q[2];
+      const int *row_in = idx_in + ((size_t)b * N + j) * S;
+      for (int l = lane; l < S; l += 64) {
+        const int k = row_in[l];
+        nbr[l] = (unsigned)k < (unsigned)N ? k : 0;
+      }
+      cnt = S;
+    }
+    // ---- ball query: first S hits in index order, tail padded with the first hit
+    for (int k0 = 0; !IDX && k0 < N && cnt < S; k0 += 64) {
       const int k = k0 + lane;
       bool hit = false;
       if (k < N) {
@@ -255,9 +271,9 @@ __global__ __launch_bounds__(256) void query_lrf_group_kernel(const float *__res
       const int k = nbr[l];
       const Vec3 d = v3(sx[k] - cx, sy[k] - cy, sz[k] - cz);
       const Vec3 q = v3(d.x / radius, d.y / radius, d.z / radius);
-      row[l] = d.x;
-      row[chan + l] = d.y;
-      row[2 * chan + l] = d.z;
+      row[l] = IDX ? sx[k] - qx : d.x;
+      row[chan + l] = IDX ? sy[k] - qy : d.y;
+      row[2 * chan + l] = IDX ? sz[k] - qz : d.z;
       row[3 * chan + l] = dot(xp, q);
       row[4 * chan + l] = dot(yp, q);
       row[5 * chan + l] = dot(zp, q);
@@ -396,16 +412,30 @@ int unopose_query_lrf_group(const float *xyz, int B, int N, float radius, int ns
   static const long lds_probe = getenv("UNOPOSE_QLG_LDS_PROBE") ? atol(getenv("UNOPOSE_QLG_LDS_PROBE")) : 0;
   if (lds_probe > (long)lds) {
     static bool opt[64];
-    if (lds_optin(opt, (const void *)query_lrf_group_kernel, (size_t)lds_probe, "query_lrf_group") != UNOPOSE_OK) return UNOPOSE_ELAUNCH;
+    if (lds_optin(opt, (const void *)query_lrf_group_kernel<false>, (size_t)lds_probe, "query_lrf_group") != UNOPOSE_OK) return UNOPOSE_ELAUNCH;
     lds = (size_t)lds_probe;
   }
 #endif
   const long centres = (long)B * N;
   int cpw = centres >= 65536 ? 8 : centres >= 16384 ? 4 : centres >= 4096 ? 2 : 1;
   dim3 grid(cdiv(N, 4 * cpw), B);
-  hipLaunchKernelGGL(query_lrf_group_kernel, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius, nsample, cpw,
-                     out);
+  hipLaunchKernelGGL(query_lrf_group_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius, nsample, cpw,
+                     out, (const float *)nullptr, (const int *)nullptr);
   return check_launch("query_lrf_group");
+}
+
+int unopose_lrf_group_idx(const float *xyz, const float *new_xyz, const int *idx, int B, int N, float radius, int nsample,
+                          float *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(xyz && new_xyz && idx && out, "lrf_group_idx: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && N >= 1 && nsample >= 1 && B <= 65535, "lrf_group_idx: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  const size_t lds = ((size_t)3 * N + 4 * (size_t)nsample) * 4;
+  UNOPOSE_REQUIRE(lds <= 64 * 1024, "lrf_group_idx: N=%d nsample=%d exceed the 64 KiB LDS tile", N, nsample);
+  const long centres = (long)B * N;
+  const int cpw = centres >= 65536 ? 8 : centres >= 16384 ? 4 : centres >= 4096 ? 2 : 1;
+  hipLaunchKernelGGL(query_lrf_group_kernel<true>, dim3(cdiv(N, 4 * cpw), B), dim3(256), lds, (hipStream_t)stream, xyz, N, radius,
+                     nsample, cpw, out, new_xyz, idx);
+  return check_launch("lrf_group_idx");
 }
 
 int unopose_weighted_procrustes(const float *src, const float *ref, const float *w, int M, int N, float thresh,

@@ -65,6 +65,27 @@ def query_lrf_group(xyz, radius, nsample):
     return out
 
 
+def lrf_group_idx(xyz, new_xyz, idx, radius):
+    """The general form of QueryAndLRFGroup.forward (pointnet2_utils.py:548-565): neighbour lists `idx` (B,N,S) int32 given
+    (ball_query around `new_xyz`, possibly re-drawn by sample_uniformly) -> (B,6,N,S) with channels 0-2 relative to
+    new_xyz and the frame / channels 3-5 relative to xyz, as the reference computes them."""
+    xyz, new_xyz = _c(xyz.float()), _c(new_xyz.float())
+    check_f32(xyz, "xyz")
+    check_f32(new_xyz, "new_xyz")
+    if new_xyz.shape != xyz.shape:
+        raise ValueError(f"QueryAndLRFGroup: LRF_batch(xyz, grouped) needs npoint == N, got xyz {tuple(xyz.shape)} "
+                         f"new_xyz {tuple(new_xyz.shape)} (pointnet2_utils.py:432-436)")
+    idx = _c(idx.to(torch.int32))
+    B, N, _ = xyz.shape
+    if idx.shape[:2] != (B, N) or not idx.is_cuda:
+        raise ValueError(f"idx must be a (B,N,S) device tensor, got {tuple(idx.shape)}")
+    S = idx.shape[2]
+    out = torch.empty(B, 6, N, S, dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        call("unopose_lrf_group_idx", ptr(xyz), ptr(new_xyz), ptr(idx), B, N, float(radius), S, ptr(out), stream_ptr())
+    return out
+
+
 def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
     """weighted_procrustes (utils/model_utils.py:667-743): R (M,3,3), t (M,3), ref ~ R src + t."""
     src, ref = _c(src.float()), _c(ref.float())

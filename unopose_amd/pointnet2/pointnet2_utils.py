@@ -108,19 +108,40 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+def _resample_uniformly(idx, nsample):
+    """The reference's ``sample_uniformly`` loop (pointnet2_utils.py:343-351, 536-544) for all rows at once, on the device:
+    each neighbour list becomes [its distinct indices, ascending] + [picks drawn uniformly with replacement from them], and
+    ``unique_cnt`` (B,npoint) counts the distinct ones.  The picks are random in the reference too (torch.randint), so
+    only the distribution is reproducible, not the draw."""
+    s, _ = idx.sort(dim=-1)
+    first = torch.ones_like(s, dtype=torch.bool)
+    first[..., 1:] = s[..., 1:] != s[..., :-1]
+    cnt = first.sum(-1, keepdim=True)  # (B,P,1)
+    order = torch.sort((~first).to(torch.int8), dim=-1, stable=True).indices  # distinct entries first, still ascending
+    uniq = s.gather(-1, order)
+    pick = (torch.rand(idx.shape, device=idx.device) * cnt).long().minimum(cnt - 1)
+    slot = torch.arange(nsample, device=idx.device).expand_as(idx)
+    out = torch.where(slot < cnt, uniq, uniq.gather(-1, pick))
+    # the reference builds unique_cnt with torch.zeros(...) on the host (P:344); same dtype and device here
+    return out.to(idx.dtype).contiguous(), cnt.squeeze(-1).float().cpu()
+
+
 class QueryAndGroup(nn.Module):
-    """pointnet2_utils.py:292-367 (without the host-side ``sample_uniformly`` loop)."""
+    """pointnet2_utils.py:292-367."""
 
     def __init__(self, radius, nsample, use_xyz=True, ret_grouped_xyz=False, normalize_xyz=False,
                  sample_uniformly=False, ret_unique_cnt=False):
         super().__init__()
-        if sample_uniformly or ret_unique_cnt:
-            raise NotImplementedError("sample_uniformly is a per-row host loop in the reference; not on the hot path")
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
         self.ret_grouped_xyz, self.normalize_xyz = ret_grouped_xyz, normalize_xyz
+        self.sample_uniformly, self.ret_unique_cnt = sample_uniformly, ret_unique_cnt
+        if ret_unique_cnt:
+            assert sample_uniformly
 
     def forward(self, xyz, new_xyz, features=None):
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        if self.sample_uniformly:
+            idx, unique_cnt = _resample_uniformly(idx, self.nsample)
         grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
         grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
         if self.normalize_xyz:
@@ -131,29 +152,57 @@ class QueryAndGroup(nn.Module):
         else:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
             new_features = grouped_xyz
-        return (new_features, grouped_xyz) if self.ret_grouped_xyz else new_features
+        ret = [new_features]
+        if self.ret_grouped_xyz:
+            ret.append(grouped_xyz)
+        if self.ret_unique_cnt:
+            ret.append(unique_cnt)
+        return ret[0] if len(ret) == 1 else tuple(ret)
 
 
 class QueryAndLRFGroup(nn.Module):
-    """pointnet2_utils.py:484-584.  Output channels [p_k - c (3), R^T (p_k - c) / radius (3)]."""
+    """pointnet2_utils.py:484-584.  Output channels [p_k - c (3), R^T (p_k - c) / radius (3)].  Called the way UNOPose calls it
+    (centres are the points themselves, no re-sampling) it is ONE fused ball-query + group + frame kernel; any other
+    configuration takes ball_query -> (sample_uniformly) -> the same frame kernel fed with the neighbour lists."""
 
     def __init__(self, radius, nsample, use_xyz=False, use_feature=False, ret_grouped_xyz=False,
                  normalize_xyz=False, sample_uniformly=False, ret_unique_cnt=False):
         super().__init__()
-        if sample_uniformly or ret_unique_cnt or normalize_xyz or ret_grouped_xyz:
-            raise NotImplementedError("only the options UNOPose configures are built")
         self.radius, self.nsample, self.use_xyz, self.use_feature = radius, nsample, use_xyz, use_feature
+        self.ret_grouped_xyz, self.normalize_xyz = ret_grouped_xyz, normalize_xyz
+        self.sample_uniformly, self.ret_unique_cnt = sample_uniformly, ret_unique_cnt
+        if ret_unique_cnt:
+            assert sample_uniformly
 
     def forward(self, xyz, new_xyz, features=None):
-        same = new_xyz is xyz or (new_xyz.shape == xyz.shape and new_xyz.data_ptr() == xyz.data_ptr())
-        if not same:
-            raise NotImplementedError("the fused kernel is built for centres == points (how UNOPose calls it)")
-        fused = ops.query_lrf_group(xyz, self.radius, self.nsample)  # (B,6,N,S)
-        if features is None:
-            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-            return fused[:, 3:]
-        new_features = fused if self.use_xyz else fused[:, 3:]
-        if self.use_feature:
+        same = new_xyz is xyz or (new_xyz.shape == xyz.shape and new_xyz.data_ptr() == xyz.data_ptr()
+                                  and new_xyz.stride() == xyz.stride())
+        idx = unique_cnt = None
+        if same and not self.sample_uniformly:
+            fused = ops.query_lrf_group(xyz, self.radius, self.nsample)  # (B,6,N,S)
+        else:
             idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
-            new_features = torch.cat([grouping_operation(features, idx), new_features], dim=1)
-        return new_features
+            if self.sample_uniformly:
+                idx, unique_cnt = _resample_uniformly(idx, self.nsample)
+            fused = ops.lrf_group_idx(xyz, new_xyz, idx, self.radius)
+        grouped_xyz, lrf_features = fused[:, :3], fused[:, 3:]
+        if self.normalize_xyz:
+            grouped_xyz = grouped_xyz / self.radius
+        if features is not None:
+            if not self.use_xyz:
+                new_features = lrf_features
+            else:  # the kernel's own (B,6,N,S) layout is already [grouped_xyz, lrf]
+                new_features = torch.cat([grouped_xyz, lrf_features], dim=1) if self.normalize_xyz else fused
+            if self.use_feature:
+                if idx is None:
+                    idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+                new_features = torch.cat([grouping_operation(features, idx), new_features], dim=1)
+        else:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            new_features = lrf_features
+        ret = [new_features]
+        if self.ret_grouped_xyz:
+            ret.append(grouped_xyz)
+        if self.ret_unique_cnt:
+            ret.append(unique_cnt)
+        return ret[0] if len(ret) == 1 else tuple(ret)
