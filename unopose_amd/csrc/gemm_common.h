@@ -19,10 +19,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define GEMM_OPBYTES (256 * GEMM_ROWB)    // one operand stage: 32 KiB
 #define GEMM_BUFBYTES (2 * GEMM_OPBYTES)  // A + W: 64 KiB
 #ifndef GEMM_GM
-#define GEMM_GM 4  // row panels per patch of co-resident tiles
+#define GEMM_GM 1  // row panels per group of the tile order (1: row-major, the tiles sharing an A panel are neighbours in the sequence)
 #endif
 #ifndef GEMM_SKEW
-#define GEMM_SKEW 4  // tiles sharing a panel start 0..SKEW-1 stages apart
+#define GEMM_SKEW 1  // tiles sharing a panel start 0..SKEW-1 K-tiles apart (1: together -- measured: least fabric traffic, same time)
 #endif
 
 // 0.5 x (1 + erf(x / sqrt 2)); erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), z >= 0
@@ -58,12 +58,19 @@ __device__ __forceinline__ float gelu_bf16_class(float x) {
 // descriptor + per-lane byte offset (VGPR) + scalar offset.  Issued from inline asm: the compiler does not see an LDS write
 // and so keeps its own s_waitcnt vmcnt out of the LDS reads; the waits on DMA data are the explicit vmcnt + barrier pairs of
 // the kernels.
+template <int POL = 0>  // cache policy of the load: 0 default, 1 nt (streamed: first to leave L2), 2 sc1, 3 sc0 sc1 nt
 __device__ __forceinline__ void gemm_dma16(uint32_t lds_byte, uint32_t vo, __amdgpu_buffer_rsrc_t rs, int so) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "s"(__builtin_amdgcn_readfirstlane(lds_byte)), "v"(vo), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(so))
-               : "memory");
+#define GEMM_DMA16_ASM(POLSTR)                                                                                                          \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen" POLSTR " lds\n\ts_mov_b32 m0, %0" \
+               : "=&s"(keep)                                                                                                            \
+               : "s"(__builtin_amdgcn_readfirstlane(lds_byte)), "v"(vo), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(so))               \
+               : "memory")
+  if constexpr (POL == 1) GEMM_DMA16_ASM(" nt");
+  else if constexpr (POL == 2) GEMM_DMA16_ASM(" sc1");
+  else if constexpr (POL == 3) GEMM_DMA16_ASM(" sc0 sc1 nt");
+  else GEMM_DMA16_ASM("");
+#undef GEMM_DMA16_ASM
 }
 
 // Small-tile kernels (gemm_small.hip): 128 x 128 tiles for epilogue 0 / 1 / 2, 64 x 256 tiles for the residual + LayerNorm epilogue.

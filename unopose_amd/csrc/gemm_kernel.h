@@ -14,6 +14,15 @@ namespace unopose {
 #ifndef GEMM_SAME
 #define GEMM_SAME 0  // probe: every tile streams the operands of tile (0, 0) -- an all-hit L2 stream under the full K loop
 #endif
+#ifndef GEMM_POLA
+#define GEMM_POLA 0  // cache policy of the A / W operand streams (gemm_dma16<POL>)
+#endif
+#ifndef GEMM_POLW
+#define GEMM_POLW 0
+#endif
+#ifndef GEMM_CW
+#define GEMM_CW -1  // column-blocked tile walk: column tiles per block (0: never; -1: chosen from the size of W, see the kernel)
+#endif
 #ifndef GEMM_PRIO
 #define GEMM_PRIO 0  // 1 = s_setprio 1 around the MFMA segment (measured: -1..2 % with 16-MFMA segments; scripts/ubench/gemm_r04_variants.hip)
 #endif
@@ -90,12 +99,25 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
   // 130 KiB of LDS admits one per CU).  Workgroup b sits on XCD b % 8 (observed dispatch rule: a SPEED assumption
   // only) and is slot b / 8 of that XCD; XCD x owns one contiguous range of the tile sequence and its slots take
   // tiles slot, slot + nslots, ... of it.  All workgroups start together and every tile costs the same, so the ~32
-  // tiles an XCD has in flight are 32 CONSECUTIVE tiles walking K in lock step: a (GEMM_GM x 32/GEMM_GM) patch of the
-  // output that shares GEMM_GM A panels and 32/GEMM_GM W panels K-slice by K-slice in that XCD's L2.
+  // tiles an XCD has in flight are 32 CONSECUTIVE tiles walking K in lock step.  The order is row-major (GEMM_GM = 1): the tiles
+  // that share an A panel are neighbours in the sequence, hence closest in time, and start on the same K-tile (GEMM_SKEW = 1) --
+  // round 4's counters: fabric reads of the four ViT linears 2691 -> 1668 MB per layer against (GM 4, SKEW 4), same time.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  const int cq = tiles >> 3, cr = tiles & 7;
-  const int chunk_base = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, chunk_len = cq + (xcd < cr ? 1 : 0);
   const int tiles_m = tiles / tiles_n, per_group = GEMM_GM * tiles_n;
+  // Column-blocked walk: XCD x owns a contiguous range of ROW PANELS and walks it once per block of `cw` column tiles, so the
+  // block's W panels stay in that XCD's 4 MiB L2 while its share of A streams through.  Used when W as a whole does not fit
+  // (fc1: 4.7 MB; measured fabric reads 646 -> 417 MB per launch) and the row panels split evenly enough over the 8 XCDs.
+  int cw = GEMM_CW;
+  if (GEMM_CW < 0) {
+    cw = (size_t)N * K * ESZ > (size_t)(4u << 20) ? (2400 * 1024) / (GEMM_BN * K * ESZ) : 0;
+    if (cw < 3) cw = 0;
+  }
+  const bool colwalk = cw > 0 && !GATHER && tiles_n > cw && ((tiles_m & 7) == 0 || tiles_m >= 512);
+  const int rq = tiles_m >> 3, rr = tiles_m & 7;
+  const int rows_x = rq + (xcd < rr ? 1 : 0), row_base = xcd < rr ? xcd * (rq + 1) : rr * (rq + 1) + (xcd - rr) * rq;
+  const int cq = tiles >> 3, cr = tiles & 7;
+  const int chunk_base = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+  const int chunk_len = colwalk ? rows_x * tiles_n : cq + (xcd < cr ? 1 : 0);
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, (int)((size_t)M * LDA * ESZ), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, (int)((size_t)N * LDW * ESZ), 0x00020000);
   const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(Cv, 0, GATHER ? 0x7fffffff : (int)((size_t)M * LDC * 2), 0x00020000);  // (bf16 form)
@@ -129,6 +151,15 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
       const int ng = N / GEMM_BN;
       for (int g = 1; g < ng; ++g) tn += t >= tile_info[1 + g] ? 1 : 0;  // the group of tile t (uniform scalar loads)
       tn = __builtin_amdgcn_readfirstlane(tn);
+    } else if (colwalk) {
+      const int per_block = rows_x * cw;
+      const int cb = ti / per_block, v = ti - cb * per_block;
+      const int cwb = min(cw, tiles_n - cb * cw);  // (the last block may be narrower)
+      const int g = v / (GEMM_GM * cwb), w = v - g * GEMM_GM * cwb;
+      const int gm = min(GEMM_GM, rows_x - g * GEMM_GM);
+      const int tl = w / gm;
+      tn = cb * cw + tl;
+      tm = row_base + g * GEMM_GM + (w - tl * gm);
     } else {
       // tile order: groups of GEMM_GM row panels, column tiles fastest across the group
       const int mg = t / per_group, rr = t - mg * per_group;
@@ -172,14 +203,14 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
     if (kind == H_A0 || kind == H_A1) {
       const int ah = kind == H_A1 ? 1 : 0;
       const uint32_t la = lds0 + bufoff + a_dst + ah * 8192;
-      gemm_dma16(la, p.a_off[2 * ah], a_rs, so);
-      gemm_dma16(la + 1024, p.a_off[2 * ah + 1], a_rs, so);
+      gemm_dma16<GEMM_POLA>(la, p.a_off[2 * ah], a_rs, so);
+      gemm_dma16<GEMM_POLA>(la + 1024, p.a_off[2 * ah + 1], a_rs, so);
     } else {
       const int bh = kind == H_B1 ? 1 : 0;
       const uint32_t lw = lds0 + bufoff + w_dst + bh * 4096;
       const int sob = so + bh * (32 * ESZ) * LDW;
-      gemm_dma16(lw, p.w_off[0], w_rs, sob);
-      gemm_dma16(lw + 1024, p.w_off[1], w_rs, sob);
+      gemm_dma16<GEMM_POLW>(lw, p.w_off[0], w_rs, sob);
+      gemm_dma16<GEMM_POLW>(lw + 1024, p.w_off[1], w_rs, sob);
     }
   };
   // the tile's 256 bias values (1 KiB) by LDS-DMA as well: no ordinary load sits between the stream's counted waits.  Every wave
