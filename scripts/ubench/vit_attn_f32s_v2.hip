@@ -5,13 +5,11 @@
 // [hi (32 bf16) | lo (32 bf16)], x = hi + lo to 2^-17): the qkv GEMM writes it in its epilogue and the projection GEMM reads it, so
 // this kernel never sees fp32 data and never splits an operand itself -- round 3's kernel (attn_f32.hip) read fp32 qkv and every one
 // of the 11 workgroups of an (image, head) re-split the whole K / V on its way into LDS, V^T through 2-byte LDS stores.
-// Structure: 12 waves x 32 queries per workgroup (3 waves per SIMD); K / V of a 128-key chunk (hi and lo planes, 65 KiB) arrive in
-// double-buffered LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 64 pieces of 1 KiB per chunk, per-lane source addresses pick the planes
-// apart; the K rows are XOR-swizzled on the SOURCE address, the V image is the [sub-tile][key][16 channels] form ds_read_b64_tr_b16
-// wants) -- no staging registers, no LDS stores, one counted wait + barrier per chunk; S^T = K Q^T with the operands swapped so that a
-// lane holds 16 keys of ONE query, deferred reference point + end-of-tile fix-up (vit_attn.hip), P from registers (split into hi / lo
-// there), three MFMAs per product (hi.hi + hi.lo + lo.hi, fp32 accumulation) in both contractions.
-// Round 4: 1293 us (8 waves, register-staged chunks) -> 1086 us at 64 images x 12 heads x 1374 tokens, same box.
+// Structure = the bf16 kernel's skeleton (vit_attn.hip): 8 waves x 32 queries per workgroup, K / V of a 128-key chunk staged once
+// per workgroup by register prefetch into double-buffered LDS (hi and lo planes side by side, 141 KiB), S^T = K Q^T with the operands
+// swapped so that a lane holds 16 keys of ONE query, deferred reference point + end-of-tile fix-up, P from registers (split into
+// hi / lo there), V^T fragments by ds_read_b64_tr_b16, one barrier per chunk -- with three MFMAs per product
+// (hi.hi + hi.lo + lo.hi, fp32 accumulation) in both contractions.
 #include "common.h"
 #include "gemm_common.h"
 
@@ -27,10 +25,7 @@ constexpr int VS_VOFF = 2 * VS_KPLANE;     // K hi | K lo | V hi | V lo
 constexpr int VS_BUFB = 2 * VS_KPLANE + 2 * VS_VPLANE;  // 66560 B
 constexpr float VS_DEFER = 8.f;  // log2 of the largest P the deferred rescale lets through
 #ifndef VS_MODE
-#define VS_MODE 0  // 0: score MFMAs, softmax, P.V per tile; 1: the score MFMAs of tile t + 1 issued before the softmax of tile t (measured: slower at 3 waves / SIMD)
-#endif
-#ifndef VS_NW
-#define VS_NW 12   // wavefronts per workgroup = 3 per SIMD (154 VGPRs); 8: 1189 us, 12: 1086 us at 64 x 12 x 1374 (scripts/ubench/vit_attn_var.py)
+#define VS_MODE 1  // 0: score MFMAs, softmax, P.V per tile; 1: the score MFMAs of tile t + 1 are issued before the softmax of tile t
 #endif
 
 struct HLf {
@@ -277,6 +272,9 @@ int unopose_vit_attention_f32_ss(const void *qkv_split, int B, int T, int H, voi
   UNOPOSE_REQUIRE(qkv_split && out_split, "vit_attention_f32_ss: null pointer");
   UNOPOSE_REQUIRE(B >= 0 && T >= 1 && H >= 1 && (long)B * H * cdiv(T, 256) < (1L << 28), "vit_attention_f32_ss: bad sizes");
   if (B == 0) return UNOPOSE_OK;
+#ifndef VS_NW
+#define VS_NW 8
+#endif
   constexpr int NW = VS_NW;
   static bool opt[64];
   const size_t lds = (size_t)2 * VS_BUFB;

@@ -102,12 +102,12 @@ def test_vit_attention_fp32_class_vs_oracle(T, spike):
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("T,spike", [(261, None), (1374, None), (1374, (77, 1201)), (261, (5, 250)), (40, None), (129, None)])
+@pytest.mark.parametrize("T,spike", [(261, None), (1374, None), (1374, (77, 1201)), (261, (5, 250)), (40, None), (129, None), (385, None), (1, None)])
 def test_vit_attention_fp32_split_in_split_out_vs_oracle(T, spike):
     """csrc/vit_attn_f32s.hip (round 4: the attention core of the fp32 ViT blocks -- qkv and output in the split layout of
-    csrc/gemm_f32.hip, 8 waves x 32 queries, 128-key double-buffered chunks) vs the oracle on the same fp32 qkv: 2e-4, including the
-    inputs that move the deferred reference point late in the sequence, a sequence shorter than one chunk and one ending on a
-    one-key partial tile."""
+    csrc/gemm_f32.hip, 12 waves x 32 queries, 128-key chunks by LDS-DMA into double-buffered LDS) vs the oracle on the same fp32 qkv:
+    2e-4, including the inputs that move the deferred reference point late in the sequence, a sequence shorter than one chunk, one ending
+    on a one-key partial tile, one query past a full workgroup (385) and a single token."""
     from oracle import unopose_ref as R
     from unopose_amd import ops
 
