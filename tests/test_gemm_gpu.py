@@ -110,10 +110,12 @@ def test_split_layout_roundtrip():
 
 @torch.no_grad()
 @pytest.mark.parametrize("M,K,N,epi", [(1, 32, 256, 0), (300, 256, 256, 2), (4173, 768, 768, 1), (5000, 3072, 768, 0),
-                                       (2049 * 3, 256, 512, 2), (64 * 261, 768, 2304, 0)])
+                                       (2049 * 3, 256, 512, 2), (64 * 261, 768, 2304, 0), (12608, 256, 512, 1), (6304, 512, 256, 0),
+                                       (127, 64, 1792, 2), (131136, 256, 256, 1)])
 def test_linear_f32x3_vs_fp64_reference(M, K, N, epi):
     """C = act(A W^T + b) on fp32 data: error budget 3 x 2^-17 of sum |a| |w| (the split's representation error and the
-    dropped lo x lo term) -- fp32-class, 400 x tighter than a bf16 GEMM."""
+    dropped lo x lo term) -- fp32-class, 400 x tighter than a bf16 GEMM.  Shapes with fewer 256 x 256 tiles than CUs (the matcher's
+    197-token layers among them) run on gemm_small.hip's 128 x 128 fp32-class kernel, the others on gemm_kernel.h's."""
     from unopose_amd import ops
 
     g = torch.Generator().manual_seed(M + K + N)

@@ -133,6 +133,13 @@ def test_bmm_f32_strided_contractions():
     assert kvt.shape == (3, 4, 64, 64) and kvt.is_contiguous() and (kvt.double() - ref).abs().max().item() < 1e-4
     x, r = torch.randn(2, 33, 3, generator=g).cuda(), torch.randn(2, 3, 3, generator=g).cuda()
     assert (ops.bmm_nt_f32(x, r.transpose(1, 2)) - x @ r).abs().max().item() < 1e-5
+    # the 64 x 64-per-wave form (outputs >= 256 x 256: the fp32 path's fine similarity, ragged 2049 x 2049 there): the same k-ordered fma
+    # chain per element, so it equals the 32 x 32 form BIT FOR BIT (reached here through row slices narrower than 256) and float64 to 2e-4
+    a, b = torch.randn(2, 321, 256, generator=g).cuda(), torch.randn(2, 449, 256, generator=g).cuda()
+    c = ops.bmm_nt_f32(a, b)
+    assert c.shape == (2, 321, 449) and (c.double() - torch.einsum("bik,bjk->bij", a.double(), b.double())).abs().max().item() < 2e-4
+    parts = torch.cat([ops.bmm_nt_f32(a[:, i0:i0 + 107], b) for i0 in (0, 107, 214)], 1)
+    assert torch.equal(c, parts)
 
 
 def test_gather_rows_kernel_matches_torch_composite():

@@ -48,13 +48,16 @@ static inline int use_nt_store(long M, int N) { return (size_t)M * N * 2 > (32u 
 // (Measured and not kept: giving the 256-tile kernel only whole rounds of tiles and the last row panels to the small kernel --
 // fc2 at M = 87 936 is 1032 tiles on 256 CUs -- gains 0 - 3 % per shape, 0.07 ms per forward: the few tiles of a last round
 // already run faster than those of a full one.)
-static int small_tiles_limit() {
+namespace unopose {
+int gemm_small_tiles_limit() {
   static const int v = [] {
     const char *e = getenv("UNOPOSE_GEMM_SMALL_TILES");
     return e && *e ? atoi(e) : -1;
   }();
   return v >= 0 ? v : gemm_cu_count();
 }
+}  // namespace unopose
+static int small_tiles_limit() { return unopose::gemm_small_tiles_limit(); }
 
 // Ticket slots of the dynamic tile scheduling: a ring of 1024 slots of 16 ints per device (zeroed once; every launch's last workgroup
 // re-zeroes its slot).  Consecutive launches take consecutive slots, so launches of different streams that run at the same time never

@@ -62,6 +62,8 @@ int unopose_linear_f32x3(const void *As, const void *Ws, const float *bias, floa
   UNOPOSE_REQUIRE((size_t)M * K * 4 < (1UL << 32) && (size_t)N * K * 4 < (1UL << 32), "linear_f32x3: operand larger than 4 GiB");
   UNOPOSE_REQUIRE(epilogue >= 0 && epilogue <= 2, "linear_f32x3: epilogue must be 0 (bias), 1 (bias + GELU) or 2 (bias + ReLU)");
   const int tiles_m = cdiv(M, GEMM_BM), tiles_n = N / GEMM_BN, tiles = tiles_m * tiles_n;
+  // too few 256 x 256 tiles for one per CU (the matcher's 197-token layers): 128 x 128 tiles, four times the workgroups (gemm_small.hip)
+  if (tiles < gemm_small_tiles_limit()) return gemm_small_linear_f32(As, Ws, bias, C, Cs, M, N, K, epilogue, (hipStream_t)stream);
   const int n_cu = gemm_cu_count();
   const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
   const int nt = (size_t)M * N * 4 > (32u << 20) ? 1 : 0;

@@ -243,4 +243,165 @@ int gemm_small_linear_ln(const void *A, const void *W, const float *bias, const 
   return launch_small<64, 256, 3, 2>(A, W, bias, C, M, 256, K, K, K, 256, resid, ln_w, ln_b, eps, s);
 }
 
+// ---- fp32-class form (gemm_f32.hip's split operands: 128-byte rows hold 32 k as [hi (32 bf16) | lo (32 bf16)]): 128 x 128 tiles, 4 waves of
+// 64 x 64, two stages of K = 32, 24 MFMAs per K-tile and wave (hi.hi + hi.lo + lo.hi per fragment pair).  Users: the fp32 path's matcher
+// linears (6 304 - 12 608 rows x 256 / 512: 25 - 100 tiles of 256 x 256 -- 96 launches, 5.4 ms per forward on the 256-tile kernel).
+// Epilogue: bias / exact-erf GELU / ReLU, the 64 x 64 fp32 block of a wave staged through 16 KiB of the (free) stage buffers (16-byte
+// slots XOR-swizzled by row), then whole 256-byte row segments as fp32 (C) and / or in the split layout (Cs).
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_small_f32_kernel(const char *__restrict__ A, const char *__restrict__ W, const float *__restrict__ bias,
+                                                                float *__restrict__ C, char *__restrict__ Cs, int M, int N, int K, int tiles_m, int tiles_n) {
+  constexpr int BM = 128, BN = 128, NST = 2;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int PPW = (BM + BN) / 8 / 4, A_PIECES = BM / 8;
+  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int tiles = tiles_m * tiles_n;
+  const int per_xcd = (tiles + 7) >> 3;
+  const int t_id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (t_id >= tiles) return;
+  const int tm = t_id / tiles_n, tn = t_id - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const size_t rowb = (size_t)K * 4;  // bytes per operand row
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, (int)((size_t)M * rowb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, (int)((size_t)N * rowb), 0x00020000);
+  const int nk = K / 32;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+  const int r8 = lane >> 3;
+  const int c_sw = (lane & 7) ^ (((wave & 1) << 2) | (r8 >> 1));
+  const uint32_t a_lane = (uint32_t)((size_t)(m0 + r8) * rowb + c_sw * 16);
+  const uint32_t w_lane = (uint32_t)((size_t)(n0 + r8) * rowb + c_sw * 16);
+  auto stage = [&](int kt, int buf) {
+    const int so = kt * 128;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int j = wave + 4 * i;
+      if (4 * i < A_PIECES)
+        gemm_dma16(lds0 + buf * STAGE + j * 1024, a_lane + (uint32_t)(j * 8) * (uint32_t)rowb, a_rs, so);
+      else
+        gemm_dma16(lds0 + buf * STAGE + j * 1024, w_lane + (uint32_t)((j - A_PIECES) * 8) * (uint32_t)rowb, w_rs, so);
+    }
+  };
+  // fragment reads: tile row r = base + l31, 16-byte chunk c: hi part of k-step ks = 2 ks + hi, lo part = 4 + 2 ks + hi
+  const int fx = (l31 >> 1) & 7;
+  uint32_t fr_off[4];
+#pragma unroll
+  for (int c2 = 0; c2 < 4; ++c2) fr_off[c2] = (uint32_t)((l31 >> 3) * 1024 + (l31 & 7) * 128 + ((((c2 << 1) | hi) ^ fx) << 4));
+  const uint32_t a_base = (uint32_t)(wm * 64 * 128), w_base = (uint32_t)(A_BYTES + wn * 64 * 128);
+  float4 bv[2][4];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv[nb][g] = *reinterpret_cast<const float4 *>(bias + n0 + wn * 64 + nb * 32 + 8 * g + 4 * hi);
+  stage(0, 0);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][mb][r] = 0.f;
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nk) {
+      stage(t + 1, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char *lb = smem + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 wh[2], wl[2], ah[2], al[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        wh[nb] = *reinterpret_cast<const bf16x8 *>(lb + w_base + nb * 4096 + fr_off[ks]);
+        wl[nb] = *reinterpret_cast<const bf16x8 *>(lb + w_base + nb * 4096 + fr_off[2 + ks]);
+      }
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        ah[mb] = *reinterpret_cast<const bf16x8 *>(lb + a_base + mb * 4096 + fr_off[ks]);
+        al[mb] = *reinterpret_cast<const bf16x8 *>(lb + a_base + mb * 4096 + fr_off[2 + ks]);
+      }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {  // (the order of gemm_kernel.h's F32 form: small terms first)
+          acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[nb], ah[mb], acc[nb][mb], 0, 0, 0);
+          acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nb], al[mb], acc[nb][mb], 0, 0, 0);
+          acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nb], ah[mb], acc[nb][mb], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  // ---- epilogue: acc[nb][mb][4g + e] = C[m = m0 + wm*64 + mb*32 + l31][n = n0 + wn*64 + nb*32 + 8g + 4hi + e]
+  char *cw = smem + wave * 16384;  // [64 rows][256 B], 16-byte slot c of row r at c ^ (r & 15)
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v0 = acc[nb][mb][4 * g + 0] + bv[nb][g].x, v1 = acc[nb][mb][4 * g + 1] + bv[nb][g].y;
+        float v2 = acc[nb][mb][4 * g + 2] + bv[nb][g].z, v3 = acc[nb][mb][4 * g + 3] + bv[nb][g].w;
+        if (EPI == 1) {
+          v0 = gelu_erf(v0);
+          v1 = gelu_erf(v1);
+          v2 = gelu_erf(v2);
+          v3 = gelu_erf(v3);
+        }
+        if (EPI == 2) {
+          v0 = fmaxf(v0, 0.f);
+          v1 = fmaxf(v1, 0.f);
+          v2 = fmaxf(v2, 0.f);
+          v3 = fmaxf(v3, 0.f);
+        }
+        const int row = mb * 32 + l31, slot = nb * 8 + 2 * g + hi;
+        *reinterpret_cast<float4 *>(cw + row * 256 + ((slot ^ (row & 15)) << 4)) = make_float4(v0, v1, v2, v3);
+      }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 4 + (lane >> 4), q = lane & 15;
+    const int m = m0 + wm * 64 + row;
+    const float4 v = *reinterpret_cast<const float4 *>(cw + row * 256 + ((q ^ (row & 15)) << 4));
+    if (m < M) {
+      const int n = n0 + wn * 64 + q * 4;
+      if (C) *reinterpret_cast<float4 *>(C + (size_t)m * N + n) = v;
+      if (Cs) {
+        uint2 h, l;
+        h.x = cvt_pk_bf16_f32(v.x, v.y);
+        h.y = cvt_pk_bf16_f32(v.z, v.w);
+        l.x = cvt_pk_bf16_f32(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u));
+        l.y = cvt_pk_bf16_f32(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u));
+        char *line = Cs + (size_t)m * N * 4 + (size_t)(n >> 5) * 128 + (n & 31) * 2;
+        *reinterpret_cast<uint2 *>(line) = h;
+        *reinterpret_cast<uint2 *>(line + 64) = l;
+      }
+    }
+  }
+}
+
+// Entry point for gemm_f32.hip's unopose_linear_f32x3 (N % 128 == 0, K % 32 == 0; epilogue 0 / 1 / 2; C and / or Cs).
+int gemm_small_linear_f32(const void *As, const void *Ws, const float *bias, float *C, void *Cs, long M, int N, int K, int epilogue, hipStream_t s) {
+  const int tiles_m = cdiv(M, 128), tiles_n = N / 128, tiles = tiles_m * tiles_n;
+  const int grid = ((tiles + 7) >> 3) << 3;
+#define UNOPOSE_LAUNCH_SMALL_F32(E)                                                                                                                   \
+  hipLaunchKernelGGL((gemm_small_f32_kernel<E>), dim3(grid), dim3(256), 0, s, (const char *)As, (const char *)Ws, bias, C, (char *)Cs, (int)M, N, K, \
+                     tiles_m, tiles_n)
+  if (epilogue == 1) UNOPOSE_LAUNCH_SMALL_F32(1);
+  else if (epilogue == 2) UNOPOSE_LAUNCH_SMALL_F32(2);
+  else UNOPOSE_LAUNCH_SMALL_F32(0);
+#undef UNOPOSE_LAUNCH_SMALL_F32
+  return check_launch("linear_f32x3 (small tiles)");
+}
+
 }  // namespace unopose
