@@ -36,6 +36,9 @@ constexpr float VA_DEFER = 8.f;
 #ifndef VA_NW
 #define VA_NW 8  // wavefronts per workgroup (one workgroup per CU: NW / 4 waves per SIMD)
 #endif
+#ifndef VA_ONES
+#define VA_ONES 0  // 1: row sums through the matrix pipe (modes 0 / 1)
+#endif
 #ifndef VA_SCHED
 #define VA_SCHED 1
 #endif
@@ -110,6 +113,14 @@ __global__ __launch_bounds__(NW * 64) void vit_attn2_kernel(const u16 *__restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[qb][t][r] = 0.f;
   }
+  f32x16 lacc[QB];
+  union { bf16x8 v; uint32_t w[4]; } ones;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ones.w[e] = 0x3f803f80u;
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[qb][r] = 0.f;
   // K fragment of key row kt + col, k-step ks: 16-byte chunk 2 ks + hb, swizzled by the row (kt is a multiple of 32)
   uint32_t koff[4];
 #pragma unroll
@@ -128,10 +139,13 @@ __global__ __launch_bounds__(NW * 64) void vit_attn2_kernel(const u16 *__restric
       for (int qb = 0; qb < QB; ++qb) s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], s[qb], 0, 0, 0);
     }
   };
+  // VA_ONES: the row sums ride the matrix pipe -- lacc += ONES . P^T (every row of the 32 x 32 result is the column sum of the bf16 P the
+  // P.V product also uses), so the softmax loses its 16 adds, the cross-half exchange of the sum and the per-tile alpha; alpha is only
+  // computed in the rare re-reference path, where lacc is fixed up exactly like O.
   auto softmax_pv_tile = [&](const char *buf, int kt, f32x16 (&s)[QB]) {
     const char *vlane = buf + vlane_off;
     union PF { bf16x8 v; uint32_t w[4]; } pf[QB][2];
-    float alpha[QB];
+    float alpha[QB], m_old[QB];
     bool moved = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -142,17 +156,20 @@ __global__ __launch_bounds__(NW * 64) void vit_attn2_kernel(const u16 *__restric
       mx = fmaxf(__uint_as_float(sm[0]), __uint_as_float(sm[1])) * scale_log2e;
       const bool grow = mx > m_run[qb] + VA_DEFER;
       const float m_use = grow ? mx : m_run[qb];
-      alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
+      m_old[qb] = m_run[qb];
+      if (!VA_ONES) alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
       m_run[qb] = m_use;
       moved |= grow;
       float ls = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         s[qb][r] = __builtin_amdgcn_exp2f(fmaf(s[qb][r], scale_log2e, -m_use));
-        ls += s[qb][r];
+        if (!VA_ONES) ls += s[qb][r];
       }
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
-      l_run[qb] = fmaf(l_run[qb], alpha[qb], __uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+      if (!VA_ONES) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
+        l_run[qb] = fmaf(l_run[qb], alpha[qb], __uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -166,14 +183,32 @@ __global__ __launch_bounds__(NW * 64) void vit_attn2_kernel(const u16 *__restric
       return vf.v;
     };
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const bf16x8 vf = v_frag(s2, t);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) o[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][s2].v, o[qb][t], 0, 0, 0);
       }
+      if (VA_ONES) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) lacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones.v, pf[qb][s2].v, lacc[qb], 0, 0, 0);
+      }
+    }
     if (__builtin_expect(__any(moved), 0)) {
+      if (VA_ONES) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          alpha[qb] = __builtin_amdgcn_exp2f(m_old[qb] - m_run[qb]);
+          f32x16 d;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[r] = 0.f;
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones.v, pf[qb][0].v, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones.v, pf[qb][1].v, d, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) lacc[qb][r] = fmaf(lacc[qb][r] - d[r], alpha[qb], d[r]);
+        }
+      }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const bf16x8 v0 = v_frag(0, t), v1 = v_frag(1, t);
@@ -360,7 +395,7 @@ __global__ __launch_bounds__(NW * 64) void vit_attn2_kernel(const u16 *__restric
   if (!active) return;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    const float inv = 1.f / l_run[qb];
+    const float inv = 1.f / (VA_ONES ? lacc[qb][0] : l_run[qb]);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll

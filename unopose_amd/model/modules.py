@@ -330,7 +330,7 @@ class _AttentionOutput(nn.Module):
 
     def forward(self, x):
         if x.is_cuda and not ops.is_differentiable():  # squeeze + residual + LayerNorm: one launch under autocast
-            return ops.linear_add_layernorm(ops.linear(x, self.expand, relu=True), self.squeeze, x, self.norm)
+            return ops.ffn_add_layernorm(x, self.expand, self.squeeze, self.norm)
         return self.norm(x + ops.linear(ops.linear(x, self.expand, relu=True), self.squeeze))
 
 
