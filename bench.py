@@ -613,17 +613,24 @@ def main():
         res["forward_latency_ms"] = {"median": q(lat, 0.5), "p10": q(lat, 0.1), "p90": q(lat, 0.9)}
     if rank == 0 and world == 1 and not args.dry_run:
         if amp and not args.no_fp32 and graphed is None:
-            # the reference's default precision (configs/main_cfg.py:87-89: test.amp.enabled=False): 3 warm-ups, 20 steps one at a
-            # time on the current stream, HIP events around every step (median / p10 / p90) beside the wall-clock rate
+            # the reference's default precision (configs/main_cfg.py:87-89: test.amp.enabled=False) through the same runner object as
+            # `--dtype fp32` (PipelinedForward without autocast: one forward at a time): 3 warm-ups, 20 steps, HIP events around every
+            # step (median / p10 / p90) beside the wall-clock rate
             k = 20 if args.steps >= 20 else max(3, args.steps)
+            if pipe is not None:
+                pipe.close()
+            from unopose_amd.pipeline import PipelinedForward
+
+            pipe32 = PipelinedForward(model, depth=1, autocast_dtype=None)
+            step32 = lambda: pipe32.submit(dict(batch)).result  # noqa: E731
             for _ in range(3):
-                step(False)
+                step32()
             sync()
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
             t1 = time.perf_counter()
             for a, b in evs:
                 a.record()
-                o32 = step(False)
+                o32 = step32()
                 b.record()
             sync()
             d32 = time.perf_counter() - t1

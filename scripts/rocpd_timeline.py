@@ -4,20 +4,20 @@ For a window of whole steps (from the first ViT attention launch of step `skip` 
 instant is attributed: idle (no kernel resident), solo (exactly one kernel resident: its time is on the critical
 path) or shared (several resident: split equally).  Prints per-kernel solo / shared / total ms per step.
 
-    python scripts/rocpd_timeline.py <db> [attn launches per step = 12] [steps to skip = 3]
+    python scripts/rocpd_timeline.py <db> [attn launches per step = 12] [steps to skip = 3] [marker kernel = vit_attn_kernel]
 """
 import collections
 import sqlite3
 import sys
 
 
-def main(path, per_step=12, skip=3):
+def main(path, per_step=12, skip=3, marker="vit_attn_kernel"):
     db = sqlite3.connect(path)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else "kernel_name"
     rows = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
-    marks = [s for (n, s, e) in rows if "vit_attn_kernel" in n][::per_step]
+    marks = [s for (n, s, e) in rows if marker in n][::per_step]
     t0, t1, steps = marks[skip], marks[-1], len(marks) - 1 - skip
     ev = []
     for i, (n, s, e) in enumerate(rows):
@@ -62,4 +62,4 @@ def main(path, per_step=12, skip=3):
 
 if __name__ == "__main__":
     a = sys.argv
-    main(a[1], int(a[2]) if len(a) > 2 else 12, int(a[3]) if len(a) > 3 else 3)
+    main(a[1], int(a[2]) if len(a) > 2 else 12, int(a[3]) if len(a) > 3 else 3, a[4] if len(a) > 4 else "vit_attn_kernel")

@@ -54,7 +54,7 @@ class PipelinedForward:
     caches are rebuilt on whichever stream sees the new version first); after an update call `drain()` then `reset()`.
     `close()` restores the model's `internal_overlap` switch."""
 
-    def __init__(self, model, depth=2, autocast_dtype=torch.bfloat16, run_ahead=1, timing=False, stages="auto"):
+    def __init__(self, model, depth=2, autocast_dtype=torch.bfloat16, run_ahead=None, timing=False, stages="auto"):
         if depth not in (1, 2, 3, 4):
             raise ValueError("depth must be 1..4")
         self.model, self.autocast_dtype = model, autocast_dtype
@@ -78,6 +78,13 @@ class PipelinedForward:
         self.last_mode = None
         self._n = 0
         self._pending = collections.deque()
+        # run_ahead: forwards the host may enqueue beyond `depth` before it has seen one finish.  Default 1 with several forwards in
+        # flight; 0 with ONE forward at a time (fp32): there the next forward's first side-stream wait, enqueued a whole forward early,
+        # can share a hardware queue with the running forward's stream (HIP multiplexes streams onto GPU_MAX_HW_QUEUES = 4 queues) --
+        # measured 87 -> 101 ms per fp32 forward whenever the stream pool happened to be laid out that way (bf16 stage-mode steps earlier
+        # in the process; GPU_MAX_HW_QUEUES=8 also cures it), against 1 % for giving up the run-ahead.
+        if run_ahead is None:
+            run_ahead = 1 if self.depth > 1 else 0
         self._limit = self.depth + max(0, int(run_ahead))  # forwards the host may have enqueued and not yet seen finish
         # stages: every forward is cut in two -- `forward_features` (the ViT) on one stream, `forward_matching` on a second,
         # high-priority one -- so that ViTs never overlap each other and the latency-bound matcher of batch i always runs
