@@ -310,7 +310,17 @@ __global__ __launch_bounds__(256) void pe_pack_weights_kernel(const float *__res
   if (tid < 128) L->b3[tid] = b3[tid];
 }
 
+#ifndef PE_WPE
+#define PE_WPE 0
+#endif
+#ifndef PE_PREFETCH
+#define PE_PREFETCH 1
+#endif
+#if PE_WPE
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void pe_group_mlp_max_bf16x3_kernel(
+#else
 __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
+#endif
     const float *__restrict__ xyz, int N, float radius, int S, int cpw, const uint4 *__restrict__ image,
     const int *__restrict__ cand_in, const int *__restrict__ cand_cnt_in, int cand_stride, int *__restrict__ cand_out,
     int *__restrict__ cand_cnt_out, float *__restrict__ out, int out_ld, int out_split) {
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) rmax[t][r] = 0.f;
+      for (int r = 0; r < 16; ++r) rmax[t][r] = 0.f;  // post-ReLU values are >= 0
     for (int t0 = 0; t0 < S; t0 += 32) {
       // keep the weight fragments in LDS (re-read per tile) instead of letting the compiler hoist ~170
       // registers of loop-invariant operands: leaves room for 2 waves / SIMD so one wave's VALU phases
@@ -377,6 +387,102 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
       }
       bf16x8 xh, xl;
       pe_split8(f, xh, xl);
+#if PE_PREFETCH
+      // The weight fragments and bias values of the NEXT group of MFMAs are read from LDS (into the other of two register sets) before
+      // the current group is issued: left to the compiler every k-step's two fragments were read right in front of their three MFMAs
+      // -- ~20 exposed LDS round trips per tile (round 4: the tile loop was latency-bound, the matrix pipe 36 % busy).
+      struct Grp {
+        bf16x8 h[4], l[4];
+        float4 b[4];
+      } ga, gb;
+      auto load_l1 = [&](Grp &g) {
+        g.h[0] = *reinterpret_cast<const bf16x8 *>(&L->w1h[col][half * 8]);
+        g.l[0] = *reinterpret_cast<const bf16x8 *>(&L->w1l[col][half * 8]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g.b[q] = *reinterpret_cast<const float4 *>(&L->b1[8 * q + 4 * half]);
+      };
+      auto load_l2 = [&](Grp &g, int ot) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          g.h[ks] = *reinterpret_cast<const bf16x8 *>(&L->w2h[ot * 32 + col][ks * 16 + half * 8]);
+          g.l[ks] = *reinterpret_cast<const bf16x8 *>(&L->w2l[ot * 32 + col][ks * 16 + half * 8]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g.b[q] = *reinterpret_cast<const float4 *>(&L->b2[ot * 32 + 8 * q + 4 * half]);
+      };
+      auto load_l3 = [&](Grp &g, int ot) {
+        const int row = ot * 32 + col;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int kp = (ks * 16 + half * 8) ^ ((row & 7) << 3);
+          g.h[ks] = *reinterpret_cast<const bf16x8 *>(&L->w3h[row][kp]);
+          g.l[ks] = *reinterpret_cast<const bf16x8 *>(&L->w3l[row][kp]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g.b[q] = *reinterpret_cast<const float4 *>(&L->b3[ot * 32 + 8 * q + 4 * half]);
+      };
+      auto init = [&](f32x16 &h, const Grp &g) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          h[4 * q + 0] = g.b[q].x;
+          h[4 * q + 1] = g.b[q].y;
+          h[4 * q + 2] = g.b[q].z;
+          h[4 * q + 3] = g.b[q].w;
+        }
+      };
+      bf16x8 a1h[2], a1l[2], a2h[4], a2l[4];
+      auto relu_split = [&](const f32x16 &h, bf16x8 *oh, bf16x8 *ol) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(h[s2 * 8 + e], 0.f);
+          pe_split8(v, oh[s2], ol[s2]);
+        }
+      };
+      load_l1(ga);
+      load_l2(gb, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        f32x16 h1;
+        init(h1, ga);
+        PE_MFMA3(h1, ga.h[0], ga.l[0], xh, xl);
+        load_l2(ga, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        relu_split(h1, a1h, a1l);
+      }
+      {
+        f32x16 h2;
+        init(h2, gb);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { PE_MFMA3(h2, gb.h[ks], gb.l[ks], a1h[ks], a1l[ks]); }
+        load_l3(gb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        relu_split(h2, a2h, a2l);
+        init(h2, ga);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { PE_MFMA3(h2, ga.h[ks], ga.l[ks], a1h[ks], a1l[ks]); }
+        load_l3(ga, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        relu_split(h2, a2h + 2, a2l + 2);
+      }
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot) {
+        Grp &g = (ot & 1) ? ga : gb;
+        // (measured and not kept: b3 + ReLU once per centre after the loop -- max_k relu(h_k + b) = relu(max_k h_k + b) -- with the
+        // accumulator starting from the inline constant 0: 2021 -> 2101 us at S = 256, 1036 -> 1139 us at S = 64)
+        f32x16 h3;
+        init(h3, g);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { PE_MFMA3(h3, g.h[ks], g.l[ks], a2h[ks], a2l[ks]); }
+        if (ot + 2 < 4) {
+          load_l3(g, ot + 2);  // (into the set the MFMAs above have just read: the hardware keeps the order)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rmax[ot][r] = fmaxf(rmax[ot][r], h3[r]);
+      }
+#else
       // layer 1 (one k-step)
       // (biases are folded into the accumulator initialisation: one move instead of move + add)
       f32x16 h1;
@@ -435,6 +541,7 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) rmax[ot][r] = fmaxf(rmax[ot][r], h3[r]);
       }
+#endif
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
