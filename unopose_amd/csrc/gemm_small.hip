@@ -17,6 +17,9 @@
 namespace unopose {
 
 #define GS_BK 64
+#ifndef GS_PREFETCH
+#define GS_PREFETCH 1
+#endif
 
 template <int BM, int BN, int EPI, int NST>
 __global__ __launch_bounds__(256, (BM == 128 && NST == 2) ? 2 : 1) void gemm_small_kernel(const u16 *__restrict__ A, const u16 *__restrict__ W,
@@ -106,6 +109,29 @@ __global__ __launch_bounds__(256, (BM == 128 && NST == 2) ? 2 : 1) void gemm_sma
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const char *lb = smem + buf * STAGE;
+#if GS_PREFETCH
+    // the fragments of k-step ks + 1 are read (into the other of two register sets) before the MFMAs of k-step ks are issued: left to
+    // the compiler, one set was reused and every k-step began with its four reads
+    bf16x8 wf[2][2], af[2][2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) wf[0][nb] = *reinterpret_cast<const bf16x8 *>(lb + w_base + nb * 4096 + fr_off[0]);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) af[0][mb] = *reinterpret_cast<const bf16x8 *>(lb + a_base + mb * 4096 + fr_off[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) wf[(ks + 1) & 1][nb] = *reinterpret_cast<const bf16x8 *>(lb + w_base + nb * 4096 + fr_off[ks + 1]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) af[(ks + 1) & 1][mb] = *reinterpret_cast<const bf16x8 *>(lb + a_base + mb * 4096 + fr_off[ks + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nb], af[ks & 1][mb], acc[nb][mb], 0, 0, 0);
+    }
+#else
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 wf[2], af[2];
@@ -118,6 +144,7 @@ __global__ __launch_bounds__(256, (BM == 128 && NST == 2) ? 2 : 1) void gemm_sma
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], af[mb], acc[nb][mb], 0, 0, 0);
     }
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this K-tile's reads are done before anybody refills the buffer
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
