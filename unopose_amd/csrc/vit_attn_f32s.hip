@@ -29,6 +29,9 @@ constexpr float VS_DEFER = 8.f;  // log2 of the largest P the deferred rescale l
 #ifndef VS_MODE
 #define VS_MODE 0  // 0: score MFMAs, softmax, P.V per tile; 1: the score MFMAs of tile t + 1 issued before the softmax of tile t (measured: slower at 3 waves / SIMD)
 #endif
+#ifndef VS_BATCH_READS
+#define VS_BATCH_READS 2  // 1: all fragments of a product read before its MFMAs; 2: the V fragments already before the softmax arithmetic (1101 -> 1086 -> 1079 us)
+#endif
 #ifndef VS_NW
 #define VS_NW 12   // wavefronts per workgroup = 3 per SIMD (154 VGPRs); 8: 1189 us, 12: 1086 us at 64 x 12 x 1374 (scripts/ubench/vit_attn_var.py)
 #endif
@@ -121,12 +124,27 @@ __global__ __launch_bounds__(NW * 64) void vit_attn_f32s_kernel(const char *__re
     // S^T = K Q^T: rows = 32 keys, cols = 32 queries
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#if VS_BATCH_READS
+    // all eight K fragments first, then the twelve MFMAs (the compiler otherwise reads every k-step's pair right in front of its MFMAs:
+    // four exposed LDS round trips instead of one)
+    HLf kf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const char *kp = buf + kt * 128 + kfo[ks];
+      kf[ks].h = *reinterpret_cast<const bf16x8 *>(kp);
+      kf[ks].l = *reinterpret_cast<const bf16x8 *>(kp + VS_KPLANE);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { VS_MFMA3(s, kf[ks], qf[ks]); }
+#else
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const char *kp = buf + kt * 128 + kfo[ks];
       const HLf kf{*reinterpret_cast<const bf16x8 *>(kp), *reinterpret_cast<const bf16x8 *>(kp + VS_KPLANE)};
       VS_MFMA3(s, kf, qf[ks]);
     }
+#endif
     if (partial) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -134,6 +152,25 @@ __global__ __launch_bounds__(NW * 64) void vit_attn_f32s_kernel(const char *__re
     }
   };
   auto softmax_pv_tile = [&](const char *buf, int kt, f32x16 &s) {
+#if VS_BATCH_READS == 2
+    HLf vfe[2][2];  // (experiment: the V fragments read before the softmax arithmetic)
+    {
+      const char *vl0 = buf + vlane_off;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const char *vp = vl0 + t * 2 * VS_VSUBB + (kt + s2 * 16) * 32;
+          union { bf16x8 v; s16x4 h4[2]; } vh, vl;
+          vh.h4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp));
+          vh.h4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp + 8 * 32));
+          vl.h4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp + VS_VPLANE));
+          vl.h4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp + VS_VPLANE + 8 * 32));
+          vfe[s2][t] = HLf{vh.v, vl.v};
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     // online softmax with the deferred reference point (vit_attn.hip): per-lane select, no branch before the P.V MFMAs
     float mx = s[0];
 #pragma unroll
@@ -179,6 +216,27 @@ __global__ __launch_bounds__(NW * 64) void vit_attn_f32s_kernel(const char *__re
       vl.h4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp + VS_VPLANE + 8 * 32));
       return HLf{vh.v, vl.v};
     };
+#if VS_BATCH_READS
+    HLf vfa[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#if VS_BATCH_READS == 2
+        vfa[s2][t] = vfe[s2][t];
+#else
+        vfa[s2][t] = v_frag(s2, t);
+#endif
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const HLf pf{ph[s2].v, pl[s2].v};
+        VS_MFMA3(o[t], vfa[s2][t], pf);
+      }
+#else
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -187,6 +245,7 @@ __global__ __launch_bounds__(NW * 64) void vit_attn_f32s_kernel(const char *__re
         const HLf pf{ph[s2].v, pl[s2].v};
         VS_MFMA3(o[t], vf, pf);
       }
+#endif
     if (__builtin_expect(__any(grow), 0)) {  // rare after the first tile: O = (O - D) alpha + D with D = this tile's P.V (vit_attn.hip)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
