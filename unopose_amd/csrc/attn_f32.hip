@@ -52,6 +52,9 @@ __device__ __forceinline__ float af_swz(float v) {
 }
 
 constexpr int AF_NT = 14, AF_MP = AF_NT * 16;
+#ifndef AF_PF_DEPTH
+#define AF_PF_DEPTH 4  // operand pairs in flight ahead of the MFMAs of the token attention
+#endif
 
 // ---- token attention (see attn.hip for the scheme): one wave = 4 query rows x 4 heads ----------------
 template <bool RPE>
@@ -74,16 +77,38 @@ __global__ __launch_bounds__(256) void token_attn_f32_kernel(const float *__rest
 #pragma unroll
   for (int t = 0; t < AF_NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nt_valid = (m + 15) >> 4;
+  // Operand streams straight from global memory (K is L2-resident, the geometric embedding E is a 2.5 GB HBM stream per launch): the
+  // raw 32-byte pieces of the next AF_PF (k-step, key tile) pairs are in flight while the current one is split and multiplied -- the
+  // compiler had issued every pair of loads directly in front of its three MFMAs (one exposed memory round trip per 3 MFMAs).
+  struct Raw {
+    float4 a, b;
+  };
+  auto ld8 = [](const float *p) { return Raw{*reinterpret_cast<const float4 *>(p), *reinterpret_cast<const float4 *>(p + 4)}; };
+  auto sp8 = [](const Raw &r) {
+    const float v[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
+    return af_split(v);
+  };
+  constexpr int AF_PF = AF_PF_DEPTH, NPAIR = 8 * AF_NT;
+  {
+    auto addr = [&](int i) { return K + (size_t)min((i % AF_NT) * 16 + li, m - 1) * ldk + (i / AF_NT) * 32 + kg * 8; };
+    Raw ring[AF_PF];
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    const int kk = ks * 32 + kg * 8;
+    for (int i = 0; i < AF_PF; ++i) ring[i] = ld8(addr(i));
     HL a = af_zero();
-    if (a_valid && (kk >> 6) == a_h) a = af_load8(Q + kk);
 #pragma unroll
-    for (int t = 0; t < AF_NT; ++t) {
-      if (t >= nt_valid) continue;
-      const HL bv = af_load8(K + (size_t)min(t * 16 + li, m - 1) * ldk + kk);
-      AF_MFMA3_16(acc[t], a, bv);
+    for (int i = 0; i < NPAIR; ++i) {
+      const int ks = i / AF_NT, t = i % AF_NT;
+      if (t == 0) {
+        const int kk = ks * 32 + kg * 8;
+        a = af_zero();
+        if (a_valid && (kk >> 6) == a_h) a = af_load8(Q + kk);
+      }
+      const Raw cur = ring[i % AF_PF];
+      if (i + AF_PF < NPAIR) ring[i % AF_PF] = ld8(addr(i + AF_PF));
+      if (t < nt_valid) {
+        const HL bv = sp8(cur);
+        AF_MFMA3_16(acc[t], a, bv);
+      }
     }
   }
   if (RPE) {
@@ -91,14 +116,24 @@ __global__ __launch_bounds__(256) void token_attn_f32_kernel(const float *__rest
       if (n0 + nl >= n) break;
       const float *QP = qp + ((size_t)b * n + n0 + nl) * ldqp + a_h * 256;
       const float *En = E + ((size_t)b * n + n0 + nl) * (size_t)m * 256;
+      auto addr = [&](int i) { return En + (size_t)min((i % AF_NT) * 16 + li, m - 1) * 256 + (i / AF_NT) * 32 + kg * 8; };
+      Raw ring[AF_PF];
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        HL a = af_zero();
-        if (a_nl == nl) a = af_load8(QP + ks * 32 + kg * 8);
+      for (int i = 0; i < AF_PF; ++i) ring[i] = ld8(addr(i));
+      Raw araw = ld8(QP + kg * 8);  // the query-side fragment of k-step 0; the next one is fetched a whole k-step ahead
+      HL a = af_zero();
 #pragma unroll
-        for (int t = 0; t < AF_NT; ++t) {
-          if (t >= nt_valid) continue;
-          const HL bv = af_load8(En + (size_t)min(t * 16 + li, m - 1) * 256 + ks * 32 + kg * 8);
+      for (int i = 0; i < NPAIR; ++i) {
+        const int ks = i / AF_NT, t = i % AF_NT;
+        if (t == 0) {
+          a = af_zero();
+          if (a_nl == nl) a = sp8(araw);
+          if (ks + 1 < 8) araw = ld8(QP + (ks + 1) * 32 + kg * 8);
+        }
+        const Raw cur = ring[i % AF_PF];
+        if (i + AF_PF < NPAIR) ring[i % AF_PF] = ld8(addr(i + AF_PF));
+        if (t < nt_valid) {
+          const HL bv = sp8(cur);
           AF_MFMA3_16(acc[t], a, bv);
         }
       }
@@ -149,16 +184,23 @@ __global__ __launch_bounds__(256) void token_attn_f32_kernel(const float *__rest
 #pragma unroll
   for (int ks = 0; ks < AF_MP / 32; ++ks) pa[ks] = af_load8(&Pl[wave][li][ks * 32 + kg * 8]);
   const float *VT = vt + (size_t)b * 256 * AF_MP;
+  {
+    constexpr int NKS = AF_MP / 32, NP2 = 16 * NKS;
+    auto addr = [&](int i) { return VT + (size_t)((i / NKS) * 16 + li) * AF_MP + kg * 8 + (i % NKS) * 32; };
+    Raw ring[AF_PF];
 #pragma unroll
-  for (int nt = 0; nt < 16; ++nt) {
+    for (int i = 0; i < AF_PF; ++i) ring[i] = ld8(addr(i));
     f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float *Vr = VT + (size_t)(nt * 16 + li) * AF_MP + kg * 8;
 #pragma unroll
-    for (int ks = 0; ks < AF_MP / 32; ++ks) {
-      const HL bv = af_load8(Vr + ks * 32);
+    for (int i = 0; i < NP2; ++i) {
+      const int nt = i / NKS, ks = i % NKS;
+      if (ks == 0) o = f32x4{0.f, 0.f, 0.f, 0.f};
+      const Raw cur = ring[i % AF_PF];
+      if (i + AF_PF < NP2) ring[i % AF_PF] = ld8(addr(i + AF_PF));
+      const HL bv = sp8(cur);
       AF_MFMA3_16(o, pa[ks], bv);
+      if (ks == NKS - 1 && n0 + kg < n) out[((size_t)b * n + n0 + kg) * 256 + nt * 16 + li] = o[nt >> 2];
     }
-    if (n0 + kg < n) out[((size_t)b * n + n0 + kg) * 256 + nt * 16 + li] = o[nt >> 2];
   }
 }
 
