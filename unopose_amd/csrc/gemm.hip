@@ -43,7 +43,7 @@ using namespace unopose;
 // next launch reads them, and a round of tiles would otherwise push the operand panels out of L2.
 static inline int use_nt_store(long M, int N) { return (size_t)M * N * 2 > (32u << 20) ? 1 : 0; }
 
-// Shape policy: when the 256 x 256 tiles cannot give every CU one (`UNOPOSE_GEMM_SMALL_TILES` overrides the limit for A/Bs:
+// Shape policy: when the 256 x 256 tiles cannot give 5 / 8 of the CUs one (`UNOPOSE_GEMM_SMALL_TILES` overrides the limit for A/Bs:
 // scripts/gemm_policy_ab.sh), the GEMM runs on gemm_small.hip's 128 x 128 (64 x 256 with the LayerNorm epilogue) tiles.
 // (Measured and not kept: giving the 256-tile kernel only whole rounds of tiles and the last row panels to the small kernel --
 // fc2 at M = 87 936 is 1032 tiles on 256 CUs -- gains 0 - 3 % per shape, 0.07 ms per forward: the few tiles of a last round
@@ -54,7 +54,9 @@ int gemm_small_tiles_limit() {
     const char *e = getenv("UNOPOSE_GEMM_SMALL_TILES");
     return e && *e ? atoi(e) : -1;
   }();
-  return v >= 0 ? v : gemm_cu_count();
+  // default: below 5/8 of the CUs.  At 77 % fill (198 tiles: the 224 x 224 ViT's proj / fc2, M = 16 704) the 256-tile kernel is 8 - 17 %
+  // faster than 786 small tiles, at 39 % (100 tiles) the small tiles win by 28 % (profiles/r04_gemm_policy_224.txt)
+  return v >= 0 ? v : gemm_cu_count() * 5 / 8;
 }
 }  // namespace unopose
 static int small_tiles_limit() { return unopose::gemm_small_tiles_limit(); }

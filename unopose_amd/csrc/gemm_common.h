@@ -80,7 +80,7 @@ int gemm_small_linear_ln(const void *A, const void *W, const float *bias, const 
                          void *C, long M, int K, hipStream_t s);
 
 int gemm_small_linear_f32(const void *As, const void *Ws, const float *bias, float *C, void *Cs, long M, int N, int K, int epilogue, hipStream_t s);
-// 256 x 256 tile counts below this run on the small-tile kernels (default: the CU count; UNOPOSE_GEMM_SMALL_TILES)
+// 256 x 256 tile counts below this run on the small-tile kernels (default: 5 / 8 of the CU count; UNOPOSE_GEMM_SMALL_TILES)
 int gemm_small_tiles_limit();
 
 // A ticket slot for one launch of the persistent kernel with dynamic tile scheduling (gemm.hip), or nullptr (static tile lists).
