@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
                                         # >= 256 tiles of 256 x 256: the persistent kernel (csrc/gemm.hip), below: 128 x 128 tiles (gemm_small.hip).
                                         # One / two / three (odd) / many K-tiles, ragged last row panel, more tiles than CUs (stream continues)
                                         (70000, 64, 256, False), (65536 + 37, 128, 256, True), (33000, 192, 512, False), (64 * 1374, 768, 768, False),
-                                        (40000, 3072, 768, True)])
+                                        (40000, 3072, 768, True),
+                                        # W larger than an XCD's L2 and row panels a multiple of 8: the column-blocked tile walk (round 4)
+                                        (8192, 768, 3072, True), (16384 + 5, 1024, 2304, False)])
 def test_linear_bf16_vs_fp32_reference(M, K, N, gelu):
     from unopose_amd import ops
 
@@ -111,7 +113,9 @@ def test_split_layout_roundtrip():
 @torch.no_grad()
 @pytest.mark.parametrize("M,K,N,epi", [(1, 32, 256, 0), (300, 256, 256, 2), (4173, 768, 768, 1), (5000, 3072, 768, 0),
                                        (2049 * 3, 256, 512, 2), (64 * 261, 768, 2304, 0), (12608, 256, 512, 1), (6304, 512, 256, 0),
-                                       (127, 64, 1792, 2), (131136, 256, 256, 1)])
+                                       (127, 64, 1792, 2), (131136, 256, 256, 1),
+                                       # split W larger than an XCD's L2, row panels a multiple of 8: the column-blocked tile walk
+                                       (8192, 768, 2304, 0), (16384, 768, 3072, 1)])
 def test_linear_f32x3_vs_fp64_reference(M, K, N, epi):
     """C = act(A W^T + b) on fp32 data: error budget 3 x 2^-17 of sum |a| |w| (the split's representation error and the
     dropped lo x lo term) -- fp32-class, 400 x tighter than a bf16 GEMM.  Shapes with fewer 256 x 256 tiles than CUs (the matcher's
