@@ -39,6 +39,9 @@ constexpr float VA_DEFER = 8.f;
 #ifndef VA_ONES
 #define VA_ONES 0  // 1: row sums through the matrix pipe (modes 0 / 1)
 #endif
+#ifndef VA_NBUF
+#define VA_NBUF 3  // chunk buffers in LDS (2: the next chunk is in flight during the current one; 3: two chunks ahead)
+#endif
 #ifndef VA_SCHED
 #define VA_SCHED 1
 #endif
@@ -46,10 +49,10 @@ constexpr float VA_DEFER = 8.f;
 #define VA_INTERLEAVE VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1
 
 template <int QB, int NW, int NBUF>
-__global__ __launch_bounds__(NW * 64) void vit_attn2_kernel(const u16 *__restrict__ qkv, int T, int H, int BH, int nq,
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void vit_attn2_kernel(const u16 *__restrict__ qkv, int T, int H, int BH, int nq,
                                                                                                       float scale_log2e, u16 *__restrict__ out) {
   constexpr int NPC = 32 / NW;  // LDS-DMA pieces per wave and chunk: NPC / 2 of K, NPC / 2 of V
-  static_assert(NW == 8 || NW == 16, "8 or 16 wavefronts");
+  static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 wavefronts");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   u16 (*Ot)[32][72] = reinterpret_cast<u16 (*)[32][72]>(smem);
   static_assert(NW * 32 * 72 * 2 <= NBUF * VA_BUFB, "output staging must fit the chunk buffers");
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(NW * 64) void vit_attn2_kernel(const u16 *__restric
   };
   const int nchunks = (T + VA_CHUNK - 1) / VA_CHUNK;
   issue_chunk(0, 0);
-  if (nchunks > 1) issue_chunk(1, 1);
+  if (NBUF == 3 && nchunks > 1) issue_chunk(1, 1);
 
   bf16x8 qf[QB][4];
 #pragma unroll
@@ -373,18 +376,23 @@ __global__ __launch_bounds__(NW * 64) void vit_attn2_kernel(const u16 *__restric
   };
 
   // chunk 0 landed (chunk 1 may still fly), every wave's pieces visible
-  if (nchunks > 1) { if (NPC == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+  auto wait_all_but_one_chunk = [&]() {
+    if (NPC == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (NPC == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  };
+  if (NBUF == 3 && nchunks > 1) wait_all_but_one_chunk();
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   int bslot = 0;
   for (int c = 0; c < nchunks; ++c) {
-    int nslot = bslot + 2;
+    int nslot = bslot + NBUF - 1;
     if (nslot >= NBUF) nslot -= NBUF;
-    if (c + 2 < nchunks) issue_chunk(c + 2, nslot);  // (that buffer was last read in chunk c - 1, before the barrier that ended it)
+    if (c + NBUF - 1 < nchunks) issue_chunk(c + NBUF - 1, nslot);  // (that buffer was last read in chunk c - 1, before the barrier that ended it)
     if (active) chunk_compute(c * VA_CHUNK, smem + bslot * VA_BUFB);
     if (c + 1 < nchunks) {
-      if (c + 2 < nchunks) { if (NPC == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+      if (NBUF == 3 && c + 2 < nchunks) wait_all_but_one_chunk();
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(NW * 64) void vit_attn2_kernel(const u16 *__restric
 using namespace unopose;
 
 extern "C" int unopose_vit_attention(const void *qkv, int B, int T, int H, void *out, unopose_stream_t stream) {
-  constexpr int QB = VA_QB, NW = VA_NW, NBUF = 3;
+  constexpr int QB = VA_QB, NW = VA_NW, NBUF = VA_NBUF;
   static bool opt[64];
   const size_t lds = (size_t)NBUF * VA_BUFB;
   if (lds_optin(opt, reinterpret_cast<const void *>(&vit_attn2_kernel<QB, NW, NBUF>), lds, "vit_attention") != UNOPOSE_OK) return UNOPOSE_ELAUNCH;

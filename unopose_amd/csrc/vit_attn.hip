@@ -12,13 +12,12 @@
 //   * K / V of a 128-key chunk are staged once per workgroup in LDS and shared by its 4 waves;
 //   * O^T is transposed through 4 KiB of LDS so every token row is stored as 128 contiguous bytes.
 #include "common.h"
+#include "gemm_common.h"
 #include <cstdlib>
 
 namespace unopose {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16;
 
 __device__ __forceinline__ u16 va_f2bf(float f) {
   uint32_t u = __float_as_uint(f);
@@ -337,9 +336,229 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the long-sequence form (T >= 1024).  Same arithmetic as vit_attn_kernel<2, ...> above -- 64 queries per wave, swapped
+// product, deferred reference point, end-of-tile fix-up -- with two structural changes:
+//  * K / V chunks arrive by LDS-DMA (`buffer_load_dwordx4 ... lds`: 32 one-KiB pieces per 128-key chunk; the per-lane source addresses
+//    swizzle the K rows (16-byte chunk c of row r at c ^ ((r >> 1) & 7): conflict-free ds_read_b128 without padding) and lay V out as
+//    the [sub-tile][key][16 channels] image ds_read_b64_tr_b16 wants; keys past the sequence fall outside the buffer descriptor and
+//    arrive as zeros): no staging registers (233 -> 213 VGPRs), no ds_write, one counted wait + barrier per chunk;
+//  * 4 waves per workgroup and TWO workgroups per CU (66.5 KiB of LDS each): with one 8-wave workgroup per CU the Q loads, the first
+//    chunk and the output pass of every workgroup ran with nothing else on the CU -- 9 workgroups per CU and launch, ~10 % of the time.
+// Same box, 64 x 12 x 1374: 489.6 us (vit_attn_kernel<2, 2, 8>) -> 472 (8 waves, LDS-DMA, 2 buffers) -> 450-469 us (this kernel);
+// a third chunk buffer (one workgroup per CU again): 622 us; results equal to the old kernel's (scripts/ubench/vit_attn_var.py).
+constexpr int VD_KBYTES = VA_CHUNK * 128;          // K chunk: [key][64 ch] bf16, swizzled
+constexpr int VD_VSUBB = 128 * 32 + 128;           // bytes per V sub-tile [128 keys][16 channels] + bank skew
+constexpr int VD_BUFB = VD_KBYTES + 4 * VD_VSUBB;  // 33 280 B per chunk buffer
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void vit_attn_kernel_dma(const u16 *__restrict__ qkv, int T, int H, int BH, int nq, float scale_log2e,
+                                                               u16 *__restrict__ out) {
+  constexpr int QB = 2, NBUF = 2, NPC = 32 / NW;  // NPC: LDS-DMA pieces per wave and chunk, half of them K, half V
+  extern __shared__ __attribute__((aligned(1024))) char smemd[];
+  u16 (*Ot)[32][72] = reinterpret_cast<u16 (*)[32][72]>(smemd);
+  static_assert(NW * 32 * 72 * 2 <= NBUF * VD_BUFB, "output staging must fit the chunk buffers");
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bh = (slot / nq) * 8 + xcd, qblk = slot % nq;
+  if (bh >= BH) return;
+  const int b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q0 = (qblk * NW + wave) * (32 * QB);
+  const bool active = q0 < T;  // inactive waves still issue their DMA pieces and hit every barrier
+  const int col = lane & 31, hb = lane >> 5;
+  const int C3 = 3 * H * 64;
+  const u16 *base = qkv + (size_t)b * T * C3;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smemd;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)((size_t)T * C3 * 2), 0x00020000);
+  uint32_t kvo[NPC / 2], vvo[NPC / 2], kdst[NPC / 2], vdst[NPC / 2];
+#pragma unroll
+  for (int i = 0; i < NPC / 2; ++i) {
+    const int p = (NPC / 2) * wave + i;  // piece 0 .. 15 of K and of V
+    const int krow = 8 * p + (lane >> 3), gch = (lane & 7) ^ ((krow >> 1) & 7);
+    kvo[i] = (uint32_t)(krow * C3 * 2 + (H * 64 + h * 64) * 2 + gch * 16);
+    kdst[i] = (uint32_t)(p * 1024);
+    const int sub = p >> 2, vkey = 32 * (p & 3) + (lane >> 1);
+    vvo[i] = (uint32_t)(vkey * C3 * 2 + (2 * H * 64 + h * 64 + sub * 16 + (lane & 1) * 8) * 2);
+    vdst[i] = (uint32_t)(VD_KBYTES + sub * VD_VSUBB + (p & 3) * 1024);
+  }
+  auto issue_chunk = [&](int c, int bslot) {  // (the key-row offset rides in the VGPR offset: the descriptor's range check covers it)
+    const uint32_t b0 = lds0 + bslot * VD_BUFB, ro = (uint32_t)(c * VA_CHUNK) * (uint32_t)(C3 * 2);
+#pragma unroll
+    for (int i = 0; i < NPC / 2; ++i) gemm_dma16(b0 + kdst[i], kvo[i] + ro, rs, 0);
+#pragma unroll
+    for (int i = 0; i < NPC / 2; ++i) gemm_dma16(b0 + vdst[i], vvo[i] + ro, rs, 0);
+  };
+  const int nchunks = (T + VA_CHUNK - 1) / VA_CHUNK;
+  issue_chunk(0, 0);
+
+  bf16x8 qf[QB][4];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int tq = min(q0 + qb * 32 + col, T - 1);
+    const u16 *qp = base + (size_t)tq * C3 + h * 64 + hb * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8 *>(qp + ks * 16);
+  }
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[qb][ks]));  // the Q loads are complete HERE (see above)
+  f32x16 o[QB][2];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -3e38f;
+    l_run[qb] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qb][t][r] = 0.f;
+  }
+  uint32_t koff[4];  // K fragment of key row kt + col (kt a multiple of 32), k-step ks: 16-byte chunk 2 ks + hb, swizzled by the row
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = (uint32_t)(col * 128 + (((2 * ks + hb) ^ ((col >> 1) & 7)) << 4));
+  const uint32_t vlane_off = (uint32_t)(VD_KBYTES + ((lane >> 4) & 1) * VD_VSUBB + (4 * hb + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8);
+
+  auto tile = [&](const char *buf, int c0, int kt, bool partial) {
+    f32x16 s[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[qb][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(buf + kt * 128 + koff[ks]);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], s[qb], 0, 0, 0);
+    }
+    if (partial) {  // the one partial tile of the sequence: keys >= T are masked out
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (c0 + kt + (r & 3) + 8 * (r >> 2) + 4 * hb >= T) s[qb][r] = -3e38f;
+    }
+    const char *vlane = buf + vlane_off;
+    union PF { bf16x8 v; uint32_t w[4]; } pf[QB][2];
+    float alpha[QB];
+    bool moved = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float mx = s[qb][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qb][r]);
+      const auto sm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sm[0]), __uint_as_float(sm[1])) * scale_log2e;
+      const bool grow = mx > m_run[qb] + VA_DEFER;
+      const float m_use = grow ? mx : m_run[qb];
+      alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
+      m_run[qb] = m_use;
+      moved |= grow;
+      float ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[qb][r] = __builtin_amdgcn_exp2f(fmaf(s[qb][r], scale_log2e, -m_use));
+        ls += s[qb][r];
+      }
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
+      l_run[qb] = fmaf(l_run[qb], alpha[qb], __uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf[qb][s2].w[e] = va_cvt_pk(s[qb][s2 * 8 + 2 * e], s[qb][s2 * 8 + 2 * e + 1]);
+    }
+    auto v_frag = [&](int s2, int t) {
+      const char *vp = vlane + t * 2 * VD_VSUBB + (kt + s2 * 16) * 32;
+      union { bf16x8 v; s16x4 h4[2]; } vf;
+      vf.h4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp));
+      vf.h4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vp + 8 * 32));
+      return vf.v;
+    };
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 vf = v_frag(s2, t);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) o[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][s2].v, o[qb][t], 0, 0, 0);
+      }
+    if (__builtin_expect(__any(moved), 0)) {  // rare after the first tile: re-reference the accumulators of the queries that moved
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 v0 = v_frag(0, t), v1 = v_frag(1, t);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          f32x16 d;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[r] = 0.f;
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[qb][0].v, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[qb][1].v, d, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[qb][t][r] = fmaf(o[qb][t][r] - d[r], alpha[qb], d[r]);
+        }
+      }
+    }
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk 0 landed; every wave's pieces visible after the barrier
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) issue_chunk(c + 1, (c + 1) & 1);  // (that buffer was last read in chunk c - 1, before the barrier that ended it)
+    if (active) {
+      const int c0 = c * VA_CHUNK, nk = min(VA_CHUNK, T - c0);
+      const char *buf = smemd + (c & 1) * VD_BUFB;
+      int kt = 0;
+      for (; kt + 32 <= nk; kt += 32) tile(buf, c0, kt, false);
+      if (kt < nk) tile(buf, c0, kt, true);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (!active) return;
+  // ---- normalise, transpose through LDS, store token rows
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float inv = 1.f / l_run[qb];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ot[wave][col][t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb] = va_f2bf(o[qb][t][r] * inv);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3), seg = lane & 7;
+      const int tq = q0 + qb * 32 + row;
+      if (tq < T) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(&Ot[wave][row][seg * 8]);
+        *reinterpret_cast<uint4 *>(out + ((size_t)b * T + tq) * (H * 64) + h * 64 + seg * 8) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 }  // namespace unopose
 
 using namespace unopose;
+
+static int launch_vit_attn_dma(const void *qkv, int B, int T, int H, void *out, hipStream_t stream) {
+  constexpr int NW = 4;
+  static bool opt[64];
+  const size_t lds = (size_t)2 * VD_BUFB;
+  if (lds_optin(opt, reinterpret_cast<const void *>(&vit_attn_kernel_dma<NW>), lds, "vit_attention") != UNOPOSE_OK) return UNOPOSE_ELAUNCH;
+  const int BH = B * H, nq = cdiv(T, 32 * NW * 2);
+  const long blocks = (long)cdiv(BH, 8) * nq * 8;
+  hipLaunchKernelGGL((vit_attn_kernel_dma<NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, (const u16 *)qkv, T, H, BH, nq,
+                     0.125f * 1.4426950408889634f, (u16 *)out);
+  return check_launch("vit_attention");
+}
 
 template <int QB, int NBUF, int NW, bool PIPE = false>
 static int launch_vit_attn(const void *qkv, int B, int T, int H, void *out, hipStream_t stream) {
@@ -363,6 +582,8 @@ int unopose_vit_attention(const void *qkv, int B, int T, int H, void *out, unopo
   static const int nw_env = getenv("UNOPOSE_VIT_NW") ? atoi(getenv("UNOPOSE_VIT_NW")) : 8;
   static const int qb4_env = getenv("UNOPOSE_VIT_QB4") ? atoi(getenv("UNOPOSE_VIT_QB4")) : 0;  // experiment: 1 wave / SIMD, 128 queries / wave
   if (T >= 1024 && qb4_env == 1) return launch_vit_attn<4, 2, 4>(qkv, B, T, H, out, (hipStream_t)stream);
+  static const int dma_env = getenv("UNOPOSE_VIT_DMA") ? atoi(getenv("UNOPOSE_VIT_DMA")) : 1;  // 0: round 3's register-staged 8-wave kernel (A/B)
+  if (T >= 1024 && dma_env == 1 && (size_t)T * 3 * H * 64 * 2 < (1UL << 31)) return launch_vit_attn_dma(qkv, B, T, H, out, (hipStream_t)stream);
   static const int pipe_env = getenv("UNOPOSE_VIT_PIPE") ? atoi(getenv("UNOPOSE_VIT_PIPE")) : 0;
   if (T >= 1024 && pipe_env == 1) return launch_vit_attn<2, 2, 8, true>(qkv, B, T, H, out, (hipStream_t)stream);
   if (T >= 1024 && nw_env == 8) return launch_vit_attn<2, 2, 8>(qkv, B, T, H, out, (hipStream_t)stream);
