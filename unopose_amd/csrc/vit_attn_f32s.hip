@@ -19,9 +19,12 @@ namespace unopose {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int VS_CHUNK = 128;           // keys staged per LDS chunk
+#ifndef VS_CHUNK_KEYS
+#define VS_CHUNK_KEYS 128
+#endif
+constexpr int VS_CHUNK = VS_CHUNK_KEYS;  // keys staged per LDS chunk (128, or 64: half the LDS, two workgroups per CU)
 constexpr int VS_KPLANE = VS_CHUNK * 128;  // bytes of a K plane [key][64 channels] bf16; 16-byte chunk c of row r sits at c ^ ((r >> 1) & 7)
-constexpr int VS_VSUBB = 128 * 32 + 128;   // bytes per V sub-tile [128 keys][16 channels] (+ bank skew), 4 per plane
+constexpr int VS_VSUBB = VS_CHUNK * 32 + 128;   // bytes per V sub-tile [128 keys][16 channels] (+ bank skew), 4 per plane
 constexpr int VS_VPLANE = 4 * VS_VSUBB;
 constexpr int VS_VOFF = 2 * VS_KPLANE;     // K hi | K lo | V hi | V lo
 constexpr int VS_BUFB = 2 * VS_KPLANE + 2 * VS_VPLANE;  // 66560 B
@@ -47,14 +50,14 @@ struct HLf {
 // qkv_s: (B, T) token rows of 3 * H * 64 values in the split layout (3 * H * 256 bytes per token: q blocks | k blocks | v blocks,
 // head h = blocks 2h, 2h + 1 of each third); out_s: (B, T) rows of H * 64 values in the split layout.
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void vit_attn_f32s_kernel(const char *__restrict__ qkv_s, int T, int H,
+__global__ __launch_bounds__(NW * 64, VS_CHUNK == 64 ? 2 : 1) void vit_attn_f32s_kernel(const char *__restrict__ qkv_s, int T, int H,
                                                                                                      int BH, int nq, float scale_log2e,
                                                                                                      char *__restrict__ out_s) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   float (*Ot)[32][68] = reinterpret_cast<float (*)[32][68]>(smem);
   static_assert(NW * 32 * 68 * 4 <= 2 * VS_BUFB, "output staging must fit the chunk buffers");
   constexpr int NT = NW * 64;
-  static_assert(NT == 512 || NT == 768 || NT == 1024, "8, 12 or 16 wavefronts per workgroup");
+  static_assert(NT == 384 || NT == 512 || NT == 768 || NT == 1024, "6, 8, 12 or 16 wavefronts per workgroup");
   // workgroup -> (image, head, query block): all query blocks of one (image, head) share id % 8 (one XCD's L2 holds its K / V)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int bh = (slot / nq) * 8 + xcd, qblk = slot % nq;
@@ -71,26 +74,27 @@ __global__ __launch_bounds__(NW * 64) void vit_attn_f32s_kernel(const char *__re
   //      32 keys), 1 KiB each; wave w issues K pieces 4w .. 4w + 3 and V pieces 4w .. 4w + 3.  Rows past the image arrive as zeros.
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)((size_t)T * RB), 0x00020000);
-  constexpr int NP = (32 + NW - 1) / NW;  // pieces of K (and of V) per wave: piece ids wave, wave + NW, ... < 32
+  constexpr int NPC = VS_CHUNK / 4, KP = VS_CHUNK / 8, VG = VS_CHUNK / 32;  // pieces of K (and of V) per chunk; K pieces / V key groups per plane
+  constexpr int NP = (NPC + NW - 1) / NW;  // pieces of K (and of V) per wave: piece ids wave, wave + NW, ... < NPC
   uint32_t kvo[NP], vvo[NP], kdst[NP], vdst[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    const int kp = min(wave + i * NW, 31), p = kp >> 4, rg = kp & 15;
+    const int kp = min(wave + i * NW, NPC - 1), p = kp / KP, rg = kp % KP;
     const int krow = 8 * rg + (lane >> 3), gch = (lane & 7) ^ ((krow >> 1) & 7);
     kvo[i] = (uint32_t)(krow * (int)RB + koff + (gch >> 2) * 128 + (gch & 3) * 16 + p * 64);
     kdst[i] = (uint32_t)(p * VS_KPLANE + rg * 1024);
-    const int sub = (kp >> 2) & 3, kq = kp & 3, vkey = 32 * kq + (lane >> 1), ch = sub * 16 + (lane & 1) * 8;
-    vvo[i] = (uint32_t)(vkey * (int)RB + voff + (ch >> 5) * 128 + (ch & 31) * 2 + p * 64);
-    vdst[i] = (uint32_t)(VS_VOFF + p * VS_VPLANE + sub * VS_VSUBB + kq * 1024);
+    const int pv = kp / (4 * VG), sub = (kp / VG) & 3, kq = kp % VG, vkey = 32 * kq + (lane >> 1), ch = sub * 16 + (lane & 1) * 8;
+    vvo[i] = (uint32_t)(vkey * (int)RB + voff + (ch >> 5) * 128 + (ch & 31) * 2 + pv * 64);
+    vdst[i] = (uint32_t)(VS_VOFF + pv * VS_VPLANE + sub * VS_VSUBB + kq * 1024);
   }
   auto issue_chunk = [&](int c, int bslot) {
     const uint32_t b0 = lds0 + bslot * VS_BUFB, ro = (uint32_t)(c * VS_CHUNK) * (uint32_t)RB;
 #pragma unroll
     for (int i = 0; i < NP; ++i)
-      if (wave + i * NW < 32) gemm_dma16(b0 + kdst[i], kvo[i] + ro, rs, 0);  // (wave-uniform)
+      if (wave + i * NW < NPC) gemm_dma16(b0 + kdst[i], kvo[i] + ro, rs, 0);  // (wave-uniform)
 #pragma unroll
     for (int i = 0; i < NP; ++i)
-      if (wave + i * NW < 32) gemm_dma16(b0 + vdst[i], vvo[i] + ro, rs, 0);
+      if (wave + i * NW < NPC) gemm_dma16(b0 + vdst[i], vvo[i] + ro, rs, 0);
   };
   const int nchunks = (T + VS_CHUNK - 1) / VS_CHUNK;
   issue_chunk(0, 0);
