@@ -49,13 +49,13 @@ constexpr float VA_DEFER = 8.f;
 #define VA_INTERLEAVE VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1 VA_IL1
 
 template <int QB, int NW, int NBUF>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void vit_attn2_kernel(const u16 *__restrict__ qkv, int T, int H, int BH, int nq,
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : (NW == 2 ? 4 : 1)) void vit_attn2_kernel(const u16 *__restrict__ qkv, int T, int H, int BH, int nq,
                                                                                                       float scale_log2e, u16 *__restrict__ out) {
   constexpr int NPC = 32 / NW;  // LDS-DMA pieces per wave and chunk: NPC / 2 of K, NPC / 2 of V
-  static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 wavefronts");
+  static_assert(NW == 2 || NW == 4 || NW == 8 || NW == 16, "2, 4, 8 or 16 wavefronts");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   u16 (*Ot)[32][72] = reinterpret_cast<u16 (*)[32][72]>(smem);
-  static_assert(NW * 32 * 72 * 2 <= NBUF * VA_BUFB, "output staging must fit the chunk buffers");
+  static_assert(NW * 32 * 72 * 2 * (VA_QB == 2 ? 1 : 1) <= NBUF * VA_BUFB, "output staging must fit the chunk buffers");
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int bh = (slot / nq) * 8 + xcd, qblk = slot % nq;
   if (bh >= BH) return;
@@ -377,7 +377,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void vit_attn2_kernel(con
 
   // chunk 0 landed (chunk 1 may still fly), every wave's pieces visible
   auto wait_all_but_one_chunk = [&]() {
-    if (NPC == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (NPC == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (NPC == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (NPC == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   };
@@ -386,6 +387,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void vit_attn2_kernel(con
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   int bslot = 0;
+  if (NBUF == 1) {  // one chunk buffer: load, wait, compute -- the CU's other workgroups compute meanwhile
+    for (int c = 0; c < nchunks; ++c) {
+      if (c > 0) {
+        issue_chunk(c, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      if (active) chunk_compute(c * VA_CHUNK, smem);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  } else
   for (int c = 0; c < nchunks; ++c) {
     int nslot = bslot + NBUF - 1;
     if (nslot >= NBUF) nslot -= NBUF;
