@@ -86,10 +86,27 @@ int *gemm_sched_slot() {
 }
 }  // namespace unopose
 
+// Round 5: the four-wave kernel (gemm4w.hip) takes the shapes its stream supports when a ticket slot is at hand.
+namespace unopose {
+bool gemm4w_ok(long M, int N, int K, int lda, int ldw, int ldc, int epilogue);
+int gemm4w_linear(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, long M, int N, int K, int epilogue, int nt,
+                  int *sched, hipStream_t s);
+}  // namespace unopose
+#ifndef GEMM_4W
+#define GEMM_4W 1
+#endif
+static int g_use_4w = GEMM_4W;
+
 static int linear_bf16_dispatch(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, long M, int N, int K,
                                 int epilogue, hipStream_t s, const char *what) {
   const int tiles_n = N / GEMM_BN;
   const int tiles = cdiv(M, GEMM_BM) * tiles_n;
+  if (g_use_4w == 2 && gemm4w_ok(M, N, K, lda, ldw, ldc, epilogue)) {  // (forced: tests drive small tile counts through the stream as well)
+    if (int *const sched4 = gemm_sched_slot()) {
+      gemm4w_linear(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, use_nt_store(M, N), sched4, s);
+      return check_launch(what);
+    }
+  }
   if (tiles < small_tiles_limit()) return gemm_small_linear(A, W, bias, C, M, N, K, lda, ldw, ldc, epilogue, s);
   const int n_cu = gemm_cu_count();
   const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
@@ -98,6 +115,12 @@ static int linear_bf16_dispatch(const void *A, int lda, const void *W, int ldw, 
   hipLaunchKernelGGL(gemm256_kernel<E>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N, K, tiles_n, \
                      tiles, nt, (const int *)nullptr, (const int *)nullptr, (const u16 *)nullptr, (const float *)nullptr,                     \
                      (const float *)nullptr, 0.f, lda, ldw, ldc, sched)
+  if (g_use_4w && tiles >= n_cu && gemm4w_ok(M, N, K, lda, ldw, ldc, epilogue)) {
+    if (int *const sched4 = gemm_sched_slot()) {
+      gemm4w_linear(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, nt, sched4, s);
+      return check_launch(what);
+    }
+  }
   int *const sched = tiles > grid ? gemm_sched_slot() : nullptr;  // (one tile per workgroup: nothing to schedule)
   if (epilogue == 1)
     UNOPOSE_LD_LAUNCH(1);
@@ -112,6 +135,12 @@ static int linear_bf16_dispatch(const void *A, int lda, const void *W, int ldw, 
 extern "C" {
 
 int unopose_gemm_bf16_tile(void) { return GEMM_BM; }
+
+int unopose_gemm4w_enable(int on) {
+  const int was = g_use_4w;
+  if (on >= 0) g_use_4w = on > 2 ? 2 : on;  // 0: off, 1: shapes with at least one tile per CU, 2: every shape the stream supports
+  return was;
+}
 
 int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C, long M, int N, int K, int epilogue,
                         unopose_stream_t stream) {
