@@ -73,29 +73,48 @@ class Raw:
         return self.s
 
 
+def issue_cost(i):
+    """issue slots an instruction keeps its wave busy for, in units of a plain VALU / SALU instruction: what a gap's capacity is counted in.
+    (measured with 5 fragment reads in one gap: every substep lost ~100 cycles -- a wave-wide ds_read_b128 or LDS-DMA piece is several
+    plain slots long, and one wave per SIMD has nobody to issue the next MFMA meanwhile)"""
+    k = i.kind
+    if k in ("label", "waitvm", "waitlgkm", "wait", "entry"):
+        return 0
+    if k == "nop":
+        return 1 + i.ops[0]
+    if k == "ds":
+        return 3 if i.op == "ds_read_b128" else 2
+    if k in ("dma", "store", "atomic", "gmem", "trans"):
+        return 2
+    return 1
+
+
 class Item:
     """A filler: instructions that stay together, a window of gaps [lo, hi], optionally a preferred gap."""
-    __slots__ = ("ins", "lo", "hi", "want", "sec", "slots")
+    __slots__ = ("ins", "lo", "hi", "want", "sec", "slots", "heavy")
 
     def __init__(self, ins, lo=None, hi=None, want=None, sec="body"):
         self.ins = ins if isinstance(ins, list) else [ins]
         self.lo, self.hi, self.want, self.sec = lo, hi, want, sec
-        self.slots = sum(1 + (i.ops[0] if i.kind == "nop" else 0) for i in self.ins if i.kind not in ("label", "waitvm", "waitlgkm"))
+        self.slots = sum(issue_cost(i) for i in self.ins)
+        self.heavy = sum(1 for i in self.ins if i.kind in ("ds", "dma", "store", "atomic", "gmem"))   # wave-wide memory instructions
 
 
 class Sched:
     """Gaps -1 .. n-1: gap g follows MFMA g (gap -1 precedes the first MFMA).  Each gap has three sections: pre, body, post."""
 
-    def __init__(self, mfmas, cap):
-        self.mfmas, self.n, self.cap = mfmas, len(mfmas), cap
+    def __init__(self, mfmas, cap, hcap=1):
+        self.mfmas, self.n, self.cap, self.hcap = mfmas, len(mfmas), cap, hcap
         self.gaps = {g: {"pre": [], "body": [], "post": []} for g in range(-1, self.n)}
         self.count = {g: 0 for g in range(-1, self.n)}
+        self.hcount = {g: 0 for g in range(-1, self.n)}
         self.over = 0
 
     def fixed(self, g, ins, sec="body"):
         it = ins if isinstance(ins, Item) else Item(ins)
         self.gaps[g][sec].append(it)
         self.count[g] += it.slots
+        self.hcount[g] += it.heavy
 
     def stream(self, items, lo, hi, spread=True):
         """Place the items of one in-order stream between gaps lo and hi: evenly (spread) or as early as the caps allow."""
@@ -110,12 +129,13 @@ class Sched:
                 want = it.want
             g = min(max(ilo, int(want), g_prev), ihi)
             g = max(g, g_prev)
-            while g < ihi and self.count[g] + it.slots > self.cap:
+            while g < ihi and (self.count[g] + it.slots > self.cap or (it.heavy and self.hcount[g] + it.heavy > self.hcap)):
                 g += 1
             if self.count[g] + it.slots > self.cap:
                 self.over += min(it.slots, self.count[g] + it.slots - self.cap)
             self.gaps[g][it.sec].append(it)
             self.count[g] += it.slots
+            self.hcount[g] += it.heavy
             g_prev = g
 
     def emit(self):
@@ -136,9 +156,10 @@ def quad_of(q):
 
 
 class Gen:
-    def __init__(self, epi=0, nt=False, cap=5, n3_mid=8, n3_seam=4, bar_after=2, uid="0", drain_cap=4, cap_f=None, cap_l=None, cap_pre=None,
-                 cap_mid=None, units_per_mid=None, null_desc=1, piece_nop=-1, piece_sep=0):
-        self.null_desc, self.piece_nop, self.piece_sep = null_desc, piece_nop, piece_sep
+    def __init__(self, epi=0, nt=False, cap=6, n3_mid=4, n3_seam=4, bar_after=2, uid="0", drain_cap=4, cap_f=None, cap_l=None, cap_pre=None,
+                 cap_mid=None, units_per_mid=None, null_desc=1, piece_nop=-1, bar_gap=0, abl=0, hcap=1):
+        self.hcap = hcap
+        self.null_desc, self.piece_nop, self.bar_gap, self.abl = null_desc, piece_nop, bar_gap, abl   # abl (timing probes, wrong results): 1 no LDS-DMA in the blocks, 2 no MFMAs, 3 no drain / epilogue, 4 no barriers
         self.epi, self.nt, self.cap = epi, nt, cap
         self.cap_by = {"F": cap_f, "L": cap_l, "pre": cap_pre, "mid": cap_mid}
         self.n3_mid, self.n3_seam, self.bar_after = n3_mid, n3_seam, bar_after
@@ -202,6 +223,8 @@ class Gen:
         ins = [Ins("s_add_u32", M0, DMABW, dst),
                Ins("v_add_u32", pair[0], 8 * q, IDXA if is_a else IDXW),
                Ins("buffer_load_dwordx4", pair, DA if is_a else DW, KOFF, addr="idxen offen", tag=tag)]
+        if self.abl == 1 and tag in ("g", "h"):
+            ins[2] = Ins("s_nop", 0, tag=tag)
         if self.piece_nop >= 0:
             ins.append(Ins("s_nop", self.piece_nop))
         return Item(ins)
@@ -400,11 +423,14 @@ class Gen:
                 mf.append(self.mfma(mb, nb, fs[4 * ws:4 * ws + 4], fs[4 * as_:4 * as_ + 4]))
             sub_last.append(len(mf) - 1)
         n = len(mf)
-        sc = Sched(mf, self.cap_by.get("pre" if j == "pre" else kind) or self.cap)
+        sc = Sched(mf, self.cap_by.get("pre" if j == "pre" else kind) or self.cap, self.hcap)
         n3 = self.n3_mid if kind == "mid" else self.n3_seam
         cont = 16 - len([t for t in vm_in if t == "g"])   # pieces of the pending group still to issue (vm_in: tags of outstanding LOADS)
         last = nsub - 1
         b = sub_first[last] + self.bar_after - 1        # the barrier follows MFMA b
+        early = kind == "mid" and self.bar_gap and self.bar_gap < sub_first[last]
+        if early:                                       # (mid blocks: as soon as the last substep's fragments have been read)
+            b = self.bar_gap
         # ---- entry: this block's first fragments were read by the previous block
         sc.fixed(-1, Item(wait_lgkm("f0")), "post")
         if pre:
@@ -424,12 +450,15 @@ class Gen:
         sc.stream(cont_items, 0, b - 1, spread=False)
         # ---- the block's barrier: the next K-tile has landed everywhere, this one has been read by everybody
         bar = [wait_vm("g")]
+        if early:
+            bar.insert(0, wait_lgkm(f"f{last & 1}"))
         if kind == "mid" and j == 0:
             bar += self.ticket_post()
-        bar.append(Ins("s_barrier"))
+        if self.abl != 4:
+            bar.append(Ins("s_barrier"))
         sc.fixed(b, Item(bar), "post")
         tog = self.r_toggle()
-        sc.stream(tog, sub_last[last - 1] - 1, b, spread=False)
+        sc.stream(tog, sub_first[last - 1] + len(subs[last][0]) + 1 if not early else b - 3, max(b, sub_first[last]), spread=True)
         # ---- after the barrier: the next block's first fragments (other buffer) and the start of the next group
         after = self.read_items(self.substeps(next_pattern)[0][0], FSET[0], "f0")
         grp = [self.dma_piece(p, "h") for p in range(n3)]
@@ -437,7 +466,7 @@ class Gen:
             grp.append(self.group_end())
         if kind == "mid" and j == 0:
             after.insert(0, Item([Ins("v_mov_b32", X[2], LDS_MBOX), Ins("s_nop", 0), Ins("ds_read_b32", TK, X[2], tag="mb")]))
-        sc.stream(after, b + 1, n - 1, spread=False)
+        sc.stream(after, max(b + 1, sub_first[last] + 1), n - 1, spread=False)
         sc.stream(grp, b + 1, n - 1, spread=True)
         # ---- block-specific work
         if kind == "F":
@@ -464,14 +493,19 @@ class Gen:
                     ep += self.epi_stage(u, self.unit_temps(u))
                     if u != (j + 1) * U - 1:
                         ep += self.epi_store(u)
-            sc.stream(ep, 1, b - 1, spread=(self.epi == 1))
-        if drain:
+            if self.abl != 3:
+                sc.stream(ep, 1, b - 1, spread=(self.epi == 1))
+        if drain and self.abl != 3:
             sc.stream(drain, 0, n - 1, spread=False)
         self.over[(kind, j)] = sc.over
         seq = sc.emit()
+        if self.abl == 2:
+            seq = [i for i in seq if i.kind != "mfma"]
         seq, vm, lg = resolve_waits(seq, vm_in, lg_in)
         # canonical exit state: the loads outstanding are the first pieces of the next group
         vm = [t for t, ld in vm if ld]
+        if self.abl == 1:
+            vm = [t for t in vm if t not in ("g", "h")] + ["h"] * n3
         assert [t for t in vm if t == "h"] == vm[len(vm) - n3:] and len([t for t in vm if t == "h"]) == n3 and "g" not in vm, (kind, j, vm)
         vm = ["g" if t == "h" else t for t in vm]
         return seq, vm, lg
@@ -577,7 +611,7 @@ class Gen:
         # the first tile has no predecessor: F's lazy epilogue finds a descriptor with 0 records (set above)
         s += [Ins("s_mov_b32", NM0, CM0), Ins("s_mov_b32", NN0, CN0), Ins("s_mov_b32", TIN, TI), Ins("s_branch", self.L("F_body"))]
         seq, vm, lg = resolve_waits(s)
-        vm = [t for t in vm if t[0] == "g"]
+        vm = [t for t in vm if t[0] == "g"] if self.abl != 1 else ["g"] * self.n3_seam
         assert len(vm) == self.n3_seam and [t for t in lg if t] == ["f0"] * 8, (vm, lg)
         return seq, ["g"] * self.n3_seam, ["f0"] * 8
 
