@@ -421,6 +421,11 @@ int unopose_transpose_pad_bf16(const void *v, long ld, int B, int m, int C, int 
 int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C, long M, int N, int K,
                         int epilogue, unopose_stream_t stream);
 int unopose_gemm_bf16_tile(void);
+/* Kernel choice of unopose_linear_bf16(_ld) for the shapes both forms support: 0 (default) = the 8-wave kernel, 1 = the four-wave
+ * one-wave-per-SIMD kernel (csrc/gemm4w.hip) where a launch gives every CU a tile, 2 = the four-wave kernel for every shape its stream
+ * supports (K >= 512; with GELU K >= 768).  on < 0 only queries.  Returns the previous setting.  Same results up to the summation
+ * order; GELU is evaluated on the bf16-rounded pre-activation by the four-wave kernel, on the fp32 accumulator by the 8-wave one. */
+int unopose_gemm4w_enable(int on);
 
 /* Small batched float32 contraction on the exact-fp32 matrix instruction (an fma chain, one rounding per product):
  *     C[(bo,bi)][i][j] = alpha * sum_k A[bo sab + bi sah + i sai + k sak] * Bm[bo sbb + bi sbh + j sbj + k sbk],  C (bo*bi, n, m) row-major.

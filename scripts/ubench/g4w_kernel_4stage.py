@@ -29,8 +29,8 @@ FSET = (V(128, 32), V(160, 32))
 T = V(192, 16)
 BF = V(208, 16)
 ONES = V(224, 4)
-RA = V(228, 4)
-RW = V(232, 4)
+RA = V(228, 2)   # fragment read bases of the A / W image for the two k-substeps of a stage (ring-pair bit toggled per block)
+RW = V(232, 2)
 IDXA, IDXW = V(236), V(237)
 PE, PO = V(238, 2), V(240, 2)   # [row index, byte offset] pairs of the LDS-DMA source address: even / odd pieces
 VRW = V(242)                    # 64 * wave + (lane >> 3): the lane's row within the workgroup's 256-row operand tile
@@ -48,6 +48,7 @@ DA, DW, DC, DB = S(28, 4), S(32, 4), S(36, 4), S(40, 4)
 A_PTR, W_PTR, B_PTR, C_PTR, SCHED = S(44, 2), S(46, 2), S(48, 2), S(50, 2), S(52, 2)
 a_M, a_N, a_K, a_LDA, a_LDW, a_LDC = (S(54 + i) for i in range(6))
 a_NK, a_TN, a_NSLOT, a_MGTN, a_MGNS, a_MGNK, a_CW, a_MGCW, a_CWL, a_MGCWL, a_NCB1, a_COLW, a_GRID = (S(60 + i) for i in range(13))
+a_NK2 = S(73)      # stages per tile = 2 nk (computed)
 TP = S(74, 2)      # 64-bit temporary (kernarg dwords 30, 31 are padding)
 CBASE, CLEN, RBASE, PB, MGPB = (S(76 + i) for i in range(5))
 XCD5, WAVE, BID = S(81), S(82), S(83)
@@ -159,7 +160,7 @@ class Gen:
     def __init__(self, epi=0, nt=False, cap=6, n3_mid=4, n3_seam=4, bar_after=2, uid="0", drain_cap=4, cap_f=None, cap_l=None, cap_pre=None,
                  cap_mid=None, units_per_mid=None, null_desc=1, piece_nop=-1, bar_gap=0, abl=0, hcap=1):
         self.hcap = hcap
-        self.null_desc, self.piece_nop, self.bar_gap, self.abl = null_desc, piece_nop, bar_gap, abl   # abl (timing probes, wrong results): 1 no LDS-DMA in the blocks, 2 no MFMAs, 3 no drain / epilogue, 4 no barriers, 5 MFMAs alone (no DMA, no fragment reads, no barriers), 6 no DMA, no barriers
+        self.null_desc, self.piece_nop, self.bar_gap, self.abl = null_desc, piece_nop, bar_gap, abl   # abl (timing probes, wrong results): 1 no LDS-DMA in the blocks, 2 no MFMAs, 3 no drain / epilogue, 4 no barriers
         self.epi, self.nt, self.cap = epi, nt, cap
         self.cap_by = {"F": cap_f, "L": cap_l, "pre": cap_pre, "mid": cap_mid}
         self.n3_mid, self.n3_seam, self.bar_after = n3_mid, n3_seam, bar_after
@@ -186,7 +187,9 @@ class Gen:
         return Ins("v_mfma_f32_32x32x16_bf16", self.acc(mb, nb), wf, af, self.acc(mb, nb))
 
     def frag_read(self, dst, is_a, idx, ks, tag):
-        return Ins("ds_read_b128", dst, (RA if is_a else RW)[ks], offset=idx * 4096, tag=tag)
+        """fragment (32-row block idx, k-substep ks of the 64-k block) of the A / W image: ks 0, 1 lie in the block's first stage, 2, 3 in
+        its second one (the ring slot 32 KiB further)"""
+        return Ins("ds_read_b128", dst, (RA if is_a else RW)[ks & 1], offset=(ks >> 1) * 32768 + idx * 2048, tag=tag)
 
     def substeps(self, pattern):
         """[(fragment reads [(slot, is_a, idx, ks)], MFMAs [(mb, nb, w slot, a slot)])]"""
@@ -216,27 +219,28 @@ class Gen:
         return [Item(self.frag_read(fset[4 * slot:4 * slot + 4], is_a, idx, ks, tag)) for slot, is_a, idx, ks in reads]
 
     def dma_piece(self, p, tag):
-        """this wave's piece p of a 16-piece group (0..7: A rows 64 w + 8 p .., 8..15: W rows): 8 rows x 128 B into the buffer at DMABW"""
-        is_a, q = p < 8, p % 8
+        """this wave's piece p of an 8-piece group = one STAGE (32 k) of the operand tiles (0..3: A rows 64 w + 16 p .., 4..7: W rows):
+        16 rows x 64 B into the ring slot at DMABW"""
+        is_a, q = p < 4, p % 4
         pair = PE if q % 2 == 0 else PO
-        dst = (0 if is_a else 32768) + q * 1024
+        dst = (0 if is_a else 16384) + q * 1024
         ins = [Ins("s_add_u32", M0, DMABW, dst),
-               Ins("v_add_u32", pair[0], 8 * q, IDXA if is_a else IDXW),
+               Ins("v_add_u32", pair[0], 16 * q, IDXA if is_a else IDXW),
                Ins("buffer_load_dwordx4", pair, DA if is_a else DW, KOFF, addr="idxen offen", tag=tag)]
-        if self.abl in (1, 5, 6) and tag in ("g", "h"):
+        if self.abl == 1 and tag != "pro":
             ins[2] = Ins("s_nop", 0, tag=tag)
         if self.piece_nop >= 0:
             ins.append(Ins("s_nop", self.piece_nop))
         return Item(ins)
 
     def group_end(self):
-        """after the last piece of a group: the other buffer, the next K-tile of the tile the stream is in"""
-        return Item([Ins("s_xor_b32", DMABW, DMABW, 65536),
-                     Ins("s_add_u32", KTD, KTD, 1), Ins("s_cmp_eq_u32", KTD, a_NK), Ins("s_cselect_b32", KTD, 0, KTD),
-                     Ins("s_lshl_b32", KOFF, KTD, 7)])
+        """after the last piece of a group: the next ring slot, the next stage of the tile the stream is in"""
+        return Item([Ins("s_add_u32", DMABW, DMABW, 32768), Ins("s_and_b32", DMABW, DMABW, 0x1FFFF),
+                     Ins("s_add_u32", KTD, KTD, 1), Ins("s_cmp_eq_u32", KTD, a_NK2), Ins("s_cselect_b32", KTD, 0, KTD),
+                     Ins("s_lshl_b32", KOFF, KTD, 6)])
 
     def r_toggle(self):
-        return [Item(Ins("v_xor_b32", r, 65536, r)) for r in [RA[i] for i in range(4)] + [RW[i] for i in range(4)]]
+        return [Item(Ins("v_xor_b32", r, 65536, r)) for r in [RA[0], RA[1], RW[0], RW[1]]]
 
     def drain_block(self, mb, nb):
         b = mb * 4 + nb
@@ -341,7 +345,7 @@ class Gen:
 
     def stream_switch(self):
         """the LDS-DMA stream moves on to the next tile (NM0, NN0, NROT); no next tile: null descriptors (the loads touch nothing)"""
-        ins = [Ins("v_add_u32", IDXA, NM0, VRW), Ins("v_add_u32", IDXW, NN0, VRW), Ins("s_mov_b32", KTD, NROT), Ins("s_lshl_b32", KOFF, NROT, 7)]
+        ins = [Ins("v_add_u32", IDXA, NM0, VRW), Ins("v_add_u32", IDXW, NN0, VRW), Ins("s_lshl_b32", KTD, NROT, 1), Ins("s_lshl_b32", KOFF, NROT, 7)]
         if self.null_desc:
             ins += [Ins("s_cmp_eq_u32", MORE, 0), Ins("s_cselect_b32", DA[2], 0, DA[2]), Ins("s_cselect_b32", DW[2], 0, DW[2])]
         return Item(ins)   # (without null descriptors the loads past the last tile read tile (0, 0): NM0 = NN0 = NROT = 0 then)
@@ -352,9 +356,9 @@ class Gen:
         # column byte offset of the wave's 128 columns: (n0 + wn * 128) * 2
         s += [Ins("s_and_b32", T0, WAVE, 1), Ins("s_lshl_b32", T0, T0, 7), Ins("s_add_u32", T0, T0, CN0), Ins("s_lshl_b32", PCOL0, T0, 1),
               Ins("s_add_u32", PCOL1, PCOL0, 128)]
-        # row index of the lane's staging-read row: m0 + wm * 128 + (lane >> 3) = m0 + wm * 128 - wave * 64 + VRW
-        s += [Ins("s_lshr_b32", T0, WAVE, 1), Ins("s_lshl_b32", T0, T0, 7), Ins("s_add_u32", T0, T0, CM0), Ins("s_lshl_b32", T1, WAVE, 6),
-              Ins("s_sub_u32", T0, T0, T1), Ins("v_add_u32", STIDX, T0, VRW)]
+        # row index of the lane's staging-read row: m0 + wm * 128 + (lane >> 3)
+        s += [Ins("s_lshr_b32", T0, WAVE, 1), Ins("s_lshl_b32", T0, T0, 7), Ins("s_add_u32", T0, T0, CM0)] + self.lane_id(X[0]) + \
+             [Ins("v_lshrrev_b32", X[0], 3, X[0]), Ins("v_add_u32", STIDX, T0, X[0])]
         s += [Ins("s_mov_b32", DC[2], a_M)]   # stores on (a workgroup's first tile has no predecessor: 0 records until here)
         s += [Ins("s_mov_b32", CM0, NM0), Ins("s_mov_b32", CN0, NN0), Ins("s_mov_b32", TI, TIN), Ins("s_xor_b32", BSEL, BSEL, 1024)]
         return s
@@ -400,15 +404,21 @@ class Gen:
 
     def ticket_post(self):
         """wave 0 (its ticket has landed: an older load than the group just waited for): post it in LDS"""
-        body = [Ins("v_readfirstlane_b32", T0, TK), Ins("v_mov_b32", X[2], LDS_MBOX), Ins("v_mov_b32", X[3], T0),
+        body = [Ins("s_waitcnt", kind="wait", vmcnt=0, uncounted=True, tag="tkwait"),   # (count patched: loads issued since the ticket atomic)
+                Ins("v_readfirstlane_b32", T0, TK), Ins("v_mov_b32", X[2], LDS_MBOX), Ins("v_mov_b32", X[3], T0),
                 Ins("ds_write_b32", X[2], X[3], tag="mbw", uncounted=True), Ins("s_waitcnt", kind="wait", lgkmcnt=0, uncounted=True)]
         return self.wave0_only(body)
 
     # ------------------------------------------------------------------------------------------------------------ blocks
-    def block(self, kind, j, vm_in, lg_in, next_pattern, drain=None, pre=None):
-        """kind: 'F' | 'mid' | 'L'.  j: index of a mid block (0..J-1 unrolled with chores, 'loop', 'pre').  Returns (instructions, vm_out, lg_out)."""
-        pattern = "ks" if kind == "mid" else "quad"
-        subs = self.substeps(pattern)
+    def block(self, kind, j, vm_in, lg_in, next_quad, drain=None):
+        """One 64-k block = two 32-k STAGES of the 4-slot ring.  kind: 'F' | 'mid' | 'L'; j: index of a mid block (0..J-1 unrolled with
+        chores, 'loop', 'pre').  vm_in: tags of the LDS-DMA groups still outstanding at entry, oldest first, relative to this block:
+        'A' / 'B' its own stages, 'A2' / 'B2' the next block's, (issued here: 'A4' / 'B4' the stages two blocks ahead).
+        Two barriers: X after the last fragment read of the first stage (its slot is refilled with stage A4), Y after the last read
+        of the second (refilled with B4; the next block's first stage must have landed).  The waits in front of them leave the
+        younger groups in flight: two to three stages (64 - 96 KiB per CU) cross every barrier."""
+        quad = kind != "mid"
+        subs = self.substeps("quad" if quad else "ks")
         nsub = len(subs)
         mf, sub_first, sub_last = [], [], []
         for i, (reads, ms) in enumerate(subs):
@@ -423,67 +433,62 @@ class Gen:
                 mf.append(self.mfma(mb, nb, fs[4 * ws:4 * ws + 4], fs[4 * as_:4 * as_ + 4]))
             sub_last.append(len(mf) - 1)
         n = len(mf)
-        sc = Sched(mf, self.cap_by.get("pre" if j == "pre" else kind) or self.cap, self.hcap)
-        n3 = self.n3_mid if kind == "mid" else self.n3_seam
-        cont = 16 - len([t for t in vm_in if t == "g"])   # pieces of the pending group still to issue (vm_in: tags of outstanding LOADS)
+        sc = Sched(mf, self.cap_by.get("pre" if j == "pre" else kind) or self.cap, self.hcap if not quad else max(2, self.hcap))
+        n3 = self.n3_mid if not quad else self.n3_seam
         last = nsub - 1
-        b = sub_first[last] + self.bar_after - 1        # the barrier follows MFMA b
-        early = kind == "mid" and self.bar_gap and self.bar_gap < sub_first[last]
-        if early:                                       # (mid blocks: as soon as the last substep's fragments have been read)
-            b = self.bar_gap
+        ia = 6 if quad else 1                       # the substep whose fragments are the last reads of the block's first stage
+        gx = sub_first[ia] + self.bar_after - 1     # barrier X follows MFMA gx, Y follows MFMA gy
+        gy = sub_first[last] + self.bar_after - 1
         # ---- entry: this block's first fragments were read by the previous block
         sc.fixed(-1, Item(wait_lgkm("f0")), "post")
-        if pre:
-            for it in pre:
-                sc.fixed(-1, it, "pre")
-        # ---- continuation of the pending LDS-DMA group, then its end
-        cont_items = [self.dma_piece(p, "g") for p in range(16 - cont, 16)] if cont else []
-        if cont:
-            cont_items.append(self.group_end())
-        if kind == "mid" and j == "pre":   # the stream moves on to the next tile between two groups
-            cont_items.append(self.stream_switch())
-        # ---- fragment reads one substep ahead
+        # ---- fragment reads one substep ahead (mid blocks: the second stage's first reads wait for barrier X)
         for i in range(nsub - 1):
             tag = f"f{(i + 1) & 1}"
-            sc.stream(self.read_items(subs[i + 1][0], FSET[(i + 1) & 1], tag), sub_first[i], max(sub_first[i], sub_last[i] - 2), spread=False)
+            lo = sub_first[i] if quad or i != 1 else gx + 1
+            sc.stream(self.read_items(subs[i + 1][0], FSET[(i + 1) & 1], tag), lo, max(lo, sub_last[i] - 2), spread=False)
             sc.fixed(sub_first[i + 1] - 1, Item(wait_lgkm(tag)), "post")
-        sc.stream(cont_items, 0, b - 1, spread=False)
-        # ---- the block's barrier: the next K-tile has landed everywhere, this one has been read by everybody
-        bar = [wait_vm("g")]
-        if early:
-            bar.insert(0, wait_lgkm(f"f{last & 1}"))
+        # ---- barriers
+        barx = [] if quad else [wait_vm("B")]
         if kind == "mid" and j == 0:
-            bar += self.ticket_post()
-        if self.abl not in (4, 5, 6):
-            bar.append(Ins("s_barrier"))
-        sc.fixed(b, Item(bar), "post")
-        tog = self.r_toggle()
-        sc.stream(tog, sub_first[last - 1] + len(subs[last][0]) + 1 if not early else b - 3, max(b, sub_first[last]), spread=True)
-        # ---- after the barrier: the next block's first fragments (other buffer) and the start of the next group
-        after = self.read_items(self.substeps(next_pattern)[0][0], FSET[0], "f0")
-        grp = [self.dma_piece(p, "h") for p in range(n3)]
-        if n3 == 16:
-            grp.append(self.group_end())
-        if kind == "mid" and j == 0:
-            after.insert(0, Item([Ins("v_mov_b32", X[2], LDS_MBOX), Ins("s_nop", 0), Ins("ds_read_b32", TK, X[2], tag="mb")]))
-        sc.stream(after, max(b + 1, sub_first[last] + 1), n - 1, spread=False)
-        sc.stream(grp, b + 1, n - 1, spread=True)
+            barx += self.ticket_post()
+        barx.append(Ins("s_barrier"))
+        sc.fixed(gx, Item(barx), "post")
+        sc.fixed(gy, Item([wait_vm(("A2", "B2") if next_quad else ("A2",)), Ins("s_barrier")]), "post")
+        sc.stream(self.r_toggle(), sub_first[last - 1] + len(subs[last][0]) + 1, gy, spread=True)
+        # ---- the LDS-DMA stream of the block, in order: the rest of the group begun by the block before (B2), the refill of the first
+        #      stage's slot behind X (A4), the start of the refill of the second one behind Y (B4)
+        have = len([t for t in vm_in if t == "B2"])
+        dma = [self.dma_piece(p, "B2") for p in range(have, 8)]
+        if have < 8:
+            dma.append(self.group_end())
+        if kind == "mid" and j == "pre":   # the stream moves on to the next tile between two groups
+            dma.append(self.stream_switch())
+        a4 = [self.dma_piece(p, "A4") for p in range(8)] + [self.group_end()]
+        for it in a4:
+            it.lo = gx + 1
+        b4 = [self.dma_piece(p, "B4") for p in range(n3)] + ([self.group_end()] if n3 == 8 else [])
+        for it in b4:
+            it.lo = gy + 1
+        # ---- behind Y: the next block's first fragments
+        after = self.read_items(self.substeps("quad" if next_quad else "ks")[0][0], FSET[0], "f0")
+        sc.stream(after, gy + 1, n - 1, spread=False)
+        sc.stream(dma + a4 + b4, 0, n - 1, spread=False)
+        if kind == "mid" and j == 0:   # everybody picks the next tile's ticket up behind X
+            sc.stream([Item([Ins("v_mov_b32", X[2], LDS_MBOX), Ins("s_nop", 0), Ins("ds_read_b32", TK, X[2], tag="mb")])], gx + 1, gy - 1, spread=False)
         # ---- block-specific work
         if kind == "F":
             chores = [self.ticket_atomic(), Item(Ins("s_sub_u32", KLEFT, a_NK, 2 + self.J + 1))]
             sc.stream(chores, 2, 12, spread=False)
         if kind == "mid" and j == 1:
-            ch = [Item(Ins("v_readfirstlane_b32", TIN, TK))] + self.tile_params(TIN, NM0, NN0, NROT, valid=MORE)
+            ch = [Item([wait_lgkm("mb"), Ins("v_readfirstlane_b32", TIN, TK)])] + self.tile_params(TIN, NM0, NN0, NROT, valid=MORE)
             ch.append(self.bias_dma(NN0, [Ins("s_xor_b32", T1, BSEL, 1024)]))
-            sc.stream(ch, 0, b - 2, spread=True)
+            sc.stream(ch, 0, gy - 2, spread=True)
         if kind == "mid" and j == 3:
-            sc.stream(self.bias_frags(None, T=P[0:16]), 0, b - 1, spread=True)   # (P[0:16]: unit 0 left them in mid block 0)
+            sc.stream(self.bias_frags(None, T=P[0:16]), gx + 1, gy - 1, spread=True)   # (P[0:16]: unit 0 left them in mid block 0)
         if kind == "mid" and j == "loop":
             sc.stream([Item(Ins("s_sub_u32", KLEFT, KLEFT, 1))], 20, 30, spread=False)
         if kind == "mid" and isinstance(j, int) and j <= self.n_units_mid:
-            # the stores of a unit are issued EARLY in a block -- a whole block's worth of MFMAs lies between them and the next wait on the
-            # LDS-DMA stream, which (one counter for loads and stores) waits for them as well -- : the last unit of block j - 1 is stored
-            # at the start of block j
+            # (the stores of a block's last unit are issued at the start of the next block: see epi_store)
             U = self.units_per_mid
             ep = []
             if j > 0:
@@ -494,25 +499,23 @@ class Gen:
                     if u != (j + 1) * U - 1:
                         ep += self.epi_store(u)
             if self.abl != 3:
-                sc.stream(ep, 1, b - 1, spread=(self.epi == 1))
+                sc.stream(ep, 1, gy - 1, spread=(self.epi == 1))
         if drain and self.abl != 3:
             sc.stream(drain, 0, n - 1, spread=False)
         self.over[(kind, j)] = sc.over
         seq = sc.emit()
         if self.abl == 2:
             seq = [i for i in seq if i.kind != "mfma"]
-        if self.abl == 5:
-            seq = [i for i in seq if not (i.kind == "ds" and i.op == "ds_read_b128" and i.tag in ("f0", "f1"))]
-        seq, vm, lg = resolve_waits(seq, vm_in, lg_in)
-        # canonical exit state: the loads outstanding are the first pieces of the next group
-        vm = [t for t, ld in vm if ld]
-        if self.abl in (1, 5, 6):
-            vm = [t for t in vm if t not in ("g", "h")] + ["h"] * n3
-        if self.abl == 5:
-            lg = [t for t in lg if t not in ("f0", "f1")] + ["f0"] * 8
-        assert [t for t in vm if t == "h"] == vm[len(vm) - n3:] and len([t for t in vm if t == "h"]) == n3 and "g" not in vm, (kind, j, vm)
-        vm = ["g" if t == "h" else t for t in vm]
-        return seq, vm, lg
+        if self.abl == 4:
+            seq = [i for i in seq if i.kind != "barrier"]
+        seq, vm, lg = resolve_waits(seq, [(t, True) for t in vm_in], lg_in)
+        # exit state, relative to the next block
+        loads = [t for t, ld in vm if ld]
+        if self.abl == 1:
+            loads = [t for t in loads if t not in ("A", "B", "A2", "B2", "A4", "B4")] + ([] if next_quad else ["B2"] * 8) + ["A4"] * 8 + ["B4"] * n3
+        assert "A" not in loads and "B" not in loads and loads.count("A4") == 8 and loads.count("B4") == n3, (kind, j, loads)
+        ren = {"A2": "A", "B2": "B", "A4": "A2", "B4": "B2"}
+        return seq, [ren.get(t, t) for t in loads], lg
 
     # drain schedule over the seam: global gap coordinates (L: 0..63, F: 64 + F gap)
     def drain_plan(self):
@@ -550,7 +553,7 @@ class Gen:
               Ins("s_add_u32", TP[0], KARG[0], T0), Ins("s_addc_u32", TP[1], KARG[1], 0)]
         for reg, key in ((CBASE, "cbase"), (CLEN, "clen"), (RBASE, "rbase"), (PB, "pb"), (MGPB, "mg_pb")):
             s.append(Ins("s_load_dword", reg, TP, offset=4 * KA[key]))
-        s.append(Ins("s_waitcnt", kind="wait", lgkmcnt=0))
+        s += [Ins("s_waitcnt", kind="wait", lgkmcnt=0), Ins("s_lshl_b32", a_NK2, a_NK, 1)]
         # descriptors.  A / W / C: structured (stride = row bytes, records = rows: a row index past the end reads zeros / drops the store)
         FLAGS = 0x00020000
         for d, ptr, ld, rec in ((DA, A_PTR, a_LDA, a_M), (DW, W_PTR, a_LDW, a_N), (DC, C_PTR, a_LDC, None)):
@@ -564,17 +567,20 @@ class Gen:
         lane, l31, hi, r, c7, fx, base = (T[i] for i in range(7))
         s += self.lane_id(lane)
         s += [Ins("v_and_b32", l31, 31, lane), Ins("v_lshrrev_b32", hi, 5, lane), Ins("v_lshrrev_b32", r, 3, lane), Ins("v_and_b32", c7, 7, lane)]
-        s += [Ins("v_lshrrev_b32", fx, 1, l31), Ins("v_and_b32", fx, 7, fx)]
-        s += [Ins("v_lshrrev_b32", T[7], 3, l31), Ins("v_lshlrev_b32", T[7], 10, T[7]), Ins("v_and_b32", T[8], 7, l31), Ins("v_lshlrev_b32", T[8], 7, T[8]),
-              Ins("v_add_u32", base, T[7], T[8])]
-        # fragment read bases: + wm * 16 KiB (A image), 32 KiB + wn * 16 KiB (W image)
-        s += [Ins("s_lshr_b32", T0, WAVE, 1), Ins("s_lshl_b32", T0, T0, 14), Ins("s_and_b32", T1, WAVE, 1), Ins("s_lshl_b32", T1, T1, 14),
-              Ins("s_add_u32", T1, T1, 32768)]
-        for ks in range(4):
+        # fragment reads.  LDS image of a stage: [256 rows][64 B], the row's 16-byte chunk c at position c ^ ((row >> 2) & 3) (the XOR is
+        # applied to the SOURCE address of the LDS-DMA; every 16-lane group of a ds_read_b128 then covers all 64 banks once).
+        # A block (row base a multiple of 32), k-substep ks' of the stage: byte = (base + l31) * 64 + (((2 ks' + hi) ^ ((l31 >> 2) & 3)) << 4)
+        s += [Ins("v_lshrrev_b32", fx, 2, l31), Ins("v_and_b32", fx, 3, fx), Ins("v_lshlrev_b32", base, 6, l31)]
+        # + wm * 8 KiB (A image of the slot), 16 KiB + wn * 8 KiB (W image)
+        s += [Ins("s_lshr_b32", T0, WAVE, 1), Ins("s_lshl_b32", T0, T0, 13), Ins("s_and_b32", T1, WAVE, 1), Ins("s_lshl_b32", T1, T1, 13),
+              Ins("s_add_u32", T1, T1, 16384)]
+        for ks in range(2):
             s += [Ins("v_or_b32", T[9], 2 * ks, hi), Ins("v_xor_b32", T[9], T[9], fx), Ins("v_lshlrev_b32", T[9], 4, T[9]), Ins("v_add_u32", T[9], T[9], base),
                   Ins("v_add_u32", RA[ks], T0, T[9]), Ins("v_add_u32", RW[ks], T1, T[9])]
-        s += [Ins("s_lshl_b32", T0, WAVE, 6), Ins("v_add_u32", VRW, T0, r)]
-        s += [Ins("v_lshrrev_b32", T[9], 1, r), Ins("v_xor_b32", T[9], T[9], c7), Ins("v_lshlrev_b32", PE[1], 4, T[9]), Ins("v_xor_b32", PO[1], 64, PE[1])]
+        # LDS-DMA source of a piece (16 rows x 64 B): lane -> row (lane >> 2) of the piece, chunk (lane & 3) ^ ((row >> 2) & 3)
+        s += [Ins("v_lshrrev_b32", T[9], 2, lane), Ins("s_lshl_b32", T0, WAVE, 6), Ins("v_add_u32", VRW, T0, T[9])]
+        s += [Ins("v_lshrrev_b32", T[9], 4, lane), Ins("v_and_b32", T[9], 3, T[9]), Ins("v_and_b32", T[10], 3, lane), Ins("v_xor_b32", T[9], T[9], T[10]),
+              Ins("v_lshlrev_b32", PE[1], 4, T[9]), Ins("v_mov_b32", PO[1], PE[1])]
         # staging: write base (row l31, 16-byte slot XOR-swizzled by the row, 8-byte half hi), read base (row lane >> 3, slot lane & 7)
         s += [Ins("s_lshl_b32", T0, WAVE, 12), Ins("s_add_u32", T0, T0, LDS_STAGE)]
         s += [Ins("v_lshlrev_b32", T[9], 7, l31), Ins("v_and_b32", T[10], 7, l31), Ins("v_lshlrev_b32", T[10], 4, T[10]), Ins("v_add_u32", T[9], T[9], T[10]),
@@ -599,15 +605,17 @@ class Gen:
               Ins("s_cmp_ge_u32", TI, CLEN), Ins("s_cbranch_scc1", self.L("done"))]
         for it in self.tile_params(TI, CM0, CN0, NROT):
             s += it.ins
-        s += [Ins("v_add_u32", IDXA, CM0, VRW), Ins("v_add_u32", IDXW, CN0, VRW), Ins("s_mov_b32", KTD, NROT), Ins("s_lshl_b32", KOFF, NROT, 7),
-              Ins("s_lshl_b32", DMABW, WAVE, 13), Ins("s_mov_b32", BSEL, 0), Ins("s_mov_b32", MORE, 1)]
+        s += [Ins("v_add_u32", IDXA, CM0, VRW), Ins("v_add_u32", IDXW, CN0, VRW), Ins("s_lshl_b32", KTD, NROT, 1), Ins("s_lshl_b32", KOFF, NROT, 7),
+              Ins("s_lshl_b32", DMABW, WAVE, 12), Ins("s_mov_b32", BSEL, 0), Ins("s_mov_b32", MORE, 1)]
         s += self.bias_dma(CN0, [Ins("s_mov_b32", T1, 0)]).ins
-        for p in range(16):
-            s += self.dma_piece(p, "g0").ins
-        s += self.group_end().ins
-        for p in range(self.n3_seam):
-            s += self.dma_piece(p, "g").ins
-        s += [wait_vm("g0"), Ins("s_barrier")]
+        abl, self.abl = self.abl, 0   # (the pipeline is always filled with real loads)
+        for tag, cnt in (("A", 8), ("B", 8), ("A2", 8), ("B2", self.n3_seam)):   # the first four stages of the stream
+            for p in range(cnt):
+                s += self.dma_piece(p, tag).ins
+            if cnt == 8:
+                s += self.group_end().ins
+        self.abl = abl
+        s += [wait_vm(("A", "B")), Ins("s_barrier")]
         for it in self.bias_frags(0):
             s += it.ins
         for it in self.read_items(self.substeps("quad")[0][0], FSET[0], "f0"):
@@ -615,9 +623,9 @@ class Gen:
         # the first tile has no predecessor: F's lazy epilogue finds a descriptor with 0 records (set above)
         s += [Ins("s_mov_b32", NM0, CM0), Ins("s_mov_b32", NN0, CN0), Ins("s_mov_b32", TIN, TI), Ins("s_branch", self.L("F_body"))]
         seq, vm, lg = resolve_waits(s)
-        vm = [t for t in vm if t[0] == "g"] if self.abl not in (1, 5, 6) else ["g"] * self.n3_seam
-        assert len(vm) == self.n3_seam and [t for t in lg if t] == ["f0"] * 8, (vm, lg)
-        return seq, ["g"] * self.n3_seam, ["f0"] * 8
+        loads = [t for t, ld in vm if ld]
+        assert loads == ["A2"] * 8 + ["B2"] * self.n3_seam and [t for t in lg if t] == ["f0"] * 8, (loads, lg)
+        return seq, loads, ["f0"] * 8
 
     def build(self):
         self.drain_l, self.drain_f = self.drain_plan()
@@ -628,23 +636,29 @@ class Gen:
         out.append(label(self.L("F_rot")))
         out += self.tile_rotate()
         out.append(label(self.L("F_body")))
-        seq, vm, lg = self.block("F", None, vm_p, lg_p, "ks", drain=self.drain_f)
+        seq, vm, lg = self.block("F", None, vm_p, lg_p, False, drain=self.drain_f)
         out += seq
         for j in range(self.J):
-            seq, vm, lg = self.block("mid", j, vm, lg, "ks")
+            seq, vm, lg = self.block("mid", j, vm, lg, False)
             out += seq
         vm_loop_in, lg_loop_in = list(vm), list(lg)
         out += [label(self.L("loop")), Ins("s_cmp_eq_u32", KLEFT, 0), Ins("s_cbranch_scc1", self.L("pre"))]
-        seq, vm2, lg2 = self.block("mid", "loop", vm, lg, "ks")
+        seq, vm2, lg2 = self.block("mid", "loop", vm, lg, False)
         assert vm2 == vm_loop_in and lg2 == lg_loop_in, (vm2, lg2, vm_loop_in, lg_loop_in)
         out += seq
         out += [Ins("s_branch", self.L("loop")), label(self.L("pre"))]
-        seq, vm, lg = self.block("mid", "pre", vm, lg, "quad")
+        seq, vm, lg = self.block("mid", "pre", vm, lg, True)
         out += seq
-        seq, vm, lg = self.block("L", None, vm, lg, "quad", drain=self.drain_l)
+        seq, vm, lg = self.block("L", None, vm, lg, True, drain=self.drain_l)
         out += seq
         assert vm == vm_p and lg == lg_p, (vm, lg, vm_p, lg_p)
         out += [Ins("s_cmp_lg_u32", MORE, 0), Ins("s_cbranch_scc1", self.L("F_rot"))]
+        # wave 0 waits for its ticket (drawn in F, posted at mid block 0's barrier X) by an explicit count: the loads it has issued since
+        idx = [i for i, ins in enumerate(out) if ins.tag == "tk" and ins.uncounted]
+        iw = [i for i, ins in enumerate(out) if ins.tag == "tkwait"]
+        assert len(idx) == 1 and len(iw) == 1 and idx[0] < iw[0]
+        from .isa import is_load
+        out[iw[0]].mods["vmcnt"] = min(63, sum(1 for ins in out[idx[0] + 1:iw[0]] if is_load(ins) and not ins.uncounted))
         # ---- tail: the last tile's remaining drain and its whole epilogue, no MFMAs beside it
         tail = [Ins("s_waitcnt", kind="wait", vmcnt=0, lgkmcnt=0)] + self.tile_rotate() + [Ins("s_nop", 7), Ins("s_nop", 7)]
         for it in self.drain_f:

@@ -284,7 +284,11 @@ int unopose_fine_assign(const void *f1, const void *f2, int B, int R, int C, int
       lds_optin(opt2, (const void *)fine_assign_kernel<2>, 150 * 1024, "fine_assign") != UNOPOSE_OK)
     return UNOPOSE_ELAUNCH;
   const int nb = p.nblk[0] > p.nblk[1] ? p.nblk[0] : p.nblk[1];
+#ifdef UNOPOSE_PROBE_BUILD  // (the grid order before the XCD-aware one: A/B in probe builds only)
   static const int old_grid = getenv("UNOPOSE_FA_OLD_GRID") ? atoi(getenv("UNOPOSE_FA_OLD_GRID")) : 0;
+#else
+  const int old_grid = 0;
+#endif
   p.old_grid = old_grid;
   if (old_grid) {
     hipLaunchKernelGGL(fine_assign_kernel<0>, dim3(nb, B, 2), dim3(512), lds0, s, p);

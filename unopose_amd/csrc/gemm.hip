@@ -50,10 +50,14 @@ static inline int use_nt_store(long M, int N) { return (size_t)M * N * 2 > (32u 
 // already run faster than those of a full one.)
 namespace unopose {
 int gemm_small_tiles_limit() {
+#ifdef UNOPOSE_PROBE_BUILD  // (scripts/gemm_policy_ab.sh: probe builds only)
   static const int v = [] {
     const char *e = getenv("UNOPOSE_GEMM_SMALL_TILES");
     return e && *e ? atoi(e) : -1;
   }();
+#else
+  const int v = -1;
+#endif
   // default: below 5/8 of the CUs.  At 77 % fill (198 tiles: the 224 x 224 ViT's proj / fc2, M = 16 704) the 256-tile kernel is 8 - 17 %
   // faster than 786 small tiles, at 39 % (100 tiles) the small tiles win by 28 % (profiles/r04_gemm_policy_224.txt)
   return v >= 0 ? v : gemm_cu_count() * 5 / 8;
@@ -63,14 +67,21 @@ static int small_tiles_limit() { return unopose::gemm_small_tiles_limit(); }
 
 // Ticket slots of the dynamic tile scheduling: a ring of 1024 slots of 16 ints per device (zeroed once; every launch's last workgroup
 // re-zeroes its slot).  Consecutive launches take consecutive slots, so launches of different streams that run at the same time never
-// share one (a slot comes round again after 1024 launches: 20 forwards later).  `UNOPOSE_GEMM_DYN=0`: static tile lists (A/B).
+// share one (a slot comes round again after 1024 launches: 20 forwards later).
 namespace unopose {
-int *gemm_sched_slot() {
+int *gemm_sched_slot(hipStream_t stream) {
+#ifdef UNOPOSE_PROBE_BUILD  // `UNOPOSE_GEMM_DYN=0`: static tile lists (A/B, probe builds only)
   static const bool on = [] {
     const char *e = getenv("UNOPOSE_GEMM_DYN");
     return !(e && *e == '0');
   }();
   if (!on) return nullptr;
+#endif
+  // A launch being CAPTURED into a hipGraph gets static tile lists: a slot baked into a graph would be replayed while eager launches of
+  // other streams cycle through the same ring (tickets shared between two running launches: tiles skipped or computed twice), and the
+  // ring's first-use hipMalloc / hipMemset is not legal under capture.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
   static std::mutex mu;
   static int *ring[64] = {nullptr};
   static unsigned next_slot[64] = {0};
@@ -82,6 +93,7 @@ int *gemm_sched_slot() {
     if (hipMalloc(&p, 1024 * 16 * sizeof(int)) != hipSuccess || hipMemset(p, 0, 1024 * 16 * sizeof(int)) != hipSuccess) return nullptr;
     ring[dev] = p;
   }
+  // (1024 slots: a slot comes round again after 1024 launches -- about 17 forwards; fewer than that many launches may be in flight)
   return ring[dev] + (size_t)(next_slot[dev]++ & 1023u) * 16;
 }
 }  // namespace unopose
@@ -93,7 +105,7 @@ int gemm4w_linear(const void *A, int lda, const void *W, int ldw, const float *b
                   int *sched, hipStream_t s);
 }  // namespace unopose
 #ifndef GEMM_4W
-#define GEMM_4W 1
+#define GEMM_4W 0  // default: the 8-wave kernel (same-box A/Bs put the two within +-3 % of each other on the ViT shapes: profiles/r05_gemm4w_ablate.txt)
 #endif
 static int g_use_4w = GEMM_4W;
 
@@ -102,7 +114,7 @@ static int linear_bf16_dispatch(const void *A, int lda, const void *W, int ldw, 
   const int tiles_n = N / GEMM_BN;
   const int tiles = cdiv(M, GEMM_BM) * tiles_n;
   if (g_use_4w == 2 && gemm4w_ok(M, N, K, lda, ldw, ldc, epilogue)) {  // (forced: tests drive small tile counts through the stream as well)
-    if (int *const sched4 = gemm_sched_slot()) {
+    if (int *const sched4 = gemm_sched_slot(s)) {
       gemm4w_linear(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, use_nt_store(M, N), sched4, s);
       return check_launch(what);
     }
@@ -116,12 +128,12 @@ static int linear_bf16_dispatch(const void *A, int lda, const void *W, int ldw, 
                      tiles, nt, (const int *)nullptr, (const int *)nullptr, (const u16 *)nullptr, (const float *)nullptr,                     \
                      (const float *)nullptr, 0.f, lda, ldw, ldc, sched)
   if (g_use_4w && tiles >= n_cu && gemm4w_ok(M, N, K, lda, ldw, ldc, epilogue)) {
-    if (int *const sched4 = gemm_sched_slot()) {
+    if (int *const sched4 = gemm_sched_slot(s)) {
       gemm4w_linear(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, nt, sched4, s);
       return check_launch(what);
     }
   }
-  int *const sched = tiles > grid ? gemm_sched_slot() : nullptr;  // (one tile per workgroup: nothing to schedule)
+  int *const sched = tiles > grid ? gemm_sched_slot(s) : nullptr;  // (one tile per workgroup: nothing to schedule)
   if (epilogue == 1)
     UNOPOSE_LD_LAUNCH(1);
   else if (epilogue == 2)

@@ -84,7 +84,7 @@ int gemm_small_linear_f32(const void *As, const void *Ws, const float *bias, flo
 int gemm_small_tiles_limit();
 
 // A ticket slot for one launch of the persistent kernel with dynamic tile scheduling (gemm.hip), or nullptr (static tile lists).
-int *gemm_sched_slot();
+int *gemm_sched_slot(hipStream_t stream);
 
 // One persistent workgroup per CU of the CURRENT device (a multiple of 8: the tile walk is per XCD).
 inline int gemm_cu_count() {
@@ -95,8 +95,10 @@ inline int gemm_cu_count() {
     int cu = 0;
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8) cu = 256;
     n_cu[dev] = cu & ~7;
+#ifdef UNOPOSE_PROBE_BUILD
     const char *e = getenv("UNOPOSE_GEMM_CUS");  // probe: persistent grid capped below the CU count (leaves CUs to another stream)
     if (e && *e && atoi(e) >= 8) n_cu[dev] = min(n_cu[dev], atoi(e) & ~7);
+#endif
   }
   return n_cu[dev];
 }

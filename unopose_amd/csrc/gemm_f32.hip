@@ -59,7 +59,8 @@ int unopose_linear_f32x3(const void *As, const void *Ws, const float *bias, floa
   UNOPOSE_REQUIRE(As && Ws && bias && (C || Cs), "linear_f32x3: null pointer");
   UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && K >= GEMMF_BK && K % GEMMF_BK == 0,
                   "linear_f32x3: needs N %% 256 == 0 and K %% 32 == 0 (got M=%ld N=%d K=%d)", M, N, K);
-  UNOPOSE_REQUIRE((size_t)M * K * 4 < (1UL << 32) && (size_t)N * K * 4 < (1UL << 32), "linear_f32x3: operand larger than 4 GiB");
+  UNOPOSE_REQUIRE((size_t)M * K * 4 < (1UL << 32) && (size_t)N * K * 4 < (1UL << 32) && (size_t)M * N * 4 < (1UL << 32),
+                  "linear_f32x3: operand or output larger than 4 GiB (32-bit buffer offsets)");
   UNOPOSE_REQUIRE(epilogue >= 0 && epilogue <= 2, "linear_f32x3: epilogue must be 0 (bias), 1 (bias + GELU) or 2 (bias + ReLU)");
   const int tiles_m = cdiv(M, GEMM_BM), tiles_n = N / GEMM_BN, tiles = tiles_m * tiles_n;
   // too few 256 x 256 tiles for one per CU (the matcher's 197-token layers): 128 x 128 tiles, four times the workgroups (gemm_small.hip)
@@ -68,7 +69,7 @@ int unopose_linear_f32x3(const void *As, const void *Ws, const float *bias, floa
   const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
   const int nt = (size_t)M * N * 4 > (32u << 20) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
-  int *const sched = tiles > grid ? gemm_sched_slot() : nullptr;
+  int *const sched = tiles > grid ? gemm_sched_slot((hipStream_t)stream) : nullptr;
 #define UNOPOSE_LAUNCH_F32X3(E)                                                                                                            \
   hipLaunchKernelGGL((gemm256_kernel<E, false, true>), dim3(grid), dim3(512), 0, s, As, Ws, bias, (void *)C, (int)M, N, K, tiles_n, tiles, nt,  \
                      (const int *)nullptr, (const int *)nullptr, (const u16 *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f, 0, \
@@ -85,13 +86,14 @@ int unopose_linear_f32x3_bf16(const void *As, const void *Ws, const float *bias,
   UNOPOSE_REQUIRE(As && Ws && bias && Cb, "linear_f32x3_bf16: null pointer");
   UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && K >= GEMMF_BK && K % GEMMF_BK == 0,
                   "linear_f32x3_bf16: needs N %% 256 == 0 and K %% 32 == 0 (got M=%ld N=%d K=%d)", M, N, K);
-  UNOPOSE_REQUIRE((size_t)M * K * 4 < (1UL << 32) && (size_t)N * K * 4 < (1UL << 32), "linear_f32x3_bf16: operand larger than 4 GiB");
+  UNOPOSE_REQUIRE((size_t)M * K * 4 < (1UL << 32) && (size_t)N * K * 4 < (1UL << 32) && (size_t)M * N * 2 < (1UL << 32),
+                  "linear_f32x3_bf16: operand or output larger than 4 GiB (32-bit buffer offsets)");
   const int tiles_m = cdiv(M, GEMM_BM), tiles_n = N / GEMM_BN, tiles = tiles_m * tiles_n;
   const int n_cu = gemm_cu_count();
   const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
   hipLaunchKernelGGL((gemm256_kernel<4, false, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, As, Ws, bias, Cb, (int)M, N, K, tiles_n,
                      tiles, 0, (const int *)nullptr, (const int *)nullptr, (const u16 *)resid, (const float *)nullptr, (const float *)nullptr,
-                     0.f, 0, 0, 0, tiles > grid ? gemm_sched_slot() : nullptr, (void *)nullptr);
+                     0.f, 0, 0, 0, tiles > grid ? gemm_sched_slot((hipStream_t)stream) : nullptr, (void *)nullptr);
   return check_launch("linear_f32x3_bf16");
 }
 

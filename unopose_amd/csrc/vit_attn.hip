@@ -579,14 +579,19 @@ int unopose_vit_attention(const void *qkv, int B, int T, int H, void *out, unopo
   UNOPOSE_REQUIRE(qkv && out, "vit_attention: null pointer");
   UNOPOSE_REQUIRE(B >= 0 && T >= 1 && H >= 1 && (long)B * H * cdiv(T, 128) < (1L << 31), "vit_attention: bad sizes");
   if (B == 0) return UNOPOSE_OK;
+#ifdef UNOPOSE_PROBE_BUILD  // A/B routes exist in probe builds only (UNOPOSE_EXTRA_HIPCC_FLAGS=-DUNOPOSE_PROBE_BUILD; scripts/ubench/vit_attn_modes.py)
   static const int nw_env = getenv("UNOPOSE_VIT_NW") ? atoi(getenv("UNOPOSE_VIT_NW")) : 8;
   static const int qb4_env = getenv("UNOPOSE_VIT_QB4") ? atoi(getenv("UNOPOSE_VIT_QB4")) : 0;  // experiment: 1 wave / SIMD, 128 queries / wave
   if (T >= 1024 && qb4_env == 1) return launch_vit_attn<4, 2, 4>(qkv, B, T, H, out, (hipStream_t)stream);
   static const int dma_env = getenv("UNOPOSE_VIT_DMA") ? atoi(getenv("UNOPOSE_VIT_DMA")) : 1;  // 0: round 3's register-staged 8-wave kernel (A/B)
-  if (T >= 1024 && dma_env == 1 && (size_t)T * 3 * H * 64 * 2 < (1UL << 31)) return launch_vit_attn_dma(qkv, B, T, H, out, (hipStream_t)stream);
   static const int pipe_env = getenv("UNOPOSE_VIT_PIPE") ? atoi(getenv("UNOPOSE_VIT_PIPE")) : 0;
-  if (T >= 1024 && pipe_env == 1) return launch_vit_attn<2, 2, 8, true>(qkv, B, T, H, out, (hipStream_t)stream);
-  if (T >= 1024 && nw_env == 8) return launch_vit_attn<2, 2, 8>(qkv, B, T, H, out, (hipStream_t)stream);
+  if (T >= 1024 && dma_env != 1 && pipe_env == 1) return launch_vit_attn<2, 2, 8, true>(qkv, B, T, H, out, (hipStream_t)stream);
+  if (T >= 1024 && dma_env != 1 && nw_env != 8) return launch_vit_attn<2, 2, 4>(qkv, B, T, H, out, (hipStream_t)stream);
+  if (T >= 1024 && dma_env != 1) return launch_vit_attn<2, 2, 8>(qkv, B, T, H, out, (hipStream_t)stream);
+#endif
+  // T >= 1024: LDS-DMA staging, 4-wave workgroups, two per CU; a qkv image past 2 GiB per crop (32-bit DMA offsets): the register-staged kernel
+  if (T >= 1024 && (size_t)T * 3 * H * 64 * 2 < (1UL << 31)) return launch_vit_attn_dma(qkv, B, T, H, out, (hipStream_t)stream);
+  if (T >= 1024) return launch_vit_attn<2, 2, 8>(qkv, B, T, H, out, (hipStream_t)stream);
   if (T >= 512) return launch_vit_attn<2, 2, 4>(qkv, B, T, H, out, (hipStream_t)stream);
   return launch_vit_attn<1, 1, 4>(qkv, B, T, H, out, (hipStream_t)stream);
 }

@@ -4,7 +4,6 @@ C = oneref_predator_coarse_point_matching.py, Fi = oneref_predator_fine_point_ma
 F = oneref_feature_extraction.py, U = utils/model_utils.py.  `.eval()`: the fused inference path.  `.train()`: the
 reference's training branches (per-block overlap / saliency / correspondence losses, C:78-107, Fi:101-117) on
 autograd-recorded composites (ops.differentiable), the frozen backbone still on the fused kernels."""
-import os
 
 import torch
 import torch.nn as nn
@@ -17,12 +16,12 @@ from .modules import (GeometricStructureEmbedding, GeometricTransformer, Positio
                       SparseToDenseTransformer, ViTEncoderOneRef, _adjacent)
 
 
-STACKED_FINE = os.environ.get("UNOPOSE_STACKED_FINE", "1") == "1"  # A/B switch for the 2B-stacked fine matcher
+STACKED_FINE = True  # (module attributes: A/Bs set them from the script) the 2B-stacked fine matcher
 # Reference-cloud PE on a side stream under the coarse stage.  (Switched off for part of round 3 while the PE / frame kernels were not
 # reproducible beside the token attention of another stream; the cause -- packed-fp32 instructions, DESIGN.md section 7 -- is gone.)
-PE_UNDER_COARSE = os.environ.get("UNOPOSE_PE_UNDER_COARSE", "1") == "1"
-GEOM_UNDER_VIT = int(os.environ.get("UNOPOSE_GEOM_UNDER_VIT", "1"))  # 1: FPS-196 / gathers, 2: + frames + embedding
-LRF_UNDER_VIT = os.environ.get("UNOPOSE_LRF_UNDER_VIT", "1") == "1"  # the two global frames on the side stream as well
+PE_UNDER_COARSE = True
+GEOM_UNDER_VIT = 1  # 1: FPS-196 / gathers, 2: + frames + embedding
+LRF_UNDER_VIT = True  # the two global frames on the side stream as well
 
 
 def _scores(scores, n1):
@@ -402,10 +401,19 @@ class UNOPose(nn.Module):
     def forward_features(self, end_points):
         """First half of the eval forward: the ViT over both crops, the 5000 -> 2048 FPS and the pixel features (a9, a10, a21).
         `pipeline.PipelinedForward` runs the two halves of consecutive batches on different HIP streams."""
-        return self._features(end_points)
+        try:
+            return self._features(end_points)
+        finally:
+            ops.clear_split_memo()
 
     def forward_matching(self, end_points, feats):
         """Second half: coarse + fine matching on what `forward_features` returned."""
+        try:
+            return self._matching(end_points, feats)
+        finally:
+            ops.clear_split_memo()
+
+    def _matching(self, end_points, feats):
         dense_pm, dense_fm, dense_po, dense_fo, radius, pre = feats
         if pre is not None:
             return self._forward_from(pre, end_points, dense_pm, dense_fm, dense_po, dense_fo, radius)

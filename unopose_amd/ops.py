@@ -104,10 +104,10 @@ def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
 
 
 # =============================================================================
-# Dense-math operators.  Plain GEMMs go through torch (rocBLAS / hipBLASLt) as the
-# brief allows; everything with structure (attention, sampling, assignment, pose
-# hypotheses) is moved into hand-written HIP kernels one by one -- each function
-# below names its current implementation.
+# Dense-math operators.  Every GEMM of the eval path -- bf16 under autocast (csrc/gemm.hip, gemm_small.hip, gemm4w.hip), fp32-class
+# without (csrc/gemm_f32.hip, bmm_f32.hip) -- and everything with structure (attention, sampling, assignment, pose hypotheses) is a
+# hand-written HIP kernel behind the C ABI; the `*_torch` composites below are the training path's differentiable forms and the
+# fall-backs for shapes the kernels refuse (each warns once through note_fallback).
 # =============================================================================
 
 import torch.nn.functional as F
@@ -224,22 +224,39 @@ USE_F32X3 = True
 
 
 def f32x3_ok(rows, N, K):
-    return USE_F32X3 and N % 256 == 0 and K % 32 == 0 and rows >= 1 and rows * K * 4 < 2 ** 32 and N * K * 4 < 2 ** 32
+    # (operands AND the output: the kernel addresses all three through 32-bit buffer offsets)
+    return USE_F32X3 and N % 256 == 0 and K % 32 == 0 and rows >= 1 and rows * K * 4 < 2 ** 32 and N * K * 4 < 2 ** 32 and rows * N * 4 < 2 ** 32
 
 
 _SPLIT_MEMO = []  # [(key, source tensor, split tensor)], newest first
+_MUTATION_EPOCH = [0]  # bumped by every wrapper that writes a tensor through its raw pointer (in place, `out=`): see split_f32
 
 
-def split_f32(x2):
+def note_mutation():
+    """A kernel is about to write an existing tensor through `ptr()` (torch's version counter does not see that): results remembered
+    for tensors of an earlier epoch are dropped."""
+    _MUTATION_EPOCH[0] += 1
+    _SPLIT_MEMO.clear()
+
+
+def clear_split_memo():
+    """end of a forward: the remembered operands (and the source tensors they pin) are released"""
+    _SPLIT_MEMO.clear()
+
+
+def split_f32(x2, memo=False):
     """(M,K) fp32 -> the split layout of csrc/gemm_f32.hip (per row and 32-k block one 128-byte line [hi | lo] of bf16):
     returned as an (M, 2K) bf16 tensor (same bytes as the fp32 matrix).
-    The last two SMALL results are remembered (the matcher's layers project the same token tensor two or three times: q / kv, k / v --
-    49 of the 117 splits of a forward, scripts/split_census.py): same storage, shape, strides, version counter and stream; the entry
-    holds the source tensor, so its address cannot be handed to another tensor while the entry lives.  Inference only."""
+    `memo=True` (the token projections of the matcher: the same tensor is projected two or three times, q / kv, k / v -- 49 of the 117
+    splits of a forward, scripts/split_census.py): the last two SMALL results are remembered, keyed on storage, shape, strides, stream,
+    torch's version counter (absent on inference tensors) AND the mutation epoch -- every wrapper that writes a tensor through a raw
+    pointer calls note_mutation(), which empties the memo; the model empties it at the end of each forward half as well.  The entry holds
+    the source tensor, so its address cannot be handed to another tensor while the entry lives."""
     M, K = x2.shape
-    memo = not torch.is_grad_enabled() and M * K <= (8 << 20)
+    memo = memo and not torch.is_grad_enabled() and M * K <= (8 << 20)
     if memo:
-        key = (x2.data_ptr(), M, K, x2.stride(), x2._version, torch.cuda.current_stream(x2.device).cuda_stream)
+        ver = 0 if x2.is_inference() else x2._version
+        key = (x2.data_ptr(), M, K, x2.stride(), ver, _MUTATION_EPOCH[0], torch.cuda.current_stream(x2.device).cuda_stream)
         for e in _SPLIT_MEMO:
             if e[0] == key:
                 return e[2]
@@ -296,7 +313,7 @@ def linear_f32_raw(x, w, b, owner, tag):
         with torch.no_grad():
             c = (key, split_f32(w.detach().float().contiguous()), torch.zeros(N, device=w.device) if b is None else b.detach().float().contiguous())
         caches[tag] = c
-    return linear_f32x3(split_f32(_c(x.float()).reshape(rows, K)), c[1], c[2], rows, N, K).reshape(*x.shape[:-1], N)
+    return linear_f32x3(split_f32(_c(x.float()).reshape(rows, K), memo=True), c[1], c[2], rows, N, K).reshape(*x.shape[:-1], N)
 
 
 # ---- two-way InfoNCE loss of the matchers (loss_utils.py:181-187) on the streaming softmax statistics ---------------------------
@@ -542,7 +559,7 @@ def linear(x, lin, relu=False, gelu=False):
         rows = x.numel() // K
         if f32x3_ok(rows, N, K):
             c = _f32x3_weights(lin)
-            return linear_f32x3(split_f32(_c(x).reshape(rows, K)), c[1], c[2], rows, N, K, gelu, relu).reshape(*x.shape[:-1], N)
+            return linear_f32x3(split_f32(_c(x).reshape(rows, K), memo=True), c[1], c[2], rows, N, K, gelu, relu).reshape(*x.shape[:-1], N)
     if _DIFF and not gelu and torch.is_grad_enabled():
         return linear_train(x, lin, relu)
     if _DIFF or not (torch.is_autocast_enabled() and x.is_cuda):
@@ -862,6 +879,8 @@ def bilinear_sample_native(z, choose, H, W, out=None, tok_offset=0):
     in place."""
     z = _c(z)
     assert z.shape[-1] == 256 and z.shape[-2] == 4 and z.shape[-3] == 4 and z.dtype in (torch.float32, torch.bfloat16)
+    if out is not None:
+        note_mutation()
     B = z.shape[0]
     if z.dim() == 5:  # (B, tokens, 4, 4, 256)
         tok_stride = z.shape[1]
@@ -915,6 +934,8 @@ def sparse_pixel_features(acts, lin, plan, out=None):
     activations (prefix tokens in place), lin the up-projection -> (B2, Np, 256) fp32.  Same bf16 operands, fp32
     accumulation and bf16 rounding of the cell values as the dense path (`linear` + `bilinear_sample_native`)."""
     acts = _c(acts)
+    if out is not None:
+        note_mutation()
     B2, ts, K = acts.shape
     assert acts.dtype == torch.bfloat16 and ts == plan["tok_stride"] and B2 == plan["choose"].shape[0]
     cache = _bf16_weights(lin)
@@ -1589,6 +1610,8 @@ def add_layernorm(a, b, norm, out_dtype=None, out=None):
     if b is not None:
         b = _c(b)
         assert b.shape == a.shape
+    if out is not None:
+        note_mutation()
     if out is None:
         if out_dtype is None:
             out_dtype = torch.bfloat16 if torch.is_autocast_enabled() else a.dtype
@@ -1613,6 +1636,7 @@ def add_layernorm(a, b, norm, out_dtype=None, out=None):
 
 def scale_residual_(x, y, gamma):
     """x (fp32, contiguous) += gamma * y (bf16) in place (ViT LayerScale residual)."""
+    note_mutation()
     assert x.dtype == torch.float32 and x.is_contiguous() and y.dtype == torch.bfloat16
     y = _c(y)
     C = x.shape[-1]
@@ -1624,6 +1648,7 @@ def scale_residual_(x, y, gamma):
 def scale_residual_layernorm_f32_(x, y, gamma, norm):
     """fp32 twin for the no-autocast path: x (fp32, contiguous) += gamma * y (fp32) in place (y None: no update); returns
     LayerNorm(x) in the split layout of csrc/gemm_f32.hip as a (rows, 2C) bf16 tensor (norm None: residual update only, returns x)."""
+    note_mutation()
     assert x.dtype == torch.float32 and x.is_contiguous() and (y is None or y.dtype == torch.float32)
     C = x.shape[-1]
     rows = x.numel() // C
@@ -1644,6 +1669,7 @@ def vit_f32_fused_ok(x, vit):
 
 def scale_residual_layernorm_(x, y, gamma, norm):
     """x (fp32) += gamma * y (bf16) in place; returns LayerNorm(x) in bf16 -- one pass over the residual stream."""
+    note_mutation()
     assert x.dtype == torch.float32 and x.is_contiguous() and y.dtype == torch.bfloat16
     y = _c(y)
     C = x.shape[-1]
