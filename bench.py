@@ -232,8 +232,22 @@ def roofline_leg(model, batch, img):
         8000.0, "GB/s", t, "streams the geometric embedding once; 6 launches per step")
     t = hip_event_time(lambda: attn(False), 10, stream)
     rows.append(dict(kernel="token_attn_kernel<cross>(%d clouds x %d tokens)" % (B2, n), bound="latency", us=t * 1e6,
-                     tflops=B2 * 4.0 * n * n * 256 / t / 1e12, note="4 n^2 256 flop per cloud: 2.5 GFLOP per launch, 12 launches per step"))
+                     tflops=B2 * 4.0 * n * n * 256 / t / 1e12, launches_per_step=12, ms_per_step=12 * t * 1e3,
+                     note="the query<->reference cross-attention of the correspondence transformer: 4 n^2 256 flop per cloud = 2.5 GFLOP per launch, "
+                          "latency-sized (no MFMA fraction quoted: a 197-token problem cannot fill the matrix pipe); 12 launches per step"))
     del yq, ykv, vt, Eb, oa
+    # BASELINE configs[4]: 256 pose hypotheses per pair, weighted SVD / Procrustes over N correspondences each (model_utils.py:667-743; the
+    # batched one-sided Jacobi on 3 x 3 covariances of csrc/geom.hip).  Problems = B x 256 per launch.
+    for npts in (3, 196, 2048):
+        Mh = B * 256
+        src = torch.randn(Mh, npts, 3, device=x.device)
+        ref = torch.randn(Mh, npts, 3, device=x.device)
+        wgt = torch.rand(Mh, npts, device=x.device)
+        t = hip_event_time(lambda: ops.weighted_procrustes(src, ref, wgt), 10, stream)
+        rows.append(dict(kernel="weighted_procrustes(%d hypotheses x %d points)" % (Mh, npts), bound="latency" if npts < 512 else "hbm", us=t * 1e6,
+                         problems_per_s=Mh / t, us_per_problem=t * 1e6 / Mh, gbps=Mh * npts * 28.0 / t / 1e9,
+                         note="BASELINE configs[4] (256 hypotheses per pair, %d pairs): one 3x3 covariance + Jacobi SVD per hypothesis; 28 B per correspondence read once" % B))
+        del src, ref, wgt
     # group_points (the reference's `_ext` gather): HBM-write-bound
     idx = _ext.ball_query(x, x, 0.2, 256)
     xt = x.transpose(1, 2).contiguous()
@@ -292,6 +306,8 @@ def _cpu_model_name():
 
 
 def cpu_baseline_leg(img, batches=(1, 8), timed=2, all_cores=False):
+    # (bounded: B = 1 gets one warm-up + `timed` forwards; larger batches run ONE timed forward with no warm-up of their own -- the code paths
+    #  and the allocator are warm by then -- so that the leg is ~35 s of a default run instead of ~95 s)
     """The oracle (torch-CPU port of the reference forward + the C `_ext` port; kind "port": the reference's
     Python cannot travel) timed on this host's cores on a bounded sample of the same workload
     (SURVEY.md 8(d)): per batch size one warm-up forward, then `timed` timed forwards; value = the best
@@ -310,28 +326,28 @@ def cpu_baseline_leg(img, batches=(1, 8), timed=2, all_cores=False):
     cfg = R.default_cfg()
     sd = R.random_state_dict(cfg, seed=0, img_size=img, tame=0.1)
 
-    def run(b, n_threads, n_timed):
+    def run(b, n_threads, n_timed, warm=1):
         torch.set_num_threads(n_threads)
         ep, _, _ = make_batch(b, 2048, 5000, img, seed=1)
         rand = torch.rand(b, 18000, generator=torch.Generator().manual_seed(2))
         times = []
         with torch.no_grad():
-            for i in range(1 + n_timed):
+            for i in range(warm + n_timed):
                 t0 = time.perf_counter()
                 R.unopose_forward(ep, sd, cfg, rand, oext)
                 log("cpu_baseline B=%d threads=%d forward %d: %.2f s" % (b, n_threads, i, time.perf_counter() - t0))
-                if i:
+                if i >= warm:
                     times.append(time.perf_counter() - t0)
         times.sort()
         med = times[len(times) // 2]
-        return dict(pairs_per_s=b / med, median_s=med, min_s=times[0], max_s=times[-1], timed=n_timed, warmup=1)
+        return dict(pairs_per_s=b / med, median_s=med, min_s=times[0], max_s=times[-1], timed=n_timed, warmup=warm)
 
-    by_batch = {str(b): run(b, threads, timed) for b in batches}
+    by_batch = {str(b): (run(b, threads, timed) if b == min(batches) else run(b, threads, 1, warm=0)) for b in sorted(batches)}
     best = max(by_batch.values(), key=lambda r: r["pairs_per_s"])
     out = dict(value=best["pairs_per_s"], unit="pairs/s", cores=threads, host_cores=host, kind="port",
                cpu_model=_cpu_model_name(), by_batch=by_batch,
-               sample=f"batches of {list(batches)} pairs (2048 query / 5000 reference points, {img}x{img} crops), 1 warm-up + "
-                      f"{timed} timed forwards each, fp32, torch {threads} threads + C `_ext` port; value = best median")
+               sample=f"batches of {list(batches)} pairs (2048 query / 5000 reference points, {img}x{img} crops): B={min(batches)} 1 warm-up + "
+                      f"{timed} timed forwards, larger batches one timed forward; fp32, torch {threads} threads + C `_ext` port; value = best rate")
     if all_cores and host > threads:
         b = max(batches)
         r = run(b, host, 1)
@@ -640,7 +656,10 @@ def main():
             log("fp32 leg done")
             res["fp32"] = {"value": B * k / d32, "unit": "pairs/s", "ms_per_step": d32 / k * 1e3, "steps": k, "warmup": 3,
                            "step_ms_hip_events": {"median": q32(0.5), "p10": q32(0.1), "p90": q32(0.9)},
-                           "median_rot_err_vs_gt": e32.median().item()}
+                           "median_rot_err_vs_gt": e32.median().item(),
+                           "arithmetic": "bf16x3 hi/lo split on the matrix cores with fp32 accumulation (hi.hi + hi.lo + lo.hi: ~2^-17 relative per "
+                                         "product, not IEEE fp32's 2^-24) in every linear layer and attention contraction; geometry (FPS, ball query, "
+                                         "frames, Procrustes, assignment statistics) and the small contractions of bmm_f32 in exact fp32"}
         if not args.no_roofline:
             res.update(roofline_leg(model, batch, args.img))
             log("roofline leg done")

@@ -409,11 +409,11 @@ class UNOPose(nn.Module):
     def forward_matching(self, end_points, feats):
         """Second half: coarse + fine matching on what `forward_features` returned."""
         try:
-            return self._matching(end_points, feats)
+            return self._matching_half(end_points, feats)
         finally:
             ops.clear_split_memo()
 
-    def _matching(self, end_points, feats):
+    def _matching_half(self, end_points, feats):
         dense_pm, dense_fm, dense_po, dense_fo, radius, pre = feats
         if pre is not None:
             return self._forward_from(pre, end_points, dense_pm, dense_fm, dense_po, dense_fo, radius)
