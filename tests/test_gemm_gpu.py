@@ -265,7 +265,9 @@ def test_four_wave_kernel_vs_fp32_reference_and_8_wave(M, K, N, epi):
         L.unopose_gemm4w_enable(was)
     assert not torch.isnan(outs[2]).any()   # every element written (ragged last row panel included)
     err = (outs[2] - ref).abs()
-    tol = ref.abs() * 2.0 ** -8 + 2e-3
+    # GELU acts on the bf16-rounded pre-activation: a pre-activation within an accumulation-order difference of a rounding boundary lands one
+    # bf16 step away from the reference's, and its GELU with it (2^-8 relative = half a step for the rest)
+    tol = ref.abs() * 2.0 ** (-7 if epi == 1 else -8) + 2e-3
     assert (err <= tol).all(), (err.max().item(), int((err > tol).sum()))
     assert (outs[2] - outs[0]).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
 
