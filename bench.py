@@ -263,7 +263,7 @@ def roofline_leg(model, batch, img):
 
 
 def _pmc_summary():
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd + "_pmc_summary.json")
         if os.path.exists(path):
             return json.load(open(path)), "profiles/%s_pmc_summary.json" % rnd
