@@ -412,6 +412,22 @@ int unopose_gather_rows(const void *feats, int B, int N, int row_bytes, const vo
                         const void *alt, int prepend, void *out, unopose_stream_t stream);
 int unopose_transpose_pad_bf16(const void *v, long ld, int B, int m, int C, int pad, void *vt, unopose_stream_t stream);
 
+/* Small fp32 glue of the forward (round 5: the last torch reductions / elementwise kernels of the eval path).
+ * cloud_radius: radius[b] = max_i |p_i - mean(p)| of pts (B,N,3) (oneref_grf_predator_pose_estimation_model.py: the normalisation radius).
+ * scale_by_radius: out (B,n) = x / (radius[b] + eps) (multiply = 0) or x * (radius[b] + eps) (1).
+ * overlap_scores: clamp(sigmoid(.), 0, 1) of the score-head outputs (B, n_tot) of the two stacked clouds without their background tokens
+ *   (positions 0 and n1 + 1) -> out (B, n_tot - 2) fp32 (oneref_predator_coarse_point_matching.py:68-76, fine: :91-99).
+ * rigid_rows_bf16: bf16((p - t) @ R) with bf16-rounded operands and fp32 accumulation, p (B,N,3) fp32 (autocast's bmm of
+ *   oneref_predator_fine_point_matching.py:69).
+ * token_sum_bf16: out (B,C) fp32 = sum over the J tokens of x (B,J,C) bf16 (the k-sum of the focused linear attention, transformer.py:560-566).
+ * pose_score: sum_i [dis_i < thr] w_i / (sum_i w_i + 1e-8) * mean_i w_i, dis / w (B,N) (model_utils.py:559-566). */
+int unopose_cloud_radius(const float *pts, int B, int N, float *radius, unopose_stream_t stream);
+int unopose_scale_by_radius(const float *x, int B, int n, const float *radius, float eps, int multiply, float *out, unopose_stream_t stream);
+int unopose_overlap_scores(const void *scores, int x_bf16, int B, int n_tot, int n1, float *out, unopose_stream_t stream);
+int unopose_rigid_rows_bf16(const float *p, int B, int N, const float *t, const float *R, void *out, unopose_stream_t stream);
+int unopose_token_sum_bf16(const void *x, int B, int J, int C, float *out, unopose_stream_t stream);
+int unopose_pose_score(const float *dis, const float *w, int B, int N, float thr, float *out, unopose_stream_t stream);
+
 /* nn.Linear on bf16 data with a fused epilogue (timm ViT blocks: qkv / proj / fc1 + GELU / fc2, and the
  * up-projection of oneref_feature_extraction.py:221):
  *     C (M,N) bf16 = act( A (M,K) bf16 . W (N,K)^T bf16 + bias (N) fp32 ),  fp32 accumulation,

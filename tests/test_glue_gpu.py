@@ -232,3 +232,49 @@ def test_vit_attention_f32_split_output():
     qkv = torch.randn(3, 261, 2304, device="cuda")
     want = ops.split_f32(ops.vit_attention(qkv, 12).reshape(-1, 768))
     assert torch.equal(ops.vit_attention_f32_split(qkv, 12), want)
+
+
+@torch.no_grad()
+def test_small_fp32_glue_kernels_vs_torch():
+    """Round 5: the radius / scale / sigmoid / rigid transform / token sum / pose score kernels of csrc/glue.hip against the torch ops
+    they replace (the last reductions of the eval forward that ran as at::native kernels)."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    pts = (torch.randn(6, 5000, 3, generator=g) * 0.07 + torch.tensor([0.02, -0.03, 0.8])).cuda()
+    ref_r = torch.norm(pts.double() - pts.double().mean(1, keepdim=True), dim=2).max(1)[0]
+    r = ops.cloud_radius(pts)
+    assert (r.double() - ref_r).abs().max().item() < 2e-7 * ref_r.max().item()
+    assert torch.equal(ops.scale_by_radius(pts, r), pts / (r.reshape(-1, 1, 1) + 1e-6))     # IEEE division: bit-identical
+    t = torch.randn(6, 3, generator=g).cuda()
+    assert torch.equal(ops.scale_by_radius(t, r, multiply=True), t * (r.reshape(-1, 1) + 1e-6))
+    # overlap scores: both dtypes, background tokens dropped
+    n1, n2 = 196, 150
+    sc = (3 * torch.randn(4, n1 + n2 + 2, 1, generator=g)).cuda()
+    want = torch.clamp(torch.sigmoid(torch.cat((sc[:, 1:n1 + 1], sc[:, n1 + 2:]), 1).squeeze(-1)), 0, 1)
+    assert (ops.overlap_scores(sc, n1) - want).abs().max().item() < 2e-7
+    scb = sc.bfloat16()
+    wantb = torch.clamp(torch.sigmoid(torch.cat((scb[:, 1:n1 + 1], scb[:, n1 + 2:]), 1).squeeze(-1).float()), 0, 1)
+    assert (ops.overlap_scores(scb, n1) - wantb).abs().max().item() < 2e-7
+    # (p - t) @ R under autocast: bf16-rounded operands, fp32 accumulation, bf16 result
+    p = torch.randn(3, 777, 3, generator=g).cuda()
+    tt = torch.randn(3, 3, generator=g).cuda()
+    R = torch.linalg.qr(torch.randn(3, 3, 3, generator=g))[0].cuda()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = ops.rigid_rows(p, tt, R)
+    bf = torch.bfloat16
+    xb, Rb = (p - tt.unsqueeze(1)).to(bf).float(), R.to(bf).float()
+    ref = (xb[..., 0:1] * Rb[:, None, 0, :] + xb[..., 1:2] * Rb[:, None, 1, :] + xb[..., 2:3] * Rb[:, None, 2, :]).to(bf)
+    assert y.dtype == bf and torch.equal(y, ref)
+    # pose score
+    dis, w = torch.rand(5, 2048, generator=g).cuda() * 0.3, torch.rand(5, 2048, generator=g).cuda()
+    want = ((dis < 0.15).float() * w).double().sum(1) / (w.double().sum(1) + 1e-8) * w.double().mean(1)
+    assert (ops.pose_score(dis, w, 0.15).double() - want).abs().max().item() < 1e-6
+    # token sum (through the C ABI: ops uses it inside the linear attention)
+    import ctypes
+
+    from unopose_amd._lib import call, ptr, stream_ptr
+    x = torch.randn(3, 2049, 256, generator=g).bfloat16().cuda()
+    out = torch.empty(3, 256, device="cuda")
+    call("unopose_token_sum_bf16", ptr(x), 3, 2049, 256, ptr(out), stream_ptr())
+    assert (out.double() - x.double().sum(1)).abs().max().item() < 2e-3

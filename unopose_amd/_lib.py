@@ -76,6 +76,12 @@ SIGNATURES = {
     "unopose_row_dot": [_P, _I, _P, _F, ctypes.c_long, _I, _P, _I, _P],
     "unopose_normalize_rows_bf16": [_P, _I, ctypes.c_long, _I, _F, _P, _P],
     "unopose_transpose_pad_bf16": [_P, ctypes.c_long, _I, _I, _I, _I, _P, _P],
+    "unopose_cloud_radius": [_P, _I, _I, _P, _P],
+    "unopose_scale_by_radius": [_P, _I, _I, _P, _F, _I, _P, _P],
+    "unopose_overlap_scores": [_P, _I, _I, _I, _I, _P, _P],
+    "unopose_rigid_rows_bf16": [_P, _I, _I, _P, _P, _P, _P],
+    "unopose_token_sum_bf16": [_P, _I, _I, _I, _P, _P],
+    "unopose_pose_score": [_P, _P, _I, _I, _F, _P, _P],
     "unopose_render_depth": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _P],
     "unopose_bmm_f32": [_P, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, _P, _I, _I, _I, _I, _I, _F, _P],
     "unopose_split_bf16x2": [_P, ctypes.c_long, _I, _P, _P],

@@ -181,6 +181,134 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t *__rest
 
 using namespace unopose;
 
+namespace unopose {
+
+// ---- Round 5: the last fp32 reductions / elementwise ops of the eval forward that ran as torch kernels (`sum`, `mean`, `norm`, `mul`,
+// `add`, `sigmoid`: the seven at::native kernels with packed fp32 instructions of tests/test_torch_glue_isa_gpu.py's reviewed list) --
+// tiny tensors, one launch each, deterministic reductions (fixed order, no atomics).
+
+__device__ __forceinline__ float block256_sum(float v, float *sh) {   // deterministic: wave sums, then the four partials in order
+  v = wave_sum_f32(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block256_max(float v, float *sh) {
+  v = wave_max_f32(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  return r;
+}
+
+// radius[b] = max_i | p_i - mean(p) |  (oneref_grf_predator_pose_estimation_model.py: `torch.norm(pts - pts.mean(1), dim=2).max(1)[0]`)
+__global__ __launch_bounds__(256) void cloud_radius_kernel(const float *__restrict__ pts, int N, float *__restrict__ radius) {
+  __shared__ float sh[4];
+  const float *P = pts + (size_t)blockIdx.x * N * 3;
+  // the mean in double precision, rounded once: the correctly rounded value is what any accurate fp32 summation order agrees with most often
+  // (the FPS that follows is run on pts / radius: its indices are compared bit for bit with the reference's)
+  __shared__ double shd[3][4];
+  double sx = 0., sy = 0., sz = 0.;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    sx += (double)P[3 * i];
+    sy += (double)P[3 * i + 1];
+    sz += (double)P[3 * i + 2];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    sx += __shfl_xor(sx, o);
+    sy += __shfl_xor(sy, o);
+    sz += __shfl_xor(sz, o);
+  }
+  if ((threadIdx.x & 63) == 0) shd[0][threadIdx.x >> 6] = sx, shd[1][threadIdx.x >> 6] = sy, shd[2][threadIdx.x >> 6] = sz;
+  __syncthreads();
+  const float mx = (float)(((shd[0][0] + shd[0][1]) + (shd[0][2] + shd[0][3])) / (double)N), my = (float)(((shd[1][0] + shd[1][1]) + (shd[1][2] + shd[1][3])) / (double)N),
+              mz = (float)(((shd[2][0] + shd[2][1]) + (shd[2][2] + shd[2][3])) / (double)N);
+  float r = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float dx = P[3 * i] - mx, dy = P[3 * i + 1] - my, dz = P[3 * i + 2] - mz;
+    r = fmaxf(r, sqrtf((dx * dx + dy * dy) + dz * dz));
+  }
+  r = block256_max(r, sh);
+  if (threadIdx.x == 0) radius[blockIdx.x] = r;
+}
+
+// out = x / (radius[b] + eps)  (mode 0)  or  x * (radius[b] + eps)  (mode 1), x (B, n) fp32
+__global__ __launch_bounds__(256) void scale_by_radius_kernel(const float *__restrict__ x, int n, const float *__restrict__ radius, float eps, int mode,
+                                                              float *__restrict__ out) {
+  const float s = radius[blockIdx.y] + eps;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const size_t at = (size_t)blockIdx.y * n + i;
+  out[at] = mode ? x[at] * s : x[at] / s;
+}
+
+// overlap scores: out[b][j] = clamp(sigmoid(scores[b][1 + j]), 0, 1) for j < n1, scores[b][n1 + 2 + (j - n1)] for the second cloud
+// (oneref_predator_coarse_point_matching.py:68-76: the background tokens at 0 and n1 + 1 are dropped)
+template <bool X_BF16>
+__global__ __launch_bounds__(256) void overlap_scores_kernel(const void *__restrict__ scores, int n_tot, int n1, float *__restrict__ out) {
+  const int n_out = n_tot - 2, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_out) return;
+  const size_t src = (size_t)blockIdx.y * n_tot + (j < n1 ? 1 + j : 2 + j);
+  const float x = X_BF16 ? __uint_as_float((uint32_t) reinterpret_cast<const u16 *>(scores)[src] << 16) : reinterpret_cast<const float *>(scores)[src];
+  const float y = 1.f / (1.f + expf(-x));
+  out[(size_t)blockIdx.y * n_out + j] = fminf(fmaxf(y, 0.f), 1.f);
+}
+
+// y = bf16( (p - t) @ R ) with the operands rounded to bf16 and fp32 accumulation -- what autocast's bf16 bmm computes (Fi:69); p (B,N,3) fp32
+__global__ __launch_bounds__(256) void rigid_rows_bf16_kernel(const float *__restrict__ p, int N, const float *__restrict__ t, const float *__restrict__ R,
+                                                              u16 *__restrict__ out) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  auto f2bf_rn = [](float v) { return (u16)(cvt_pk_bf16_f32(v, 0.f) & 0xffffu); };
+  auto rb = [&](float v) { return __uint_as_float((uint32_t)f2bf_rn(v) << 16); };
+  const float *pp = p + ((size_t)b * N + i) * 3, *tt = t + b * 3, *Rb = R + b * 9;
+  const float x0 = rb(pp[0] - tt[0]), x1 = rb(pp[1] - tt[1]), x2 = rb(pp[2] - tt[2]);
+  u16 *o = out + ((size_t)b * N + i) * 3;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) o[j] = f2bf_rn((x0 * rb(Rb[j]) + x1 * rb(Rb[3 + j])) + x2 * rb(Rb[6 + j]));
+}
+
+// out[b][c] = sum_j x[b][j][c], x (B, J, C) bf16, fp32 sums in token order (the focused linear attention's k-sum, transformer.py:560-566)
+__global__ __launch_bounds__(256) void token_sum_bf16_kernel(const u16 *__restrict__ x, int J, int C, float *__restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const u16 *X = x + (size_t)blockIdx.y * J * C + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int j = 0;
+  for (; j + 3 < J; j += 4) {   // four independent chains: the loads of a column are C elements apart, latency-bound otherwise
+    a0 += __uint_as_float((uint32_t)X[(size_t)j * C] << 16);
+    a1 += __uint_as_float((uint32_t)X[(size_t)(j + 1) * C] << 16);
+    a2 += __uint_as_float((uint32_t)X[(size_t)(j + 2) * C] << 16);
+    a3 += __uint_as_float((uint32_t)X[(size_t)(j + 3) * C] << 16);
+  }
+  for (; j < J; ++j) a0 += __uint_as_float((uint32_t)X[(size_t)j * C] << 16);
+  out[(size_t)blockIdx.y * C + c] = (a0 + a1) + (a2 + a3);
+}
+
+// pose score of compute_fine_Rt_overlap / compute_coarse_Rt_overlap's tail (model_utils.py:559-566):
+//   ps = sum_i [dis_i < thr] w_i / (sum_i w_i + 1e-8) * mean_i w_i
+__global__ __launch_bounds__(256) void pose_score_kernel(const float *__restrict__ dis, const float *__restrict__ w, int N, float thr, float *__restrict__ out) {
+  __shared__ float sh[4];
+  const float *D = dis + (size_t)blockIdx.x * N, *W = w + (size_t)blockIdx.x * N;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float wi = W[i];
+    s1 += D[i] < thr ? wi : 0.f;
+    s2 += wi;
+  }
+  s1 = block256_sum(s1, sh);
+  s2 = block256_sum(s2, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = s1 / (s2 + 1e-8f) * (s2 / (float)N);
+}
+
+}  // namespace unopose
+
+using namespace unopose;
+
 extern "C" {
 
 int unopose_gather_rows(const void *feats, int B, int N, int row_bytes, const void *idx, int idx_is_i64, int J, int off, const void *alt,
@@ -244,6 +372,56 @@ int unopose_transpose_pad_bf16(const void *v, long ld, int B, int m, int C, int 
   hipLaunchKernelGGL(transpose_pad_kernel, dim3(C / 64, B), dim3(256), (size_t)64 * (pad + 2) * 2, (hipStream_t)stream, (const u16 *)v, ld, m, C,
                      pad, (u16 *)vt);
   return check_launch("transpose_pad_bf16");
+}
+
+int unopose_cloud_radius(const float *pts, int B, int N, float *radius, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(pts && radius, "cloud_radius: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && N >= 1, "cloud_radius: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  hipLaunchKernelGGL(cloud_radius_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pts, N, radius);
+  return check_launch("cloud_radius");
+}
+
+int unopose_scale_by_radius(const float *x, int B, int n, const float *radius, float eps, int multiply, float *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(x && radius && out, "scale_by_radius: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && n >= 1 && B <= 65535, "scale_by_radius: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  hipLaunchKernelGGL(scale_by_radius_kernel, dim3(cdiv(n, 256), B), dim3(256), 0, (hipStream_t)stream, x, n, radius, eps, multiply, out);
+  return check_launch("scale_by_radius");
+}
+
+int unopose_overlap_scores(const void *scores, int x_bf16, int B, int n_tot, int n1, float *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(scores && out, "overlap_scores: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && B <= 65535 && n1 >= 1 && n_tot >= n1 + 3, "overlap_scores: needs two clouds behind their background tokens (n_tot=%d n1=%d)", n_tot, n1);
+  if (B == 0) return UNOPOSE_OK;
+  const dim3 grid(cdiv(n_tot - 2, 256), B);
+  if (x_bf16) hipLaunchKernelGGL(overlap_scores_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, scores, n_tot, n1, out);
+  else hipLaunchKernelGGL(overlap_scores_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, scores, n_tot, n1, out);
+  return check_launch("overlap_scores");
+}
+
+int unopose_rigid_rows_bf16(const float *p, int B, int N, const float *t, const float *R, void *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(p && t && R && out, "rigid_rows_bf16: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && B <= 65535 && N >= 1, "rigid_rows_bf16: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  hipLaunchKernelGGL(rigid_rows_bf16_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, p, N, t, R, (u16 *)out);
+  return check_launch("rigid_rows_bf16");
+}
+
+int unopose_token_sum_bf16(const void *x, int B, int J, int C, float *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(x && out, "token_sum_bf16: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && B <= 65535 && J >= 1 && C >= 1, "token_sum_bf16: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  hipLaunchKernelGGL(token_sum_bf16_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, (hipStream_t)stream, (const u16 *)x, J, C, out);
+  return check_launch("token_sum_bf16");
+}
+
+int unopose_pose_score(const float *dis, const float *w, int B, int N, float thr, float *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(dis && w && out, "pose_score: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && N >= 1, "pose_score: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  hipLaunchKernelGGL(pose_score_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dis, w, N, thr, out);
+  return check_launch("pose_score");
 }
 
 }  // extern "C"

@@ -26,8 +26,7 @@ LRF_UNDER_VIT = True  # the two global frames on the side stream as well
 
 def _scores(scores, n1):
     """C:68-76 / Fi:91-99 -- only `score` is consumed at eval time."""
-    s1, s2 = scores[:, 1:(n1 + 1)], scores[:, (n1 + 2):]
-    return torch.clamp(torch.sigmoid(torch.cat((s1, s2), dim=1).squeeze(-1).float()), 0, 1)
+    return ops.overlap_scores(scores, n1)
 
 
 def _block_outputs(out_proj, score_head, f1, f2, n1, temp):
@@ -213,7 +212,7 @@ class FinePointMatchingOneRef(nn.Module):
     @staticmethod
     def _finish(end_points, R, t, s, radius):
         end_points["pred_R"] = R
-        end_points["pred_t"] = t * (radius.reshape(-1, 1) + 1e-6)
+        end_points["pred_t"] = ops.scale_by_radius(t, radius, multiply=True)
         end_points["pred_pose_score"] = s
         return end_points
 
@@ -246,18 +245,18 @@ class UNOPose(nn.Module):
         if "dense_po" in end_points and "dense_fo" in end_points:  # precomputed reference (F:252-263)
             dense_fm = net.pixel_features(rgb, choose)
             dense_po, dense_fo = end_points["dense_po"].clone(), end_points["dense_fo"].clone()
-            radius = torch.norm(dense_po - dense_po.mean(1, keepdim=True), dim=2).max(1)[0]
-            dense_pm = dense_pm / (radius.reshape(-1, 1, 1) + 1e-6)
-            dense_po = dense_po / (radius.reshape(-1, 1, 1) + 1e-6)
+            radius = ops.cloud_radius(dense_po)
+            dense_pm = ops.scale_by_radius(dense_pm, radius)
+            dense_po = ops.scale_by_radius(dense_po, radius)
             return dense_pm, dense_fm, dense_po, dense_fo, radius, None
         if "ref_dense_po" in end_points:  # encode_reference() output: same numbers as the full path below
             radius = end_points["ref_radius"]
-            dense_pm = dense_pm / (radius.reshape(-1, 1, 1) + 1e-6)
+            dense_pm = ops.scale_by_radius(dense_pm, radius)
             return dense_pm, net.pixel_features(rgb, choose), end_points["ref_dense_po"], end_points["ref_dense_fo"], radius, None
         tem_rgb, tem_choose, tem_pts = end_points["tem1_rgb"], end_points["tem1_choose"], end_points["tem1_pts"]
-        radius = torch.norm(tem_pts - tem_pts.mean(1, keepdim=True), dim=2).max(1)[0]
-        dense_pm = dense_pm / (radius.reshape(-1, 1, 1) + 1e-6)
-        tem_n = tem_pts / (radius.reshape(-1, 1, 1) + 1e-6)
+        radius = ops.cloud_radius(tem_pts)
+        dense_pm = ops.scale_by_radius(dense_pm, radius)
+        tem_n = ops.scale_by_radius(tem_pts, radius)
         # The serial geometry chain (FPS 5000->2048: 2047 dependent iterations on B CUs) only needs the
         # points, so it runs on a side HIP stream underneath the ViT GEMMs of the main stream.
         main = torch.cuda.current_stream()
@@ -326,8 +325,8 @@ class UNOPose(nn.Module):
         crop's ViT pass, the 5000->2048 FPS and the reference LRF; unlike the reference's own
         `dense_po`/`dense_fo` shortcut (F:252-263, which re-derives the radius from the subset) the
         results equal the uncached forward."""
-        radius = torch.norm(tem1_pts - tem1_pts.mean(1, keepdim=True), dim=2).max(1)[0]
-        tem_n = tem1_pts / (radius.reshape(-1, 1, 1) + 1e-6)
+        radius = ops.cloud_radius(tem1_pts)
+        tem_n = ops.scale_by_radius(tem1_pts, radius)
         idx_o = ops.furthest_point_sample(tem_n, self.fine_npoint)
         sel_choose = torch.gather(tem1_choose, 1, idx_o.long())
         net = self.feature_extraction.rgb_net

@@ -737,10 +737,67 @@ def _own_f32(x):
     return x.is_cuda and not _DIFF and USE_F32X3 and _no_autograd()
 
 
+def _own_glue(x):
+    """the small fp32 steps between the kernels on own kernels (csrc/glue.hip, round 5): eval on the GPU, nothing recorded by autograd"""
+    return x.is_cuda and not _DIFF and _no_autograd()
+
+
+def cloud_radius(pts):
+    """max_i |p_i - mean(p)| per cloud, pts (B,N,3) -> (B,) (the normalisation radius of the forward)"""
+    if not _own_glue(pts):
+        return torch.norm(pts - pts.mean(1, keepdim=True), dim=2).max(1)[0]
+    p = _c(pts.float())
+    out = torch.empty(p.shape[0], dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        call("unopose_cloud_radius", ptr(p), p.shape[0], p.shape[1], ptr(out), stream_ptr())
+    return out
+
+
+def scale_by_radius(x, radius, multiply=False, eps=1e-6):
+    """x / (radius[b] + eps) (or x * (...)) for x (B, ...) fp32"""
+    if not (_own_glue(x) and x.dtype == torch.float32):
+        s = (radius + eps).reshape(-1, *([1] * (x.dim() - 1)))
+        return x * s if multiply else x / s
+    xc = _c(x)
+    out = torch.empty_like(xc)
+    with torch.cuda.device(x.device):
+        call("unopose_scale_by_radius", ptr(xc), xc.shape[0], xc.numel() // xc.shape[0], ptr(_c(radius.float())), float(eps), int(multiply), ptr(out), stream_ptr())
+    return out
+
+
+def overlap_scores(scores, n1):
+    """clamp(sigmoid(.)) of the score heads' outputs (B, n_tot, 1) without the two background tokens -> (B, n_tot - 2) fp32"""
+    if not (_own_glue(scores) and scores.dtype in (torch.float32, torch.bfloat16)):
+        s1, s2 = scores[:, 1:(n1 + 1)], scores[:, (n1 + 2):]
+        return torch.clamp(torch.sigmoid(torch.cat((s1, s2), dim=1).squeeze(-1).float()), 0, 1)
+    sc = _c(scores)
+    B, n_tot = sc.shape[0], sc.shape[1]
+    out = torch.empty(B, n_tot - 2, dtype=torch.float32, device=sc.device)
+    with torch.cuda.device(sc.device):
+        call("unopose_overlap_scores", ptr(sc), int(sc.dtype == torch.bfloat16), B, n_tot, n1, ptr(out), stream_ptr())
+    return out
+
+
+def pose_score(dis, w, thr):
+    """sum [dis < thr] w / (sum w + 1e-8) * mean w per batch row (model_utils.py:559-566)"""
+    if not _own_glue(dis):
+        return ((dis < thr).float() * w).sum(1) / (w.sum(1) + 1e-8) * w.mean(1)
+    d, ww = _c(dis.float()), _c(w.float())
+    out = torch.empty(d.shape[0], dtype=torch.float32, device=d.device)
+    with torch.cuda.device(d.device):
+        call("unopose_pose_score", ptr(d), ptr(ww), d.shape[0], d.shape[1], float(thr), ptr(out), stream_ptr())
+    return out
+
+
 def rigid_rows(p, t, R):
     """(p - t) @ R for row-vector points p (B,N,3), t (B,3), R (B,3,3) (Fi:69).  Under autocast the reference's `@` is a
     bf16 bmm (operands rounded to bf16, fp32 accumulation, bf16 result); here the same arithmetic as three broadcast
     multiply-adds, so that no library bf16 GEMM kernel is on the path (`own_gemm_ok`)."""
+    if HIP_GEMM_ALL and torch.is_autocast_enabled() and _own_glue(p) and p.dtype == torch.float32 and p.dim() == 3:
+        pc, out = _c(p), torch.empty(p.shape, dtype=torch.bfloat16, device=p.device)
+        with torch.cuda.device(p.device):
+            call("unopose_rigid_rows_bf16", ptr(pc), pc.shape[0], pc.shape[1], ptr(_c(t.float())), ptr(_c(R.float())), ptr(out), stream_ptr())
+        return out
     x = p - t.unsqueeze(1)
     if _own_f32(p) and not torch.is_autocast_enabled() and x.dtype == torch.float32:
         return bmm_nt_f32(x, R.float().transpose(1, 2))  # (x @ R)[n, j] = sum_k x[n, k] R[k, j]
@@ -1272,7 +1329,11 @@ def _focused_linear_attention_hip(xq, xkv, att, focusing):
         call("unopose_linear_attention", ptr(kproj), ptr(inv_sp), None, None, B, j, focusing, 1, ptr(kf),
              stream_ptr())
         kf32 = kf.float()
-        ksum = _c(kf32.sum(dim=1))  # (B,256)
+        if _own_glue(kf):
+            ksum = torch.empty(B, C, dtype=torch.float32, device=kf.device)  # (B,256): sum over the tokens
+            call("unopose_token_sum_bf16", ptr(kf), B, j, C, ptr(ksum), stream_ptr())
+        else:
+            ksum = _c(kf32.sum(dim=1))
         # kv_h^T[d][c] = sum_j v[j,h,d] k[j,h,c]   (fp32 contraction: autocast would turn it into a library bf16 GEMM)
         with torch.autocast("cuda", enabled=False):
             if _own_f32(v):
@@ -1546,8 +1607,7 @@ def fine_pose(atten, score, pts1, pts2, dis_thres=0.15):
         R, t = weighted_procrustes(pred, pts1, weight, 0.001)
         dis = torch.empty(B, N1, dtype=torch.float32, device=dev)
         call("unopose_min_dist", ptr(pts1), ptr(pts2), B, N1, N2, ptr(R), ptr(t), 1, ptr(dis), stream_ptr())
-    ps = ((dis < dis_thres).float() * w1).sum(1) / (w1.sum(1) + 1e-8)
-    return R, t, ps * w1.mean(1)
+    return R, t, pose_score(dis, w1, dis_thres)
 
 
 USE_FUSED_FINE = True  # bf16 fine stage without the (B,N1+1,N2+1) similarity (csrc/fineassign.hip)
@@ -1595,8 +1655,7 @@ def fine_pose_from_features(f1, f2, temp, score, pts1, pts2, dis_thres=0.15):
         Rm, t = weighted_procrustes(pred, pts1, weight, 0.001)
         dis = torch.empty(B, N1, dtype=torch.float32, device=dev)
         call("unopose_min_dist", ptr(pts1), ptr(pts2), B, N1, N2, ptr(Rm), ptr(t), 1, ptr(dis), stream_ptr())
-    ps = ((dis < dis_thres).float() * w1).sum(1) / (w1.sum(1) + 1e-8)
-    return Rm, t, ps * w1.mean(1)
+    return Rm, t, pose_score(dis, w1, dis_thres)
 
 
 def add_layernorm(a, b, norm, out_dtype=None, out=None):
