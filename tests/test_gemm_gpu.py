@@ -267,8 +267,12 @@ def test_four_wave_kernel_vs_fp32_reference_and_8_wave(M, K, N, epi):
     err = (outs[2] - ref).abs()
     # GELU acts on the bf16-rounded pre-activation: a pre-activation within an accumulation-order difference of a rounding boundary lands one
     # bf16 step away from the reference's, and its GELU with it (2^-8 relative = half a step for the rest)
-    tol = ref.abs() * 2.0 ** (-7 if epi == 1 else -8) + 2e-3
+    # (a flipped pre-activation moves the result by one bf16 step of the PRE-activation -- up to two steps of the output, GELU'(x) > 1
+    #  around x = 2..4 -- on top of the output's own half step: 2^-6 for those, and they must be rare)
+    tight = ref.abs() * 2.0 ** -8 + 2e-3
+    tol = ref.abs() * 2.0 ** -6 + 2e-3 if epi == 1 else tight
     assert (err <= tol).all(), (err.max().item(), int((err > tol).sum()))
+    assert (err > tight).float().mean().item() < 5e-3
     assert (outs[2] - outs[0]).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
 
 
