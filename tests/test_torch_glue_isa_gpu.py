@@ -77,17 +77,8 @@ def test_kernels_of_a_pipelined_step_have_no_packed_fp32(tmp_path):
     cross = {n: [l for l in bad if re.search(r"\bop_sel:", l)] for n, bad in dirty.items()}
     cross = {n: b for n, b in cross.items() if b}
     assert not cross, ("packed fp32 with a low-half cross-select (the form that fails beside MFMAs)", cross)
-    # (2) every other kernel with packed fp32 is one of the REVIEWED ones below: plain / op_sel_hi-only / inline-constant forms, the
-    #     classes measured benign (0 of 40 launches each; profiles/r03_asm_var_classes.txt).  A kernel outside this list fails the test:
-    #     new torch glue on the eval path has to be looked at (or replaced by a kernel of libunopose_hip.so, which has no packed fp32).
-    reviewed = (
-        r"reduce_kernel<\d+, \d+, at::native::ReduceOp<float, at::native::func_wrapper_t<float, at::native::sum_functor<float, float, float>",  # .sum(): v_pk_add_f32
-        r"reduce_kernel<\d+, \d+, at::native::ReduceOp<float, at::native::MeanOps<float, float, float, float>",   # .mean(): v_pk_add_f32
-        r"reduce_kernel<\d+, \d+, at::native::ReduceOp<float, at::native::NormTwoOps<float, float, float>",       # torch.norm: v_pk_fma_f32 v, v, v
-        r"vectorized_elementwise_kernel<\d+, at::native::BinaryFunctor<float, float, float, at::native::binary_internal::MulFunctor<float> >",  # a * b: plain v_pk_mul_f32
-        r"vectorized_elementwise_kernel<\d+, at::native::CUDAFunctorOnSelf_add<float>",   # x + scalar: v_pk_add_f32 op_sel_hi
-        r"vectorized_elementwise_kernel<\d+, at::native::CUDAFunctor_add<float>",         # a + alpha b: v_pk_fma_f32 op_sel_hi
-        r"vectorized_elementwise_kernel<\d+, at::native::sigmoid_kernel_cuda",            # 1 + exp(-x): v_pk_add_f32 with an inline constant
-    )
-    unreviewed = [n for n in dirty if not any(re.search(p, n) for p in reviewed)]
-    assert not unreviewed, ("torch kernels with packed fp32 that nobody has looked at", {n: dirty[n][:4] for n in unreviewed})
+    # (2) round 5: the sum / mean / norm / mul / add / sigmoid sites of the forward run on kernels of libunopose_hip.so now (csrc/glue.hip:
+    #     radius, scale, overlap scores, rigid transform, token sum, pose score), so the list of reviewed torch kernels with packed fp32
+    #     (plain / op_sel_hi-only / inline-constant forms: seven patterns in round 4) is EMPTY: any torch kernel with packed fp32 in the
+    #     step fails the test until it has been replaced or looked at.
+    assert not dirty, ("torch kernels with packed fp32 on the eval path", {n: dirty[n][:4] for n in dirty})
