@@ -336,6 +336,92 @@ __global__ __launch_bounds__(256) void procrustes_wave_kernel(const float *__res
   }
 }
 
+// One WORKGROUP per problem, the correspondences in REGISTERS (round 5; N <= 256 PPT): a thread owns PPT points, src / ref / w are read
+// from memory ONCE (the one-wave-per-problem form above walks them three times: weights, centroids, covariance -- at 256 hypotheses x
+// 2048 correspondences per pair, BASELINE configs[4], it is bound by those re-reads: 204 us for 470 MB of operands), the three passes of the
+// reference's formulation (model_utils.py:667-743) run on the registers, reductions in a fixed order (DPP wave sums, then the four wave
+// partials in order: deterministic).  Also what the model's own two calls per forward want: 32 problems were 32 wavefronts on the chip.
+// WAVES = 4: the whole workgroup on one problem; WAVES = 1 (N <= 512): one wavefront per problem, four problems per workgroup, no barriers.
+template <int PPT, int WAVES>
+__global__ __launch_bounds__(256) void procrustes_block_kernel(const float *__restrict__ src, const float *__restrict__ ref, const float *__restrict__ w,
+                                                               int M, int N, float thresh, float eps, float *__restrict__ Rout, float *__restrict__ tout) {
+  __shared__ float part[4][9];
+  constexpr int TP = 64 * WAVES;   // threads per problem
+  const int m = blockIdx.x * (4 / WAVES) + threadIdx.x / TP, tid = threadIdx.x % TP, lane = tid & 63, wave = tid >> 6;
+  if (WAVES == 1 && m >= M) return;   // (whole wavefronts: no barrier is skipped)
+  const float *S = src + (size_t)m * N * 3, *Rf = ref + (size_t)m * N * 3;
+  const float *W = w ? w + (size_t)m * N : nullptr;
+  float wi[PPT], sp[PPT][3], rp[PPT][3];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int i = tid + k * TP;
+    const bool ok = i < N;
+    const int ii = ok ? i : 0;
+    const float x = W ? W[ii] : 1.f;
+    wi[k] = !ok || x < thresh ? 0.f : x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      sp[k][c] = S[ii * 3 + c];
+      rp[k][c] = Rf[ii * 3 + c];
+    }
+  }
+  auto block_sum = [&](float (&v)[9], int n) {   // v[0..n) summed over the workgroup, result in every thread
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+      if (c < n) v[c] = wave_sum_f32(v[c]);
+    if (WAVES == 1) return;
+    __syncthreads();   // (the previous round's partials have been read)
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c)
+        if (c < n) part[wave][c] = v[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+      if (c < n) v[c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+  };
+  float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) v[0] += wi[k];
+  block_sum(v, 1);
+  const float inv = 1.f / (v[0] + eps);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) v[c] = 0.f;
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    wi[k] *= inv;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      v[c] += sp[k][c] * wi[k];
+      v[3 + c] += rp[k][c] * wi[k];
+    }
+  }
+  block_sum(v, 6);
+  const float s0 = v[0], s1 = v[1], s2 = v[2], r0 = v[3], r1 = v[4], r2 = v[5];
+  float h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const float a0 = sp[k][0] - s0, a1 = sp[k][1] - s1, a2 = sp[k][2] - s2;
+    const float b0 = wi[k] * (rp[k][0] - r0), b1 = wi[k] * (rp[k][1] - r1), b2 = wi[k] * (rp[k][2] - r2);
+    h[0] += a0 * b0; h[1] += a0 * b1; h[2] += a0 * b2;
+    h[3] += a1 * b0; h[4] += a1 * b1; h[5] += a1 * b2;
+    h[6] += a2 * b0; h[7] += a2 * b1; h[8] += a2 * b2;
+  }
+  block_sum(h, 9);
+  if (tid == 0) {
+    float R[9];
+    kabsch_from_H(h, R);
+    float *Ro = Rout + (size_t)m * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Ro[i] = R[i];
+    float *to = tout + (size_t)m * 3;
+    to[0] = r0 - (R[0] * s0 + R[1] * s1 + R[2] * s2);
+    to[1] = r1 - (R[3] * s0 + R[4] * s1 + R[5] * s2);
+    to[2] = r2 - (R[6] * s0 + R[7] * s1 + R[8] * s2);
+  }
+}
+
 // One THREAD per problem for tiny N (the 3-point hypotheses of the coarse stage).
 template <int NP>
 __global__ __launch_bounds__(256) void procrustes_thread_kernel(const float *__restrict__ src,
@@ -447,6 +533,15 @@ int unopose_weighted_procrustes(const float *src, const float *ref, const float 
   if (N == 3) {
     hipLaunchKernelGGL(procrustes_thread_kernel<3>, dim3(cdiv(M, 256)), dim3(256), 0, s, src, ref, w, M, thresh, eps,
                        R, t);
+  } else if (N <= 2048) {
+#define UNOPOSE_PB(P, WV) hipLaunchKernelGGL((procrustes_block_kernel<P, WV>), dim3(cdiv(M, 4 / WV)), dim3(256), 0, s, src, ref, w, M, N, thresh, eps, R, t)
+    if (N <= 64) UNOPOSE_PB(1, 1);
+    else if (N <= 128) UNOPOSE_PB(2, 1);
+    else if (N <= 256) UNOPOSE_PB(4, 1);
+    else if (N <= 512) UNOPOSE_PB(8, 1);
+    else if (N <= 1024) UNOPOSE_PB(4, 4);
+    else UNOPOSE_PB(8, 4);
+#undef UNOPOSE_PB
   } else {
     hipLaunchKernelGGL(procrustes_wave_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, src, ref, w, M, N, thresh, eps, R,
                        t);
