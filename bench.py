@@ -199,7 +199,9 @@ def roofline_leg(model, batch, img):
     # PE, S=256, bf16 hi/lo-split matrix cores; 20864 flop per neighbour row
     t = hip_event_time(lambda: ops.pe_group_mlp_max(x, pe.r2, pe.ns2, pe.mlp2, bf16x3=True), 10, stream)
     r = row("pe_group_mlp_max_bf16x3_kernel(S=%d)" % pe.ns2, "mfma", B * N * pe.ns2 * 20864.0, 1e12, 2500.0,
-            "TFLOP/s", t, "algorithmic fp32-equivalent flops; the kernel issues 3 bf16 MFMAs per product")
+            "TFLOP/s", t, "algorithmic fp32-equivalent flops of the reference's S rows per centre; the kernel issues 3 bf16 MFMAs per product and "
+                          "skips the 32-row tiles that hold nothing but the ball query's padding copies of the first neighbour (identical rows cannot "
+                          "change the max-pool: bit-identical output; on these clouds 2.4 of 8 tiles at S = 256 carry real neighbours)")
     r["traffic"] = _pmc_traffic("pe_group_mlp_max_bf16x3_kernel", B)
     t = hip_event_time(lambda: ops.pe_group_mlp_max(x, pe.r2, pe.ns2, pe.mlp2, bf16x3=False), 5, stream)
     row("pe_group_mlp_max_kernel(S=%d, exact fp32 MFMA)" % pe.ns2, "mfma", B * N * pe.ns2 * 20864.0, 1e12, 157.3,

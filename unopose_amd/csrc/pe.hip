@@ -148,7 +148,11 @@ __global__ __launch_bounds__(256) void pe_group_mlp_max_kernel(
     if (j >= N) break;  // wave-uniform
     const float cx = sx[j], cy = sy[j], cz = sz[j];
     Vec3 xp, yp, zp;
-    pe_centre_frame(sx, sy, sz, N, S, radius, r2, lane, cx, cy, cz, nbr, xp, yp, zp);
+    const int cnt_nb = pe_centre_frame(sx, sy, sz, N, S, radius, r2, lane, cx, cy, cz, nbr, xp, yp, zp);
+    // Neighbour-list entries past the `cnt` points inside the radius are copies of the FIRST neighbour (ball_query_gpu.cu:14-49): their
+    // MLP rows equal row 0's and cannot change the maximum -- tiles that hold nothing but such copies are skipped (bit-identical result).
+    // The frame above is computed over all S entries, copies included, as the reference does.
+    const int S_eff = min(S, (min(cnt_nb, S) + 31) & ~31);
 
     // ---- MLP over tiles of 32 neighbours, running max over tiles
     f32x16 rmax[4];
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256) void pe_group_mlp_max_kernel(
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) rmax[t][r] = 0.f;  // post-ReLU values are >= 0
-    for (int t0 = 0; t0 < S; t0 += 32) {
+    for (int t0 = 0; t0 < S_eff; t0 += 32) {
       const int k = nbr[t0 + col];
       const float dx = sx[k] - cx, dy = sy[k] - cy, dz = sz[k] - cz;
       const Vec3 q = v3(dx / radius, dy / radius, dz / radius);
@@ -372,7 +376,10 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) rmax[t][r] = 0.f;  // post-ReLU values are >= 0
-    for (int t0 = 0; t0 < S; t0 += 32) {
+    // (tiles of nothing but copies of the first neighbour -- the padding of a list with fewer than S points inside the radius -- are
+    //  skipped: their rows equal row 0's, the maximum cannot change; round 5)
+    const int S_eff = min(S, (min(cnt, S) + 31) & ~31);
+    for (int t0 = 0; t0 < S_eff; t0 += 32) {
       // keep the weight fragments in LDS (re-read per tile) instead of letting the compiler hoist ~170
       // registers of loop-invariant operands: leaves room for 2 waves / SIMD so one wave's VALU phases
       // (ball query, frame, hi/lo splits) overlap the other's MFMAs
