@@ -15,6 +15,10 @@
 #include "common.h"
 #include "jacobi3.h"
 
+#ifndef PE_ABL
+#define PE_ABL 0  // timing probes (scripts/ubench/pe_ab.py; wrong results): 1 no MLP tiles, 2 no frame (eigen-solver, sign vote, x axis), 3 ball query over 64 points only
+#endif
+
 namespace unopose {
 
 // channel held by accumulator register r of half-wave h in the 32x32 C/D layout
@@ -32,7 +36,7 @@ __device__ __forceinline__ int pe_centre_frame(const float *sx, const float *sy,
                                                int ncand = -1) {
   // ---- ball query (pointnet2 ball_query_gpu.cu:14-49 semantics)
   int cnt = 0, first = 0;
-  const int nscan = ncand >= 0 ? ncand : N;
+  const int nscan = PE_ABL == 3 ? 64 : ncand >= 0 ? ncand : N;
   int k0 = 0;
   for (; k0 < nscan && cnt < S; k0 += 64) {
     int k = k0 + lane;
@@ -62,6 +66,10 @@ __device__ __forceinline__ int pe_centre_frame(const float *sx, const float *sy,
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+  if (PE_ABL == 2) {
+    xp = v3(1.f, 0.f, 0.f), yp = v3(0.f, 1.f, 0.f), zp = v3(0.f, 0.f, 1.f);
+    return cnt;
+  }
   // ---- local reference frame (LRF_batch, pointnet2_utils.py:436-481)
   float a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
   for (int l = lane; l < S; l += 64) {
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
       for (int r = 0; r < 16; ++r) rmax[t][r] = 0.f;  // post-ReLU values are >= 0
     // (tiles of nothing but copies of the first neighbour -- the padding of a list with fewer than S points inside the radius -- are
     //  skipped: their rows equal row 0's, the maximum cannot change; round 5)
-    const int S_eff = min(S, (min(cnt, S) + 31) & ~31);
+    const int S_eff = PE_ABL == 1 ? 0 : min(S, (min(cnt, S) + 31) & ~31);
     for (int t0 = 0; t0 < S_eff; t0 += 32) {
       // keep the weight fragments in LDS (re-read per tile) instead of letting the compiler hoist ~170
       // registers of loop-invariant operands: leaves room for 2 waves / SIMD so one wave's VALU phases
