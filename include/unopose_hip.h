@@ -227,6 +227,17 @@ int unopose_bn_relu_train_forward(const float *x, int B, int C, long L, const fl
 int unopose_bn_relu_train_backward(const float *x, const float *dy, int B, int C, long L, const float *gamma, const float *beta,
                                    const float *mean, const float *rstd, float *workspace, float *dgamma, float *dbeta, float *dx,
                                    unopose_stream_t stream);
+
+/* nn.Conv2d(cin, cout, 1, bias=False) of the same SharedMLP under autograd (pytorch_utils.py:25-132 in train()), on (B, C, L) float32
+ * slabs with L = N * S a multiple of 64 (v_mfma_f32_32x32x2_f32: fp32 products and accumulation).
+ *   forward:  y[b, m, l] = sum_k w[m, k] x[b, k, l], w (cout, cin) row-major.  The input gradient is the same call on the transposed
+ *             weights (x := dy, w := w^T).  Built channel pairs: cin <= 8 -> 32; <= 32 -> 32, 64; <= 64 -> 32, 64, 128; <= 128 -> 64, 128.
+ *   wgrad:    dw[m, k] = sum_{b, l} dy[b, m, l] x[b, k, l]; workspace = unopose_conv1x1_train_wgrad_blocks() * cout * 128 floats
+ *             (per-workgroup partial sums, combined in double: deterministic).  Built: cout in {32, 64, 128} with cin <= 32 / 64 / 128. */
+int unopose_conv1x1_train_wgrad_blocks(void);
+int unopose_conv1x1_train_forward(const float *x, int B, int cin, long L, const float *w, int cout, float *y, unopose_stream_t stream);
+int unopose_conv1x1_train_wgrad(const float *dy, const float *x, int B, int cout, int cin, long L, float *workspace, float *dw,
+                                unopose_stream_t stream);
 int unopose_assign_labels(const float *atten, int B, int R, int C, const float *score1,
                           const float *score2, float *stats_ws, float *w1, float *w2,
                           unopose_stream_t stream);

@@ -175,6 +175,37 @@ def test_fused_infonce_matches_cross_entropy_pair():
         assert float((ga.double() - ad.grad).abs().max()) < 1e-5 * scale + 1e-9, (float((ga.double() - ad.grad).abs().max()), scale)
 
 
+@pytest.mark.parametrize("B,cin,cout,N,S,xgrad", [(2, 6, 32, 37, 64, False), (3, 32, 64, 50, 64, True), (2, 64, 128, 33, 256, True),
+                                                    (1, 64, 128, 1, 64, True), (5, 32, 64, 1030, 64, True), (2, 64, 128, 2048, 64, True)])
+def test_own_conv1x1_train_matches_torch(B, cin, cout, N, S, xgrad):
+    """csrc/conv_train.hip (bias-free 1 x 1 Conv2d on (B, C, N, S): forward, input gradient, weight gradient on the fp32 matrix
+    instruction) vs torch.nn.functional.conv2d in float64: every result within 2e-6 of its tensor's scale (fp32 products and
+    accumulation over <= 128 channels; the weight gradient sums up to 262 k positions per workgroup in fp32, partials in double)."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout + N)
+    x = torch.randn(B, cin, N, S, generator=g).cuda().requires_grad_(xgrad)
+    conv = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()
+    dy = torch.randn(B, cout, N, S, generator=g).cuda()
+    y = ops.conv1x1(x, conv)
+    assert "Conv1x1Fn" in type(y.grad_fn).__name__  # the own path was taken
+    y.backward(dy)
+    xd = x.detach().double().requires_grad_(xgrad)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xd, wd)
+    yr.backward(dy.double())
+    assert float((y.detach().double() - yr.detach()).abs().max()) < 2e-6 * float(yr.detach().abs().max())
+    assert float((conv.weight.grad.double() - wd.grad).abs().max()) < 2e-6 * float(wd.grad.abs().max()), \
+        (float((conv.weight.grad.double() - wd.grad).abs().max()), float(wd.grad.abs().max()))
+    if xgrad:
+        assert float((x.grad.double() - xd.grad).abs().max()) < 2e-6 * float(xd.grad.abs().max())
+    else:
+        assert x.grad is None
+    # slabs that are not a multiple of 64 positions, and the switch: the module itself
+    x2 = torch.randn(1, cin, 3, 33, generator=g).cuda()
+    assert torch.equal(ops.conv1x1(x2, conv), conv(x2))
+
+
 @pytest.mark.parametrize("shape", [(3, 32, 50, 64), (2, 128, 33, 256), (1, 6, 7, 4), (4, 64, 1025, 64)])
 def test_fused_bn_relu_train_matches_torch(shape):
     """csrc/bn_train.hip (relu(BatchNorm2d(x)) with batch statistics, forward + backward, running statistics) vs the torch modules in

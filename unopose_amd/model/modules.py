@@ -503,7 +503,8 @@ class _SharedMLP(nn.Module):
         """(B,C,N,S) through the unfolded layers: 1x1 Conv2d -> BatchNorm2d (train or eval statistics per module mode) ->
         ReLU.  The inference path never calls this (csrc/pe.hip runs the BN-folded chain); training does."""
         for l in self.layers():
-            x = ops.bn_relu(l.conv(x), l.normlayer.bn)  # train mode on the GPU: csrc/bn_train.hip (batch statistics + ReLU, fwd + bwd)
+            # train mode on the GPU: csrc/conv_train.hip (1 x 1 convolution, fwd + both gradients) and csrc/bn_train.hip (batch statistics + ReLU, fwd + bwd)
+            x = ops.bn_relu(ops.conv1x1(x, l.conv), l.normlayer.bn)
         return x
 
 

@@ -420,6 +420,67 @@ def bn_relu(x, bn):
     return F.relu(bn(x))
 
 
+TRAIN_OWN_CONV = True  # A/B attribute: False = nn.Conv2d (MIOpen) for the PE's 1 x 1 convolutions under train()
+_CONV_FWD_PAIRS = ((8, (32,)), (32, (32, 64)), (64, (32, 64, 128)), (128, (64, 128)))  # (cin up to, couts): csrc/conv_train.hip
+
+
+def _conv1x1_pair_ok(cin, cout):
+    return any(cin <= k and cout in ms for k, ms in _CONV_FWD_PAIRS)
+
+
+class _Conv1x1Fn(torch.autograd.Function):
+    """nn.Conv2d(cin, cout, 1, bias=False) on (B, C, N, S) fp32 (pytorch_utils.py:25-132 in train mode) on csrc/conv_train.hip:
+    forward y = W x and input gradient dx = W^T dy are one kernel (v_mfma_f32_32x32x2_f32 along the contiguous positions, weights in
+    LDS), the weight gradient dW = sum dy x^T stages both tensors through LDS (lanes along channels) with per-workgroup partials
+    reduced in double.  No NCHW <-> NHWC transposes, no library call."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        B, C = x.shape[:2]
+        L = x.numel() // (B * C)
+        M = weight.shape[0]
+        x = _c(x)
+        w2 = _c(weight.detach().reshape(M, C).float())
+        y = torch.empty((B, M) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            call("unopose_conv1x1_train_forward", ptr(x), B, C, L, ptr(w2), M, ptr(y), stream_ptr())
+        ctx.save_for_backward(x, w2)
+        ctx.wshape = tuple(weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        M, C = w2.shape
+        B = x.shape[0]
+        L = x.numel() // (B * C)
+        dy = _c(dy.float())
+        dx = dw = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                call("unopose_conv1x1_train_forward", ptr(dy), B, M, L, ptr(w2.t().contiguous()), C, ptr(dx), stream_ptr())
+            if ctx.needs_input_grad[1]:
+                ws = torch.empty(lib().unopose_conv1x1_train_wgrad_blocks() * M * 128, dtype=torch.float32, device=x.device)
+                dw = torch.empty(M, C, dtype=torch.float32, device=x.device)
+                call("unopose_conv1x1_train_wgrad", ptr(dy), ptr(x), B, M, C, L, ptr(ws), ptr(dw), stream_ptr())
+                dw = dw.reshape(ctx.wshape)
+        return dx, dw
+
+
+def conv1x1(x, conv):
+    """`conv(x)` for a bias-free 1 x 1 nn.Conv2d: under autograd on fp32 CUDA data with a supported channel pair the own kernels
+    (forward, and both gradients in backward), else the module itself."""
+    w = conv.weight
+    cout, cin = w.shape[0], w.shape[1]
+    L = x[0, 0].numel() if x.dim() >= 3 else 0
+    if (TRAIN_OWN_CONV and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and conv.bias is None
+            and w.shape[2:] == (1, 1) and x.dim() == 4 and L % 64 == 0 and 64 <= L < (1 << 28) and _conv1x1_pair_ok(cin, cout)
+            and (not x.requires_grad or _conv1x1_pair_ok(cout, cin)) and cout in (32, 64, 128)):
+        return _Conv1x1Fn.apply(x, w)
+    return conv(x)
+
+
 TRAIN_OWN_GEMM = True  # A/B attribute: False = nn.Linear through the library
 # The persistent 256 x 256-tile kernels pay off from a few tens of GFLOP per launch (measured at the training shapes: a
 # 32 776 x 256 x 256 linear takes 38 us on csrc/gemm_f32.hip and 17 us on the library, the 4096 x 3072 x 4096 up-projection
