@@ -228,6 +228,17 @@ int unopose_bn_relu_train_backward(const float *x, const float *dy, int B, int C
                                    const float *mean, const float *rstd, float *workspace, float *dgamma, float *dbeta, float *dx,
                                    unopose_stream_t stream);
 
+/* The LAST SharedMLP layer fused with the max over the S neighbours that follows it (oneref_predator_fine_point_matching.py:167-174
+ * in train()): out[b, c, n] = max_s relu(batch_norm(x))[b, c, n, s], idx = the first arg max; x (B, C, N, S) float32, S in {32, 64, 128, 256}.
+ * The normalised activation is never written.  Backward takes the POOLED gradient g (B, C, N): dgamma / dbeta from the B N winners,
+ * dx dense.  Workspaces: forward as unopose_bn_relu_train_forward (L = N S), backward 2 * B * C floats. */
+int unopose_bn_relu_maxpool_train_forward(const float *x, int B, int C, int N, int S, const float *gamma, const float *beta, float eps,
+                                          float momentum, float *running_mean, float *running_var, float *workspace, float *mean, float *rstd,
+                                          float *out, int32_t *idx, unopose_stream_t stream);
+int unopose_bn_relu_maxpool_train_backward(const float *x, const float *g, const int32_t *idx, int B, int C, int N, int S, const float *gamma,
+                                           const float *beta, const float *mean, const float *rstd, float *workspace, float *dgamma, float *dbeta,
+                                           float *dx, unopose_stream_t stream);
+
 /* nn.Conv2d(cin, cout, 1, bias=False) of the same SharedMLP under autograd (pytorch_utils.py:25-132 in train()), on (B, C, L) float32
  * slabs with L = N * S a multiple of 64 (v_mfma_f32_32x32x2_f32: fp32 products and accumulation).
  *   forward:  y[b, m, l] = sum_k w[m, k] x[b, k, l], w (cout, cin) row-major.  The input gradient is the same call on the transposed

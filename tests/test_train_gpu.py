@@ -175,6 +175,48 @@ def test_fused_infonce_matches_cross_entropy_pair():
         assert float((ga.double() - ad.grad).abs().max()) < 1e-5 * scale + 1e-9, (float((ga.double() - ad.grad).abs().max()), scale)
 
 
+@pytest.mark.parametrize("shape", [(3, 32, 50, 64), (2, 128, 33, 256), (1, 6, 7, 32), (4, 64, 1025, 64), (2, 16, 300, 128)])
+def test_fused_bn_relu_maxpool_train_matches_torch(shape):
+    """csrc/bn_train.hip, the last SharedMLP layer with its pooling: max_s relu(BatchNorm2d(x)) with batch statistics, forward +
+    backward from the POOLED gradient, vs the torch modules in float64 (same tolerances as the unpooled op).  One column is
+    duplicated many times, as ball-query padding does: ties between equal maxima must not change any gradient."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(sum(shape) + 5)
+    x0 = torch.randn(*shape, generator=g) * 1.7 + 0.4
+    x0[..., shape[3] // 2:] = x0[..., :1]  # the second half of every neighbourhood = copies of its first neighbour
+    x = x0.cuda().requires_grad_(True)
+    dy = torch.randn(*shape[:3], generator=g).cuda()
+    bn = torch.nn.BatchNorm2d(shape[1]).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(shape[1], generator=g) + 0.5)
+        bn.weight[::3] *= -1.0  # negative scales: the winner is the smallest input
+        bn.bias.copy_(torch.randn(shape[1], generator=g) * 0.3)
+    ref_bn = torch.nn.BatchNorm2d(shape[1]).double().cuda().train()
+    ref_bn.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    xd = x.detach().double().requires_grad_(True)
+    yr = torch.relu(ref_bn(xd)).max(dim=3)[0]
+    yr.backward(dy.double())
+    y = ops.bn_relu_maxpool(x, bn)
+    assert "BNReLUMaxPoolTrain" in type(y.grad_fn).__name__  # the fused path was taken
+    y.backward(dy)
+    sc = float(yr.detach().abs().max())
+    assert float((y.detach().double() - yr.detach()).abs().max()) < 2e-6 * sc
+    # the gradient of tied winners may land on any of the equal columns: compare what is invariant, the sum over each tie class
+    def classes(t):
+        half = shape[3] // 2
+        return torch.cat([t[..., :1] + t[..., half:].sum(-1, keepdim=True), t[..., 1:half]], -1)
+    gs = float(xd.grad.abs().max())
+    assert float((classes(x.grad.double()) - classes(xd.grad)).abs().max()) < 2e-6 * gs * shape[3] + 1e-9
+    assert float((bn.weight.grad.double() - ref_bn.weight.grad).abs().max()) < 1e-5 * float(ref_bn.weight.grad.abs().max())
+    assert float((bn.bias.grad.double() - ref_bn.bias.grad).abs().max()) < 1e-5 * float(ref_bn.bias.grad.abs().max())
+    assert float((bn.running_mean.double() - ref_bn.running_mean).abs().max()) < 1e-6
+    assert float((bn.running_var.double() - ref_bn.running_var).abs().max()) < 1e-6 * float(ref_bn.running_var.abs().max())
+    # other neighbourhood sizes / eval mode: the unfused composition
+    bn.eval()
+    assert torch.equal(ops.bn_relu_maxpool(x.detach(), bn), torch.relu(bn(x.detach())).max(dim=3)[0])
+
+
 @pytest.mark.parametrize("B,cin,cout,N,S,xgrad", [(2, 6, 32, 37, 64, False), (3, 32, 64, 50, 64, True), (2, 64, 128, 33, 256, True),
                                                     (1, 64, 128, 1, 64, True), (5, 32, 64, 1030, 64, True), (2, 64, 128, 2048, 64, True)])
 def test_own_conv1x1_train_matches_torch(B, cin, cout, N, S, xgrad):

@@ -507,6 +507,13 @@ class _SharedMLP(nn.Module):
             x = ops.bn_relu(ops.conv1x1(x, l.conv), l.normlayer.bn)
         return x
 
+    def forward_pooled(self, x):
+        """`forward(x).max(dim=3)[0]` with the last layer's BatchNorm + ReLU fused into the pooling (training; csrc/bn_train.hip)."""
+        ls = self.layers()
+        for l in ls[:-1]:
+            x = ops.bn_relu(ops.conv1x1(x, l.conv), l.normlayer.bn)
+        return ops.bn_relu_maxpool(ops.conv1x1(x, ls[-1].conv), ls[-1].normlayer.bn)
+
 
 class _Conv1d(nn.Module):
     def __init__(self, cin, cout):
@@ -533,8 +540,8 @@ class PositionalEncoding(nn.Module):
             # reference, whose `_ext` outputs carry no gradient), then the REAL Conv2d / BatchNorm2d modules -- batch
             # statistics and running-stat updates in train mode (pytorch_utils.py:25-132) -- recorded by autograd
             with torch.autocast("cuda", enabled=False):
-                f1 = self.mlp1(ops.query_lrf_group(pts, self.r1, self.ns1)).max(dim=3)[0]
-                f2 = self.mlp2(ops.query_lrf_group(pts, self.r2, self.ns2)).max(dim=3)[0]
+                f1 = self.mlp1.forward_pooled(ops.query_lrf_group(pts, self.r1, self.ns1))
+                f2 = self.mlp2.forward_pooled(ops.query_lrf_group(pts, self.r2, self.ns2))
             return torch.cat([f1, f2], dim=1).transpose(1, 2)
         if pts.is_cuda and (torch.is_autocast_enabled() or ops.USE_F32X3) and self.r2 >= self.r1 and self.ns1 % 32 == 0 and self.ns2 % 32 == 0:
             # the wide scale first: its neighbour lists are the candidates of the narrow scale (csrc/pe.hip)

@@ -420,6 +420,57 @@ def bn_relu(x, bn):
     return F.relu(bn(x))
 
 
+class _BNReLUMaxPoolTrain(torch.autograd.Function):
+    """max over the last axis of relu(batch_norm(x)) with BATCH statistics, x (B, C, N, S): the last SharedMLP layer and the pooling
+    after it (Fi:167-174 under train()) as one op on csrc/bn_train.hip.  Saved for backward: x, mean, rstd, the arg max (B, C, N)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn):
+        B, C, N, S = x.shape
+        x = _c(x)
+        chunk = lib().unopose_bn_train_chunk()
+        ws = torch.empty(2 * B * C * ((N * S + chunk - 1) // chunk), dtype=torch.float32, device=x.device)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        out = torch.empty(B, C, N, dtype=torch.float32, device=x.device)
+        idx = torch.empty(B, C, N, dtype=torch.int32, device=x.device)
+        track = bn.track_running_stats and bn.running_mean is not None
+        if track:
+            bn.num_batches_tracked.add_(1)
+            momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item())
+        else:
+            momentum = 0.0
+        w, b_ = _c(weight.detach().float()), _c(bias.detach().float())
+        with torch.cuda.device(x.device):
+            call("unopose_bn_relu_maxpool_train_forward", ptr(x), B, C, N, S, ptr(w), ptr(b_), float(bn.eps), float(momentum),
+                 ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None, ptr(ws), ptr(mean), ptr(rstd), ptr(out), ptr(idx),
+                 stream_ptr())
+        ctx.save_for_backward(x, w, b_, mean, rstd, idx)
+        ctx.mark_non_differentiable(idx)
+        return out, idx
+
+    @staticmethod
+    def backward(ctx, g, _gidx):
+        x, w, b_, mean, rstd, idx = ctx.saved_tensors
+        B, C, N, S = x.shape
+        g = _c(g.float())
+        ws = torch.empty(2 * B * C, dtype=torch.float32, device=x.device)
+        dgamma, dbeta, dx = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            call("unopose_bn_relu_maxpool_train_backward", ptr(x), ptr(g), ptr(idx), B, C, N, S, ptr(w), ptr(b_), ptr(mean), ptr(rstd), ptr(ws),
+                 ptr(dgamma), ptr(dbeta), ptr(dx), stream_ptr())
+        return dx, dgamma, dbeta, None
+
+
+def bn_relu_maxpool(x, bn):
+    """F.relu(bn(x)).max(dim=3)[0] for x (B, C, N, S): fused (csrc/bn_train.hip) when `bn` is in train mode on fp32 CUDA data with
+    S in {32, 64, 128, 256}, else `bn_relu` followed by torch's max."""
+    if (USE_FUSED_BN_RELU and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[3] in (32, 64, 128, 256)
+            and bn.weight is not None and bn.bias is not None and x.shape[0] <= 65535 and x.shape[1] <= 65535):
+        return _BNReLUMaxPoolTrain.apply(x, bn.weight, bn.bias, bn)[0]
+    return bn_relu(x, bn).max(dim=3)[0]
+
+
 TRAIN_OWN_CONV = True  # A/B attribute: False = nn.Conv2d (MIOpen) for the PE's 1 x 1 convolutions under train()
 _CONV_FWD_PAIRS = ((8, (32,)), (32, (32, 64)), (64, (32, 64, 128)), (128, (64, 128)))  # (cin up to, couts): csrc/conv_train.hip
 
