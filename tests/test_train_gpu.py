@@ -104,6 +104,46 @@ def test_train_step_at_baseline_config3_shape():
     assert all(p.grad is None for p in m.feature_extraction.rgb_net.vit.parameters())
 
 
+def test_no_library_convolution_or_batchnorm_in_the_training_step():
+    """The eval guard (test_pipeline_gpu.py::test_no_library_gemm_on_the_eval_path) extended to model.train(): during a training
+    forward + backward no convolution and no batch-norm op of the library (MIOpen) runs on GPU data -- the PE's SharedMLP is
+    csrc/conv_train.hip + csrc/bn_train.hip under autograd, the ViT's patch embedding is the own GEMM -- and the profiler sees the own
+    kernels of all three passes.  Self-checking: with the switches off the guard fires."""
+    from torch.profiler import ProfilerActivity, profile
+
+    from unopose_amd import ops
+    from unopose_amd.losses import process_loss
+
+    model = _model().train()
+    batch, aug = make_train_batch()
+
+    def step():
+        ep = {k: v.cuda() for k, v in batch.items()}
+        ep["aug_pose"] = (aug[0].cuda(), aug[1].cuda())
+        model.zero_grad(set_to_none=True)
+        process_loss(model(ep))["loss"].backward()
+        torch.cuda.synchronize()
+
+    def library_ops():
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            step()
+        names = [e.key for e in prof.key_averages()]
+        lib = sorted({n for n in names if any(t in n.lower() for t in ("miopen", "convolution", "conv2d", "batch_norm", "batchnorm", "igemm", "sp3asm"))})
+        return lib, names
+
+    step()  # caches
+    lib, names = library_ops()
+    assert lib == [], lib
+    for k in ("conv1x1_f32_kernel", "conv1x1_wgrad_kernel", "bn_relu_maxpool_kernel", "bn_relu_maxpool_bwd_apply_kernel", "bn_relu_apply_kernel"):
+        assert any(k in n for n in names), k
+    ops.TRAIN_OWN_CONV, ops.USE_FUSED_BN_RELU = False, False
+    try:
+        lib, _ = library_ops()
+    finally:
+        ops.TRAIN_OWN_CONV, ops.USE_FUSED_BN_RELU = True, True
+    assert len(lib) >= 2, lib
+
+
 @pytest.mark.parametrize("amp", [False, True])
 @pytest.mark.parametrize("relu", [False, True])
 def test_trainable_linear_on_own_gemm_matches_torch_autograd(amp, relu, monkeypatch):
@@ -271,8 +311,8 @@ def test_fused_bn_relu_train_matches_torch(shape):
     y = ops.bn_relu(x, bn)
     assert y.grad_fn is not None and "BNReLUTrain" in type(y.grad_fn).__name__  # the fused path was taken
     y.backward(dy)
-    sc = float(yr.abs().max())
-    assert float((y.double() - yr).abs().max()) < 2e-6 * sc
+    sc = float(yr.detach().abs().max())
+    assert float((y.detach().double() - yr.detach()).abs().max()) < 2e-6 * sc
     assert float((x.grad.double() - xd.grad).abs().max()) < 2e-6 * float(xd.grad.abs().max()) + 1e-9
     assert float((bn.weight.grad.double() - ref_bn.weight.grad).abs().max()) < 1e-5 * float(ref_bn.weight.grad.abs().max())
     assert float((bn.bias.grad.double() - ref_bn.bias.grad).abs().max()) < 1e-5 * float(ref_bn.bias.grad.abs().max())
