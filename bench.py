@@ -661,7 +661,9 @@ def main():
                            "median_rot_err_vs_gt": e32.median().item(),
                            "arithmetic": "bf16x3 hi/lo split on the matrix cores with fp32 accumulation (hi.hi + hi.lo + lo.hi: ~2^-17 relative per "
                                          "product, not IEEE fp32's 2^-24) in every linear layer and attention contraction; geometry (FPS, ball query, "
-                                         "frames, Procrustes, assignment statistics) and the small contractions of bmm_f32 in exact fp32"}
+                                         "frames, Procrustes, assignment statistics) and the small contractions of bmm_f32 in exact fp32; the "
+                                         "geometric embedding's two projections of sinusoids by 6-point Lagrange interpolation (fp32 arithmetic) on "
+                                         "fp32 tables of the projected functions (interpolation error ~1e-6 of the weights' scale)"}
         if not args.no_roofline:
             res.update(roofline_leg(model, batch, args.img))
             log("roofline leg done")

@@ -177,13 +177,13 @@ int unopose_geo_embedding(const float *points, int B, int n, const void *wd_hi,
 
 /* The same function (core/unopose/model/transformer.py:303-350) evaluated through tables: proj_d(sinus(x)) and proj_a(sinus(x))
  * are smooth functions of one scalar per output channel, tabulated by the caller -- tab_d (rows_d, 256) and tab_a (rows_a, 256)
- * float32 WITHOUT the biases, row r holding the value at x = (r - 1) / hinv (hinv must be 4; one row of margin below 0, two above
- * the last index) -- and interpolated with a 4-point Lagrange cubic (error ~1e-4 of the weights' scale: meant for the bfloat16
- * result of the autocast forward, 5x faster than the matrix-core kernel above).  A distance index above (rows_d - 4) / hinv is
- * evaluated from its defining sum with w_d (proj_d.weight, (256, 256) float32 row-major) and div_term; rows_a must cover
- * pi * factor_a (rows_a >= floor(pi factor_a hinv) + 5). */
+ * float32 WITHOUT the biases, row r holding the value at x = (r - (npoint / 2 - 1)) / hinv (hinv must be 4) -- and interpolated with
+ * an npoint-point Lagrange polynomial: npoint = 4 (error ~1e-4 of the weights' scale: the bfloat16 result of the autocast forward,
+ * 3x faster than the matrix-core kernel above) or 6 (~1e-6: float32 class, the fp32 forward).  A distance index above
+ * (rows_d - npoint) / hinv is evaluated from its defining sum with w_d (proj_d.weight, (256, 256) float32 row-major) and div_term;
+ * rows_a must cover pi * factor_a (rows_a >= floor(pi factor_a hinv) + npoint + 1). */
 int unopose_geo_embedding_table(const float *points, int B, int n, const float *tab_d, int rows_d, const float *tab_a, int rows_a,
-                                const float *bias_sum, const float *w_d, const float *div_term, int hinv, float sigma_d,
+                                const float *bias_sum, const float *w_d, const float *div_term, int hinv, int npoint, float sigma_d,
                                 float factor_a, int reduce_mean, int out_bf16, int32_t *knn_ws, void *out,
                                 unopose_stream_t stream);
 

@@ -22,7 +22,7 @@ int main(int argc, char **argv) {
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0, 0);
     for (int it = 0; it < 20; ++it)
-      if (unopose_geo_embedding_table(dp, B, n, dtd, rows_d, dta, rows_a, db, dw, dd, 4, 0.2f, 3.8197186f, 0, 1, knn, out, 0)) return 1;
+      if (unopose_geo_embedding_table(dp, B, n, dtd, rows_d, dta, rows_a, db, dw, dd, 4, 4, 0.2f, 3.8197186f, 0, 1, knn, out, 0)) return 1;
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("GT_ABL=%d B=%d: %.1f us per call (knn + table kernel)\n",

@@ -216,12 +216,13 @@ def test_geo_embedding_kernel_full_size_fp32_and_bf16(model):
 @pytest.mark.parametrize("n,scale,mean", [(197, 1.2, False), (197, 1.2, True), (70, 1.2, False), (4, 1.0, False), (130, 9.0, False),
                                           (66, 400.0, False)])
 def test_geo_embedding_table_kernel_vs_matrix_core_kernel(model, n, scale, mean):
-    """`unopose_geo_embedding_table` (4-point Lagrange on fp32 tables of proj_d(sinus(.)) / proj_a(sinus(.))) vs the
-    split-operand matrix-core kernel, both producing fp32: interpolation error <= 2e-4 off the diagonal at every size
-    class -- one and several 64-column chunks, a ragged last chunk, the minimum n, distance indices past the
-    LDS-resident rows (scale 9: up to ~75, global rows, then the defining sum) and far past the table (scale 400:
-    the defining sum, fp32 sin of large arguments on both sides -> looser).  The bf16 result the model uses is then the
-    correctly rounded fp32 value +- that error."""
+    """`unopose_geo_embedding_table` (Lagrange interpolation on fp32 tables of proj_d(sinus(.)) / proj_a(sinus(.))) vs the
+    split-operand matrix-core kernel, both producing fp32, at every size class -- one and several 64-column chunks, a ragged
+    last chunk, the minimum n, distance indices past the LDS-resident rows (scale 9: up to ~75, global rows, then the
+    defining sum) and far past the table (scale 400: the defining sum, fp32 sin of large arguments on both sides -> looser).
+    4-point (the bf16 result of the autocast forward): interpolation error <= 2e-4 off the diagonal; 6-point (the fp32
+    forward): <= 2e-5, i.e. the agreement of the two fp32-class kernels themselves.  The bf16 result the model uses is
+    the correctly rounded fp32 value +- that error."""
     import copy
 
     from unopose_amd import ops
@@ -232,25 +233,30 @@ def test_geo_embedding_table_kernel_vs_matrix_core_kernel(model, n, scale, mean)
     g = torch.Generator().manual_seed(90 + n)
     B = 3
     pts = torch.cat([torch.ones(B, 1, 3), (torch.rand(B, n - 1, 3, generator=g) - 0.5) * scale], 1).cuda()
-    ref = ops.geo_embedding(pts, m, out_dtype=torch.float32)
-    tab = ops._geo_tables(m, ("test", n, mean))
+    ops.GEO_TABLE_F32 = False
+    try:
+        ref = ops.geo_embedding(pts, m, out_dtype=torch.float32)
+    finally:
+        ops.GEO_TABLE_F32 = True
     bias = (m.proj_d.bias + m.proj_a.bias).float().contiguous()
     knn = torch.empty(B, n, 3, dtype=torch.int32, device="cuda")
-    for out_bf16 in (0, 1):
+    for npoint, out_bf16 in ((4, 0), (4, 1), (6, 0)):
+        tab = ops._geo_tables(m, ("test", n, mean), npoint)
         out = torch.empty(B, n, n, 256, dtype=torch.bfloat16 if out_bf16 else torch.float32, device="cuda")
         call("unopose_geo_embedding_table", ptr(pts), B, n, ptr(tab[0]), tab[0].shape[0], ptr(tab[1]), tab[1].shape[0], ptr(bias),
-             ptr(tab[2]), ptr(m.embedding.div_term.float().contiguous()), 4, float(m.sigma_d), float(m.factor_a), int(mean),
+             ptr(tab[2]), ptr(m.embedding.div_term.float().contiguous()), 4, npoint, float(m.sigma_d), float(m.factor_a), int(mean),
              out_bf16, ptr(knn), ptr(out), stream_ptr())
         torch.cuda.synchronize()
         if n >= 8:
             off, diag = _offdiag_err(out.float(), ref)
         else:
             off = diag = (out.float() - ref).abs().max().item()
-        tol = (2e-4 if scale < 100 else 4e-3) + (2e-2 if out_bf16 else 0.0)
-        assert off < tol and diag < 2e-2 + tol, (out_bf16, off, diag)
-    if scale < 100:   # the op routes the autocast dtype through the tables
-        outb = ops.geo_embedding(pts, m, out_dtype=torch.bfloat16)
-        assert torch.equal(outb, out)
+        tol = ((2e-4 if npoint == 4 else 2e-5) if scale < 100 else 4e-3) + (2e-2 if out_bf16 else 0.0)
+        assert off < tol and diag < 2e-2 + tol, (npoint, out_bf16, off, diag)
+        if scale < 100:   # the op routes both dtypes through the tables
+            got = ops.geo_embedding(pts, m, out_dtype=out.dtype)
+            if (npoint, out_bf16) in ((4, 1), (6, 0)):
+                assert torch.equal(got, out)
 
 
 @torch.no_grad()

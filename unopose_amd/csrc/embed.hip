@@ -284,27 +284,18 @@ __global__ __launch_bounds__(GE_THREADS) void geo_embed_kernel(
 // sinusoids of frequencies 10000^(-i/128) <= 1 --, so instead of generating 256 sinusoids per index and contracting them with a 256 x 256
 // matrix (131 kflop per index, four indices per pair: what the kernel above does on the matrix cores) the two functions
 //     f_d(x) = W_d sinus(x),   f_a(x) = W_a sinus(x)          (256 channels each, biases added at the end)
-// are tabulated once per weight version at spacing h = 1 / GT_HINV (fp32, `ops.geo_embedding`) and evaluated by 4-point Lagrange
-// interpolation: error <= 0.0234 h^4 max|d4f/dx4| = 9e-5 max|d4f/dx4| at h = 1/4, and the fourth derivative is bounded by
-// sum_i w_i^4 (|W_sin| + |W_cos|) ~ 0.5 for 1/16-sized weights -- two orders below the bf16 result's resolution (this path serves the
-// autocast forward; the fp32 forward keeps the split-operand kernel above).  The tables (distance range [0, 16): 67 rows, angle range
-// [0, pi factor_a]: ~52 rows, 1 KiB per row) live in LDS; a distance index past the LDS range reads its rows from the full table in global
-// memory (wave-uniform branch).  A wave owns a row (b, i) of the output: 64 lanes compute the four indices of 64 columns j at once, then
-// every pair is 4 lookups x 4 rows x 16 B per lane (4 channels) and 64 fma; the result row (512 B) leaves as one coalesced store.
-constexpr int GT_HINV = 4;                // table nodes per unit index
-constexpr int GT_RDL = 16 * GT_HINV + 3;  // distance rows held in LDS (index range [0, 16))
+// are tabulated once per weight version at spacing h = 1 / GT_HINV (fp32, `ops.geo_embedding`) and evaluated by NP-point Lagrange
+// interpolation.  NP = 4 (the autocast forward, bf16 result): error <= 0.0234 h^4 max|d4f/dx4| = 9e-5 max|d4f/dx4| at h = 1/4, the fourth
+// derivative bounded by sum_i w_i^4 (|W_sin| + |W_cos|) ~ 0.5 for 1/16-sized weights -- two orders below the bf16 result's resolution.
+// NP = 6 (the fp32 forward): error <= 0.0235 h^6 max|d6f/dx6| = 5.7e-6 max|d6f/dx6| -- fp32 class, as the split-operand kernel above.
+// The tables (distance range [0, 16): 64 + NP - 1 rows, angle range [0, pi factor_a]: ~48 + NP rows, 1 KiB per row) live in LDS; a distance
+// index past the LDS range reads its rows from the full table in global memory, one past that the defining sum (wave-uniform branches).
+// A wave takes a contiguous share of the pairs: 64 lanes compute the four indices, table rows and weights of 64 columns j at once, then
+// every pair is 4 lookups x NP rows x 16 B per lane (4 channels) and 16 NP fma; the result row (512 B / 1 KiB) leaves as one coalesced store.
+constexpr int GT_HINV = 4;  // table nodes per unit index
 
 typedef float gt_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const gt_f4 gt_lds_f4;
-
-// sum_m w[m] T[m] for this lane's four channels; the weights are wave-uniform (SGPRs).  Scalar v_fma_f32 on purpose: packed fp32
-// instructions return wrong values next to another kernel's MFMA waves (DESIGN.md section 7, round 3; tests/test_abi.py).
-__device__ __forceinline__ void gt_lerp(gt_f4 a, gt_f4 b, gt_f4 c, gt_f4 d, float w0, float w1, float w2, float w3, float (&v)[4]) {
-  v[0] = fmaf(d.x, w3, fmaf(c.x, w2, fmaf(b.x, w1, a.x * w0)));
-  v[1] = fmaf(d.y, w3, fmaf(c.y, w2, fmaf(b.y, w1, a.y * w0)));
-  v[2] = fmaf(d.z, w3, fmaf(c.z, w2, fmaf(b.z, w1, a.z * w0)));
-  v[3] = fmaf(d.w, w3, fmaf(c.w, w2, fmaf(b.w, w1, a.w * w0)));
-}
 
 __device__ __forceinline__ float gt_bcast(float v, int l) {
 #if defined(GT_ABL) && GT_ABL == 1   // (timing probe, scripts/ubench/geo_table_abl.cpp: no weight broadcasts)
@@ -313,16 +304,46 @@ __device__ __forceinline__ float gt_bcast(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-template <bool OUT_BF16, bool MEAN>
+// sum_m w[m] T[m] for this lane's four channels; the weights are lane l's, broadcast (SGPRs).  Scalar v_fma_f32 on purpose: packed fp32
+// instructions return wrong values next to another kernel's MFMA waves (DESIGN.md section 7, round 3; tests/test_abi.py).
+template <int NP>
+__device__ __forceinline__ void gt_lerp(const gt_f4 (&t)[NP], const float (&w)[NP], int l, float (&v)[4]) {
+  float s = gt_bcast(w[0], l);
+  v[0] = t[0].x * s, v[1] = t[0].y * s, v[2] = t[0].z * s, v[3] = t[0].w * s;
+#pragma unroll
+  for (int m = 1; m < NP; ++m) {
+    s = gt_bcast(w[m], l);
+    v[0] = fmaf(t[m].x, s, v[0]), v[1] = fmaf(t[m].y, s, v[1]), v[2] = fmaf(t[m].z, s, v[2]), v[3] = fmaf(t[m].w, s, v[3]);
+  }
+}
+
+// Lagrange weights of the nodes -(NP / 2 - 1) .. NP / 2 at f in [0, 1)
+template <int NP>
+__device__ __forceinline__ void gt_weights(float f, float (&w)[NP]) {
+  constexpr int LO = NP / 2 - 1;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    float num = 1.f, den = 1.f;
+#pragma unroll
+    for (int m = 0; m < NP; ++m)
+      if (m != j) {
+        num *= f - (float)(m - LO);
+        den *= (float)(j - m);
+      }
+    w[j] = num * (1.f / den);
+  }
+}
+
+template <bool OUT_BF16, bool MEAN, int NP>
 __global__ __launch_bounds__(1024) void geo_embed_table_kernel(const float *__restrict__ pts, const int32_t *__restrict__ knn,
                                                                const float *__restrict__ tab_d, int rows_d, const float *__restrict__ tab_a,
                                                                int rows_a, const float *__restrict__ bias, const float *__restrict__ w_d,
                                                                const float *__restrict__ div_term, int B, int n, float sigma_d,
                                                                float factor_a, void *__restrict__ out_) {
   extern __shared__ float4 gt_smem[];
-  const int rd_l = min(rows_d, GT_RDL);  // distance rows [0, rd_l) then the angle rows
+  const int rd_l = min(rows_d, 16 * GT_HINV + NP - 1);  // distance rows [0, rd_l) (index range [0, 16)), then the angle rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  {  // tables -> LDS, eight loads in flight per thread (256 workgroups read the same 119 KiB: latency-, not bandwidth-bound)
+  {  // tables -> LDS, eight loads in flight per thread
     const int nd = rd_l * 64, ne = nd + rows_a * 64;
     for (int e0 = tid; e0 < ne; e0 += 8 * (int)blockDim.x) {
       float4 r[8];
@@ -341,8 +362,9 @@ __global__ __launch_bounds__(1024) void geo_embed_table_kernel(const float *__re
   __syncthreads();
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)gt_smem + lane * 16;  // this lane's 4 channels of row 0
   const gt_f4 b4 = reinterpret_cast<const gt_f4 *>(bias)[lane];
-  const float a_max = (float)(rows_a - 4) / (float)GT_HINV;  // (angle indices are <= pi factor_a by construction; clamped for safety)
-  const float d_max = (float)(rows_d - 4) / (float)GT_HINV;
+  // row r of a table holds x = (r - (NP / 2 - 1)) / HINV: the NP rows from floor(x HINV) on are the nodes around x
+  const float a_max = (float)(rows_a - NP) / (float)GT_HINV;  // (angle indices are <= pi factor_a by construction; clamped for safety)
+  const float d_max = (float)(rows_d - NP) / (float)GT_HINV;
   // every wave takes an equal contiguous share of the B n n pairs (rows of 197 columns do not divide into waves evenly)
   const long P = (long)B * n * n, W = (long)gridDim.x * nwaves, per = (P + W - 1) / W;
   const long p0 = ((long)blockIdx.x * nwaves + wave) * per, p1 = min(P, p0 + per);
@@ -367,19 +389,15 @@ __global__ __launch_bounds__(1024) void geo_embed_table_kernel(const float *__re
       const float cosv = 0.0f + (rx * ax + ry * ay + rz * az);  // (+0: atan2(0, +0) = 0 for i == j as torch.sum gives it)
       idx[1 + k] = fminf(atan2f(sinv, cosv) * factor_a, a_max);
     }
-    int off[4];      // LDS byte offset of the first of the 4 rows (row r holds x = (r - 1) / HINV: rows floor(x HINV) .. + 3 <-> nodes -1, 0, 1, 2)
-    float w[4][4];   // Lagrange weights of nodes -1, 0, 1, 2 at f = frac(x HINV)
+    int off[4];       // LDS byte offset of the first of the NP rows
+    float w[4][NP];   // Lagrange weights at f = frac(x HINV)
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-      const float x = idx[s4] * (float)GT_HINV, fl = floorf(x), f = x - fl;
+      const float x = idx[s4] * (float)GT_HINV, fl = floorf(x);
       const int r0 = (int)fl;
-      const float fm1 = f - 1.f, fm2 = f - 2.f, fp1 = f + 1.f;
-      w[s4][0] = -f * fm1 * fm2 * (1.f / 6.f);
-      w[s4][1] = fp1 * fm1 * fm2 * 0.5f;
-      w[s4][2] = -fp1 * f * fm2 * 0.5f;
-      w[s4][3] = fp1 * f * fm1 * (1.f / 6.f);
+      gt_weights<NP>(x - fl, w[s4]);
       if (s4 == 0)
-        off[0] = (idx[0] <= d_max) ? (r0 + 3 < rd_l ? r0 * 1024 : -1 - r0) : (int)0x80000000;   // >= 0 LDS, < 0 global row, INT_MIN: the sum
+        off[0] = (idx[0] <= d_max) ? (r0 + NP - 1 < rd_l ? r0 * 1024 : -1 - r0) : (int)0x80000000;   // >= 0 LDS, < 0 global row, INT_MIN: the sum
       else
         off[s4] = (rd_l + r0) * 1024;
     }
@@ -388,22 +406,28 @@ __global__ __launch_bounds__(1024) void geo_embed_table_kernel(const float *__re
     for (int l = 0; l < cols; ++l) {
       float v[4][4];
       const int od = __builtin_amdgcn_readlane(off[0], l);
-      // the twelve angle rows first (always LDS), so that their latency runs under the distance lookup
-      gt_f4 ta[3][4];
+      // the first angle's rows before the distance lookup (always LDS): their latency runs under it
+      gt_f4 ta[NP], tb[NP];
+      auto lds_rows = [&](int k, gt_f4 (&dst)[NP]) {
+        gt_lds_f4 *t = (gt_lds_f4 *)(uintptr_t)(lds0 + __builtin_amdgcn_readlane(off[k], l));
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        gt_lds_f4 *t = (gt_lds_f4 *)(uintptr_t)(lds0 + __builtin_amdgcn_readlane(off[1 + k], l));
-        ta[k][0] = t[0], ta[k][1] = t[64], ta[k][2] = t[128], ta[k][3] = t[192];
+        for (int m = 0; m < NP; ++m) dst[m] = t[64 * m];
 #if defined(GT_ABL) && GT_ABL == 2   // (timing probe: no LDS reads)
-        ta[k][0] = ta[k][1] = ta[k][2] = ta[k][3] = gt_f4{(float)(uintptr_t)t, 1.f, 2.f, 3.f};
+#pragma unroll
+        for (int m = 0; m < NP; ++m) dst[m] = gt_f4{(float)(uintptr_t)t, 1.f, 2.f, 3.f};
 #endif
-      }
+      };
+      lds_rows(1, ta);
       if (od >= 0) {
         gt_lds_f4 *t = (gt_lds_f4 *)(uintptr_t)(lds0 + od);
-        gt_lerp(t[0], t[64], t[128], t[192], gt_bcast(w[0][0], l), gt_bcast(w[0][1], l), gt_bcast(w[0][2], l), gt_bcast(w[0][3], l), v[0]);
+#pragma unroll
+        for (int m = 0; m < NP; ++m) tb[m] = t[64 * m];
+        gt_lerp<NP>(tb, w[0], l, v[0]);
       } else if (od != (int)0x80000000) {   // past the LDS-resident rows: the full table in global memory
         const gt_f4 *g = reinterpret_cast<const gt_f4 *>(tab_d) + (size_t)(-1 - od) * 64 + lane;
-        gt_lerp(g[0], g[64], g[128], g[192], gt_bcast(w[0][0], l), gt_bcast(w[0][1], l), gt_bcast(w[0][2], l), gt_bcast(w[0][3], l), v[0]);
+#pragma unroll
+        for (int m = 0; m < NP; ++m) tb[m] = g[64 * m];
+        gt_lerp<NP>(tb, w[0], l, v[0]);
       } else {
         // (rare) a distance index past the table -- clouds that are not radius-normalised --: the defining sum itself,
         // f_d(x)[c] = sum_i W[c][2i] sin(x w_i) + W[c][2i + 1] cos(x w_i), for this lane's four channels.  (NaN coordinates come here too.)
@@ -421,10 +445,11 @@ __global__ __launch_bounds__(1024) void geo_embed_table_kernel(const float *__re
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[0][c] = acc[c];
       }
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        gt_lerp(ta[k][0], ta[k][1], ta[k][2], ta[k][3], gt_bcast(w[1 + k][0], l), gt_bcast(w[1 + k][1], l), gt_bcast(w[1 + k][2], l),
-                gt_bcast(w[1 + k][3], l), v[1 + k]);
+      lds_rows(2, tb);
+      gt_lerp<NP>(ta, w[1], l, v[1]);
+      lds_rows(3, ta);
+      gt_lerp<NP>(tb, w[2], l, v[2]);
+      gt_lerp<NP>(ta, w[3], l, v[3]);
       float o[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -481,12 +506,14 @@ int unopose_geo_embedding(const float *points, int B, int n, const void *wd_hi, 
 }
 
 int unopose_geo_embedding_table(const float *points, int B, int n, const float *tab_d, int rows_d, const float *tab_a, int rows_a,
-                                const float *bias_sum, const float *w_d, const float *div_term, int hinv, float sigma_d, float factor_a, int reduce_mean, int out_bf16, int32_t *knn_ws,
+                                const float *bias_sum, const float *w_d, const float *div_term, int hinv, int npoint, float sigma_d, float factor_a, int reduce_mean, int out_bf16, int32_t *knn_ws,
                                 void *out, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(points && tab_d && tab_a && bias_sum && w_d && div_term && knn_ws && out, "geo_embedding_table: null pointer");
   UNOPOSE_REQUIRE(B >= 0 && n >= 4 && B <= 65535, "geo_embedding_table: bad sizes (n must be >= 4 for 3-NN)");
-  UNOPOSE_REQUIRE(hinv == GT_HINV && rows_d >= 8 && rows_a >= 8, "geo_embedding_table: tables must be spaced 1 / %d (got 1 / %d)", GT_HINV, hinv);
-  const size_t lds = ((size_t)(rows_d < GT_RDL ? rows_d : GT_RDL) + rows_a) * 1024;
+  UNOPOSE_REQUIRE(hinv == GT_HINV && (npoint == 4 || npoint == 6) && rows_d >= 8 && rows_a >= 8,
+                  "geo_embedding_table: tables must be spaced 1 / %d (got 1 / %d) for 4- or 6-point interpolation (got %d)", GT_HINV, hinv, npoint);
+  const int rdl = 16 * GT_HINV + npoint - 1;
+  const size_t lds = ((size_t)(rows_d < rdl ? rows_d : rdl) + rows_a) * 1024;
   UNOPOSE_REQUIRE(lds <= 150 * 1024, "geo_embedding_table: %d angle rows do not fit the LDS-resident table", rows_a);
   if (B == 0) return UNOPOSE_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -497,17 +524,25 @@ int unopose_geo_embedding_table(const float *points, int B, int n, const float *
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
   const long pairs = (long)B * n * n;
   const int grid = (int)(pairs < (long)cus * 256 ? (pairs + 255) / 256 : cus);  // one 16-wave workgroup per CU (the tables fill its LDS), >= 16 pairs per wave
-#define UNOPOSE_GT_LAUNCH(BF, MEAN)                                                                                                       \
-  do {                                                                                                                                    \
-    static bool opt[64];                                                                                                                  \
-    if (lds_optin(opt, (const void *)geo_embed_table_kernel<BF, MEAN>, lds, "geo_embedding_table") != UNOPOSE_OK) return UNOPOSE_ELAUNCH; \
-    hipLaunchKernelGGL((geo_embed_table_kernel<BF, MEAN>), dim3(grid), dim3(1024), lds, s, points, knn_ws, tab_d, rows_d, tab_a, rows_a,  \
-                       bias_sum, w_d, div_term, B, n, sigma_d, factor_a, out);                                                            \
+#define UNOPOSE_GT_LAUNCH(BF, MEAN, NPT)                                                                                                       \
+  do {                                                                                                                                         \
+    static bool opt[64];                                                                                                                       \
+    if (lds_optin(opt, (const void *)geo_embed_table_kernel<BF, MEAN, NPT>, lds, "geo_embedding_table") != UNOPOSE_OK) return UNOPOSE_ELAUNCH; \
+    hipLaunchKernelGGL((geo_embed_table_kernel<BF, MEAN, NPT>), dim3(grid), dim3(1024), lds, s, points, knn_ws, tab_d, rows_d, tab_a, rows_a,  \
+                       bias_sum, w_d, div_term, B, n, sigma_d, factor_a, out);                                                                 \
   } while (0)
-  if (out_bf16 && reduce_mean) UNOPOSE_GT_LAUNCH(true, true);
-  else if (out_bf16) UNOPOSE_GT_LAUNCH(true, false);
-  else if (reduce_mean) UNOPOSE_GT_LAUNCH(false, true);
-  else UNOPOSE_GT_LAUNCH(false, false);
+#define UNOPOSE_GT_ORDER(BF, MEAN)         \
+  do {                                     \
+    if (npoint == 4)                       \
+      UNOPOSE_GT_LAUNCH(BF, MEAN, 4);      \
+    else                                   \
+      UNOPOSE_GT_LAUNCH(BF, MEAN, 6);      \
+  } while (0)
+  if (out_bf16 && reduce_mean) UNOPOSE_GT_ORDER(true, true);
+  else if (out_bf16) UNOPOSE_GT_ORDER(true, false);
+  else if (reduce_mean) UNOPOSE_GT_ORDER(false, true);
+  else UNOPOSE_GT_ORDER(false, false);
+#undef UNOPOSE_GT_ORDER
 #undef UNOPOSE_GT_LAUNCH
   return check_launch("geo_embedding_table");
 }

@@ -1173,32 +1173,36 @@ def _mfma_fragment_order(w):
     return w.reshape(8, 32, 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
 
 
-GEO_TABLE = True     # bf16 (autocast) result through the table-interpolated kernel; False: the matrix-core kernel for both dtypes
+GEO_TABLE = True     # bf16 (autocast) result through the table-interpolated kernel (4-point); False: the matrix-core kernel
+GEO_TABLE_F32 = True  # fp32 result through the 6-point table kernel (fp32-class interpolation error); False: the split-operand matrix-core kernel
 _GEO_HINV = 4        # table nodes per unit index (csrc/embed.hip: GT_HINV)
 _GEO_D_RANGE = 64    # distance indices the table covers (the kernel evaluates larger ones from the defining sum)
 
 
-def _geo_tables(m, key):
-    """proj_d(sinus(x)) and proj_a(sinus(x)) without their biases on the grid x = (r - 1) / 4 (fp64 sum, stored fp32), cached per
-    weight version: what `unopose_geo_embedding_table` interpolates.  None when the angle table would not fit the kernel's LDS."""
-    cache = getattr(m, "_hip_tables", None)
-    if cache is not None and cache[0] == key:
-        return cache[1]
+def _geo_tables(m, key, npoint=4):
+    """proj_d(sinus(x)) and proj_a(sinus(x)) without their biases on the grid x = (r - (npoint / 2 - 1)) / 4 (fp64 sum, stored fp32),
+    cached per weight version and interpolation order: what `unopose_geo_embedding_table` interpolates.  None when the angle table
+    would not fit the kernel's LDS."""
+    cache = m.__dict__.setdefault("_hip_tables", {})
+    c = cache.get(npoint)
+    if c is not None and c[0] == key:
+        return c[1]
     import math
-    rows_a = int(math.floor(math.pi * float(m.factor_a) * _GEO_HINV)) + 5
-    rows_d = _GEO_D_RANGE * _GEO_HINV + 4
+    lo = npoint // 2 - 1
+    rows_a = int(math.floor(math.pi * float(m.factor_a) * _GEO_HINV)) + npoint + 1
+    rows_d = _GEO_D_RANGE * _GEO_HINV + npoint
     tabs = None
-    if rows_a <= 80:
+    if rows_a <= 80 - npoint:
         div = m.embedding.div_term.detach().double()
 
         def table(rows, lin):
-            x = (torch.arange(rows, device=div.device, dtype=torch.float64) - 1.0) / _GEO_HINV
+            x = (torch.arange(rows, device=div.device, dtype=torch.float64) - float(lo)) / _GEO_HINV
             om = x[:, None] * div[None, :]
             s = torch.stack([torch.sin(om), torch.cos(om)], dim=-1).reshape(rows, -1)
             return (s @ lin.weight.detach().double().t()).float().contiguous()
 
         tabs = (table(rows_d, m.proj_d), table(rows_a, m.proj_a), m.proj_d.weight.detach().float().contiguous())
-    m._hip_tables = (key, tabs)
+    cache[npoint] = (key, tabs)
     return tabs
 
 
@@ -1206,10 +1210,10 @@ def geo_embedding(points, m, out_dtype=None):
     """GeometricStructureEmbedding.forward (transformer.py:303-350) as ONE fused HIP kernel
     (sinusoid generation -> MFMA -> max-over-k epilogue; csrc/embed.hip).  Under autocast(bf16) the
     result is bf16 with plain bf16 operands (what proj_d / proj_a produce under autocast in the
-    reference); otherwise fp32 with hi/lo-split operands (fp32-class accuracy).  Round 5: the bf16 result
-    comes from the table-interpolated kernel (`unopose_geo_embedding_table`: fp32 arithmetic on exact-to-1e-4
-    tables of the two projections, no bf16 operand rounding at all -- closer to the fp32 function than the
-    reference's own autocast result, and 5x faster than the contraction)."""
+    reference); otherwise fp32 with hi/lo-split operands (fp32-class accuracy).  Round 5: both results come
+    from the table-interpolated kernel (`unopose_geo_embedding_table`: fp32 Lagrange interpolation on tables of the
+    two projections -- 4-point for the bf16 result, no bf16 operand rounding at all, 6-point (error ~1e-6) for the
+    fp32 result; 3x / 5x faster than the contractions); `GEO_TABLE` / `GEO_TABLE_F32` switch back."""
     if _DIFF or m.proj_d.weight.shape != (256, 256) or m.angle_k != 3 or points.shape[1] < 4:
         if not _DIFF:
             note_fallback("geo_embedding", f"hidden_dim {tuple(m.proj_d.weight.shape)} / angle_k {m.angle_k} / {points.shape[1]} points (kernel: 256, 3, >= 4)")
@@ -1232,13 +1236,14 @@ def geo_embedding(points, m, out_dtype=None):
     _, wdh, wdl, wah, wal, bias, div = cache
     out = torch.empty(B, n, n, 256, dtype=out_dtype, device=points.device)
     knn = torch.empty(B, n, 3, dtype=torch.int32, device=points.device)
-    if bf16_out and GEO_TABLE:
-        tab = _geo_tables(m, key)
+    if GEO_TABLE if bf16_out else GEO_TABLE_F32:
+        npoint = 4 if bf16_out else 6
+        tab = _geo_tables(m, key, npoint)
         if tab is not None:
             with torch.cuda.device(points.device):
                 call("unopose_geo_embedding_table", ptr(points), B, n, ptr(tab[0]), tab[0].shape[0], ptr(tab[1]), tab[1].shape[0],
-                     ptr(bias), ptr(tab[2]), ptr(div), _GEO_HINV, float(m.sigma_d), float(m.factor_a),
-                     int(m.reduction_a == "mean"), 1, ptr(knn), ptr(out), stream_ptr())
+                     ptr(bias), ptr(tab[2]), ptr(div), _GEO_HINV, npoint, float(m.sigma_d), float(m.factor_a),
+                     int(m.reduction_a == "mean"), int(bf16_out), ptr(knn), ptr(out), stream_ptr())
             return out
     with torch.cuda.device(points.device):
         call("unopose_geo_embedding", ptr(points), B, n, ptr(wdh), ptr(wdl), ptr(wah), ptr(wal), ptr(bias), ptr(div),
