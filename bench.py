@@ -210,7 +210,15 @@ def roofline_leg(model, batch, img):
     n = model.coarse_npoint + 1
     gp = torch.cat([torch.ones(B, 1, 3, device=x.device), x[:, :n - 1]], 1).contiguous()
     t = hip_event_time(lambda: ops.geo_embedding(gp, model.geo_embedding, out_dtype=torch.bfloat16), 10, stream)
-    row("geo_embed_kernel<bf16>", "mfma", B * 8.0 * n * n * 256 * 256, 1e12, 2500.0, "TFLOP/s", t)
+    row("geo_embed_table_kernel<bf16>(4-point table interpolation) + geo_knn_kernel", "hbm", B * 512.0 * n * n, 1e9, 8000.0, "GB/s", t,
+        "what the step runs: the (B, n, n, 256) bf16 result is written once (the algorithmic bytes); the kernel itself is VALU-issue-bound "
+        "(16 ds_read_b128 + 64 v_fma_f32 + 20 v_readlane per pair and lane), not HBM-bound")
+    ops.GEO_TABLE = False
+    try:
+        t = hip_event_time(lambda: ops.geo_embedding(gp, model.geo_embedding, out_dtype=torch.bfloat16), 10, stream)
+    finally:
+        ops.GEO_TABLE = True
+    row("geo_embed_kernel<bf16>(matrix-core form, not on the step's path)", "mfma", B * 8.0 * n * n * 256 * 256, 1e12, 2500.0, "TFLOP/s", t)
     # correspondence-transformer attention on the 197-token coarse sequences, both clouds stacked (2B): the RPE self-attention streams the
     # geometric embedding E (B2,197,197,256) bf16 once -- its only HBM-sized operand; the cross-attention (no E) is a 39.7 MFLOP problem
     # per cloud and layer: launch / latency-sized

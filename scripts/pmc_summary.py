@@ -12,7 +12,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 SHORT = ["token_attn_kernel<true", "vit_attn_kernel", "group_points_lds_kernel", "pe_group_mlp_max_bf16x3_kernel",
-         "ball_query_kernel", "geo_embed_kernel", "geo_knn_kernel", "gemm256_kernel<1, false, false>", "gemm256_kernel<0, false, false>",
+         "ball_query_kernel", "geo_embed_kernel", "geo_embed_table_kernel", "geo_knn_kernel", "gemm256_kernel<1, false, false>", "gemm256_kernel<0, false, false>",
          "fine_assign_kernel<0>", "fine_assign_kernel<1>", "fine_assign_kernel<2>"]
 # gemm256_kernel<1, false, false>: fc1 + GELU (M = 87936, 768 -> 3072); <0, false, false>: MEAN over the qkv / proj / fc2 launches of
 # scripts/pmc_kernels.py (three shapes, three launches each); the per-shape numbers are under "gemm_shapes"
