@@ -6,7 +6,7 @@ sys.path.insert(0, root)
 mode, srcs = sys.argv[1], sys.argv[2:]
 if mode == "build":
     for i, src in enumerate(srcs):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-fPIC", "-shared",
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-fno-vectorize", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-fPIC", "-shared",
                f"-I{root}/include", f"-I{root}/unopose_amd/csrc", *src.split("@")[1:], src.split("@")[0], f"{root}/unopose_amd/csrc/abi.hip",
                "-o", os.path.join(here, f"_pe{i}.so")]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -15,6 +15,9 @@
 #include "common.h"
 #include "jacobi3.h"
 
+#ifndef PE_SCAN_STEPS
+#define PE_SCAN_STEPS 4  // 64-candidate steps of the ball query per loop trip (A/B: scripts/build_variant.py -DPE_SCAN_STEPS=1)
+#endif
 #ifndef PE_ABL
 #define PE_ABL 0  // timing probes (scripts/ubench/pe_ab.py; wrong results): 1 no MLP tiles, 2 no frame (eigen-solver, sign vote, x axis), 3 ball query over 64 points only
 #endif
@@ -38,26 +41,39 @@ __device__ __forceinline__ int pe_centre_frame(const float *sx, const float *sy,
   int cnt = 0, first = 0;
   const int nscan = PE_ABL == 3 ? 64 : ncand >= 0 ? ncand : N;
   int k0 = 0;
-  for (; k0 < nscan && cnt < S; k0 += 64) {
-    int k = k0 + lane;
-    bool hit = false;
-    if (k < nscan) {
-      if (ncand >= 0) k = cand[k];
-      const float x = sx[k], y = sy[k], z = sz[k];
-      const float d2 = (cx - x) * (cx - x) + (cy - y) * (cy - y) + (cz - z) * (cz - z);
-      hit = d2 < r2;
-    }
-    const unsigned long long mask = __ballot(hit);
-    if (mask) {
-      const int pre =
-          (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-      const int pos = cnt + pre;
-      if (hit && pos < S) nbr[pos] = k;
-      if (cnt == 0) {
-        const int fl = __builtin_ctzll(mask);  // lane of the first hit
-        first = ncand >= 0 ? __builtin_amdgcn_readlane(k, fl) : k0 + fl;
+  // PE_SCAN_STEPS (four) 64-candidate steps per trip: their LDS reads, distance tests and ballots are independent, only the list positions chain
+  // through cnt (one step at a time the loop was a chain of LDS -> VALU -> ballot -> scalar latencies: a third of a launch)
+  constexpr int U = PE_SCAN_STEPS;
+  for (; k0 < nscan && cnt < S; k0 += 64 * U) {
+    int kk[U];
+    unsigned long long mask[U];
+    bool hit[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int k = k0 + 64 * u + lane;
+      hit[u] = false;
+      if (k < nscan) {
+        if (ncand >= 0) k = cand[k];
+        const float x = sx[k], y = sy[k], z = sz[k];
+        const float d2 = (cx - x) * (cx - x) + (cy - y) * (cy - y) + (cz - z) * (cz - z);
+        hit[u] = d2 < r2;
       }
-      cnt += __builtin_popcountll(mask);
+      kk[u] = k;
+      mask[u] = __ballot(hit[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (mask[u]) {
+        const int pre =
+            (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[u], 0u));
+        const int pos = cnt + pre;
+        if (hit[u] && pos < S) nbr[pos] = kk[u];
+        if (cnt == 0) {
+          const int fl = __builtin_ctzll(mask[u]);  // lane of the first hit
+          first = ncand >= 0 ? __builtin_amdgcn_readlane(kk[u], fl) : k0 + 64 * u + fl;
+        }
+        cnt += __builtin_popcountll(mask[u]);
+      }
     }
   }
   if (k0 < nscan) cnt = S + 1;  // stopped early at a full list: the rest of the cloud was not looked at
