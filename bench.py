@@ -196,16 +196,23 @@ def roofline_leg(model, batch, img):
         row("vit_attn_f32s_kernel(T=%d)" % T, "mfma", 2.0 * B * 12 * 4.0 * T * T * 64, 1e12, 2500.0 / 3.0, "TFLOP/s", t,
             "fp32-equivalent flops against 1/3 of the bf16 dense peak (3 bf16 MFMAs per product in both contractions)")
         del qs
-    # PE, S=256, bf16 hi/lo-split matrix cores; 20864 flop per neighbour row
+    # PE, S=256, bf16 hi/lo-split matrix cores; 20864 flop per neighbour row.  The kernels skip the 32-row tiles that hold nothing but the
+    # ball query's padding (copies of the first neighbour cannot change the max-pool: bit-identical output), so `achieved` counts the rows
+    # they really push through the MLP -- from the neighbour counts of these clouds -- and the reference's S rows per centre are reported
+    # beside it (`algorithmic_rows_frac`): a fraction above what the matrix cores did would be meaningless
+    _, (_, cnt) = ops.pe_group_mlp_max(x, pe.r2, pe.ns2, pe.mlp2, bf16x3=True, want_cand=True)
+    cnt = torch.where(cnt < 0, torch.full_like(cnt, pe.ns2), cnt).clamp(max=pe.ns2)
+    rows_done = float((((cnt + 31) // 32) * 32).clamp(max=pe.ns2).sum().item())
     t = hip_event_time(lambda: ops.pe_group_mlp_max(x, pe.r2, pe.ns2, pe.mlp2, bf16x3=True), 10, stream)
-    r = row("pe_group_mlp_max_bf16x3_kernel(S=%d)" % pe.ns2, "mfma", B * N * pe.ns2 * 20864.0, 1e12, 2500.0,
-            "TFLOP/s", t, "algorithmic fp32-equivalent flops of the reference's S rows per centre; the kernel issues 3 bf16 MFMAs per product and "
-                          "skips the 32-row tiles that hold nothing but the ball query's padding copies of the first neighbour (identical rows cannot "
-                          "change the max-pool: bit-identical output; on these clouds 2.4 of 8 tiles at S = 256 carry real neighbours)")
+    r = row("pe_group_mlp_max_bf16x3_kernel(S=%d)" % pe.ns2, "mfma", rows_done * 20864.0, 1e12, 2500.0,
+            "TFLOP/s", t, "fp32-equivalent flops of the neighbour rows the kernel computes (tiles of 32; %.1f of %d rows per centre on these clouds: the "
+                          "rest is ball-query padding, skipped bit-identically); 3 bf16 MFMAs per product" % (rows_done / (B * N), pe.ns2))
+    r["algorithmic_rows_frac"] = B * N * pe.ns2 * 20864.0 / t / 1e12 / 2500.0
     r["traffic"] = _pmc_traffic("pe_group_mlp_max_bf16x3_kernel", B)
     t = hip_event_time(lambda: ops.pe_group_mlp_max(x, pe.r2, pe.ns2, pe.mlp2, bf16x3=False), 5, stream)
-    row("pe_group_mlp_max_kernel(S=%d, exact fp32 MFMA)" % pe.ns2, "mfma", B * N * pe.ns2 * 20864.0, 1e12, 157.3,
-        "TFLOP/s", t)
+    r = row("pe_group_mlp_max_kernel(S=%d, exact fp32 MFMA)" % pe.ns2, "mfma", rows_done * 20864.0, 1e12, 157.3,
+            "TFLOP/s", t, "same row count (padding tiles skipped)")
+    r["algorithmic_rows_frac"] = B * N * pe.ns2 * 20864.0 / t / 1e12 / 157.3
     # geometric embedding: 8 n^2 256^2 flop per cloud
     n = model.coarse_npoint + 1
     gp = torch.cat([torch.ones(B, 1, 3, device=x.device), x[:, :n - 1]], 1).contiguous()

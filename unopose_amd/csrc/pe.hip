@@ -18,11 +18,16 @@
 #ifndef PE_SCAN_STEPS
 #define PE_SCAN_STEPS 4  // 64-candidate steps of the ball query per loop trip (A/B: scripts/build_variant.py -DPE_SCAN_STEPS=1)
 #endif
+#ifndef PE_GRID
+#define PE_GRID 1  // uniform grid for the bf16x3 kernel's ball query (A/B: -DPE_GRID=0 = the index-order scan over the whole cloud)
+#endif
 #ifndef PE_ABL
 #define PE_ABL 0  // timing probes (scripts/ubench/pe_ab.py; wrong results): 1 no MLP tiles, 2 no frame (eigen-solver, sign vote, x axis), 3 ball query over 64 points only
 #endif
 
 namespace unopose {
+
+typedef unsigned short u16;
 
 // channel held by accumulator register r of half-wave h in the 32x32 C/D layout
 __device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -33,12 +38,85 @@ __device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >>
 // within the radius (the neighbour list a larger-radius pass of the same cloud wrote, see cand_out below);
 // ncand < 0 = scan the whole cloud.  Returns the number of points inside the radius if the list holds them
 // all, a value > S otherwise.
+// ---- Round 5: a uniform grid for the ball query of the bf16x3 kernel.  The scan tests all N points of the cloud per centre although
+// ~75 of 2048 lie inside the radius; cells of edge >= 1.001 radius (at most PE_GDIM per axis: larger clouds get larger cells) leave the 27
+// cells around the centre's, and cell ids run along x, so those are NINE contiguous runs of the cell-sorted point list: ~9 steps of 64
+// candidates instead of 32.  The reference's order (the first S hits BY INDEX) is kept exactly: hits set bits of an N-bit map in LDS
+// (ds_or), and the list is read off the map in index order (popcount prefix over the lanes' words) -- same hit test on the same
+// coordinates, same list, bit-identical outputs.
+constexpr int PE_GDIM = 8, PE_GCELLS = PE_GDIM * PE_GDIM * PE_GDIM;
+struct PeGrid {
+  float ox, oy, oz, ihx, ihy, ihz;  // origin, inverse cell edges
+  int nx, ny, nz;
+  const u16 *start;  // [PE_GCELLS + 1]: first slot of a cell in `order`
+  const u16 *order;  // [N] point ids sorted by cell
+  uint32_t *bits;    // this wave's map, ceil(N / 32) words
+};
+__device__ __forceinline__ int pe_cell(float v, float o, float ih, int n) { return max(0, min(n - 1, (int)((v - o) * ih))); }
+
+template <typename NT>
 __device__ __forceinline__ int pe_centre_frame(const float *sx, const float *sy, const float *sz, int N, int S,
                                                float radius, float r2, int lane, float cx, float cy, float cz,
-                                               int *nbr, Vec3 &xp, Vec3 &yp, Vec3 &zp, const int *cand = nullptr,
-                                               int ncand = -1) {
+                                               NT *nbr, Vec3 &xp, Vec3 &yp, Vec3 &zp, const int *cand = nullptr,
+                                               int ncand = -1, const PeGrid *grid = nullptr) {
   // ---- ball query (pointnet2 ball_query_gpu.cu:14-49 semantics)
   int cnt = 0, first = 0;
+  if (grid && ncand < 0 && PE_ABL != 3) {
+    const int W = (N + 31) >> 5;
+    for (int w = lane; w < W; w += 64) grid->bits[w] = 0u;
+    // the nine runs: lane i < 9 looks up run (dy, dz) = (i % 3 - 1, i / 3 - 1)
+    const int icx = pe_cell(cx, grid->ox, grid->ihx, grid->nx), icy = pe_cell(cy, grid->oy, grid->ihy, grid->ny),
+              icz = pe_cell(cz, grid->oz, grid->ihz, grid->nz);
+    int rs = 0, re = 0;
+    if (lane < 9) {
+      const int y = icy + lane % 3 - 1, z = icz + lane / 3 - 1;
+      if (y >= 0 && y < grid->ny && z >= 0 && z < grid->nz) {
+        const int row = (z * grid->ny + y) * grid->nx;
+        rs = grid->start[row + max(icx - 1, 0)];
+        re = grid->start[row + min(icx + 1, grid->nx - 1) + 1];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+    for (int i = 0; i < 9; ++i) {
+      const int s0 = __builtin_amdgcn_readlane(rs, i), e0 = __builtin_amdgcn_readlane(re, i);
+      for (int q = s0 + lane; q < e0; q += 64) {
+        const int k = grid->order[q];
+        const float x = sx[k], y = sy[k], z = sz[k];
+        const float d2 = (cx - x) * (cx - x) + (cy - y) * (cy - y) + (cz - z) * (cz - z);
+        if (d2 < r2) atomicOr(&grid->bits[k >> 5], 1u << (k & 31));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the list in index order: lane-owned words, exclusive prefix of their popcounts
+    for (int w0 = 0; w0 < W; w0 += 64) {
+      const int w = w0 + lane;
+      uint32_t bits = w < W ? grid->bits[w] : 0u;
+      const int pc = __builtin_popcount(bits);
+      int incl = pc;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+      }
+      int pos = cnt + incl - pc;
+      while (bits) {
+        const int bpos = __builtin_ctz(bits);
+        bits &= bits - 1u;
+        if (pos < S) nbr[pos] = (NT)(32 * w + bpos);
+        ++pos;
+      }
+      cnt += __builtin_amdgcn_readlane(incl, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (cnt > 0) first = nbr[0];
+  } else {
   const int nscan = PE_ABL == 3 ? 64 : ncand >= 0 ? ncand : N;
   int k0 = 0;
   // PE_SCAN_STEPS (four) 64-candidate steps per trip: their LDS reads, distance tests and ballots are independent, only the list positions chain
@@ -67,7 +145,7 @@ __device__ __forceinline__ int pe_centre_frame(const float *sx, const float *sy,
         const int pre =
             (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[u], 0u));
         const int pos = cnt + pre;
-        if (hit[u] && pos < S) nbr[pos] = kk[u];
+        if (hit[u] && pos < S) nbr[pos] = (NT)kk[u];
         if (cnt == 0) {
           const int fl = __builtin_ctzll(mask[u]);  // lane of the first hit
           first = ncand >= 0 ? __builtin_amdgcn_readlane(kk[u], fl) : k0 + 64 * u + fl;
@@ -77,7 +155,8 @@ __device__ __forceinline__ int pe_centre_frame(const float *sx, const float *sy,
     }
   }
   if (k0 < nscan) cnt = S + 1;  // stopped early at a full list: the rest of the cloud was not looked at
-  for (int l = min(cnt, S) + lane; l < S; l += 64) nbr[l] = first;
+  }
+  for (int l = min(cnt, S) + lane; l < S; l += 64) nbr[l] = (NT)first;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -87,6 +166,8 @@ __device__ __forceinline__ int pe_centre_frame(const float *sx, const float *sy,
     return cnt;
   }
   // ---- local reference frame (LRF_batch, pointnet2_utils.py:436-481)
+  // (measured and not kept, round 5: the three passes with the padding entries' terms as per-pass constants -- bit-identical, no faster:
+  //  the frame's time is the eigen-solver and the wave reductions, not these reads)
   float a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
   for (int l = lane; l < S; l += 64) {
     const int k = nbr[l];
@@ -259,7 +340,6 @@ __global__ __launch_bounds__(256) void pe_group_mlp_max_kernel(
 // 16s + (e&3) + 8(e>>2) + 4hb (e = 0..7) -- exactly one 16-wide k-step of the next layer -- so the
 // weights are stored with their input channels permuted to k' = 16s + 8hb + e.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16;
 
 __device__ __forceinline__ u16 pe_f2bf(float f) {
   uint32_t u = __float_as_uint(f);
@@ -344,39 +424,113 @@ __global__ __launch_bounds__(256) void pe_pack_weights_kernel(const float *__res
 #ifndef PE_PREFETCH
 #define PE_PREFETCH 1
 #endif
-#if PE_WPE
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void pe_group_mlp_max_bf16x3_kernel(
-#else
-__global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
+#ifndef PE_NW
+#define PE_NW 4  // waves per workgroup of the bf16x3 kernel: two 4-wave workgroups per CU; 8 = one per CU (measured 4 % slower: -DPE_NW=8)
 #endif
+__global__ __launch_bounds__(PE_NW * 64, 8 / PE_NW) void pe_group_mlp_max_bf16x3_kernel(
     const float *__restrict__ xyz, int N, float radius, int S, int cpw, const uint4 *__restrict__ image,
     const int *__restrict__ cand_in, const int *__restrict__ cand_cnt_in, int cand_stride, int *__restrict__ cand_out,
-    int *__restrict__ cand_cnt_out, float *__restrict__ out, int out_ld, int out_split) {
+    int *__restrict__ cand_cnt_out, float *__restrict__ out, int out_ld, int out_split, int use_grid) {
   extern __shared__ float4 smem4[];
   PeLdsB *L = reinterpret_cast<PeLdsB *>(smem4);
   float *sx = reinterpret_cast<float *>(L + 1);
   float *sy = sx + N, *sz = sy + N;
-  int *nbr_all = reinterpret_cast<int *>(sz + N);
-  float *stage_all = reinterpret_cast<float *>(nbr_all + 4 * S);
+  float *stage_all = sz + N;                                           // [PE_NW][128] floats; the grid build's counters and each wave's bit map live here too
+  u16 *nbr_all = reinterpret_cast<u16 *>(stage_all + PE_NW * 128);    // [PE_NW][S] neighbour lists (N < 65536)
+  u16 *gstart = nbr_all + PE_NW * S;                                   // grid (use_grid): [PE_GCELLS + 2] cell starts, then [N] point ids by cell
+  u16 *gorder = gstart + PE_GCELLS + 2;
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
-  int *nbr = nbr_all + wave * S;
+  u16 *nbr = nbr_all + wave * S;
   float *stage = stage_all + wave * 128;
   const float *P = xyz + (size_t)b * N * 3;
 
-  for (int e = tid; e < N * 3; e += 256) {
+  for (int e = tid; e < N * 3; e += PE_NW * 64) {
     const float v = P[e];
     const int p = e / 3, comp = e - p * 3;
     (comp == 0 ? sx : comp == 1 ? sy : sz)[p] = v;
   }
   // the LDS weight image (hi/lo bf16, permuted, swizzled; built once by pe_pack_weights_kernel) is copied
   // verbatim with coalesced 16-byte loads
-  for (int e = tid; e < (int)(sizeof(PeLdsB) / 16); e += 256) smem4[e] = *reinterpret_cast<const float4 *>(image + e);
+  for (int e = tid; e < (int)(sizeof(PeLdsB) / 16); e += PE_NW * 64) smem4[e] = *reinterpret_cast<const float4 *>(image + e);
   __syncthreads();
   const float r2 = radius * radius;
+  PeGrid grid;
+  if (use_grid) {
+    // ---- the cloud's grid, built by every workgroup for itself (2 k points: a few microseconds against ~150 of centres)
+    static_assert(PE_NW * 128 >= PE_GCELLS, "the cell counters borrow the staging area");
+    uint32_t *cnt32 = reinterpret_cast<uint32_t *>(stage_all);
+    float *red = reinterpret_cast<float *>(nbr_all);  // 6 x PE_NW partial extrema (the lists are not in use yet)
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+    for (int p = tid; p < N; p += PE_NW * 64) {
+      lo[0] = fminf(lo[0], sx[p]), hi[0] = fmaxf(hi[0], sx[p]);
+      lo[1] = fminf(lo[1], sy[p]), hi[1] = fmaxf(hi[1], sy[p]);
+      lo[2] = fminf(lo[2], sz[p]), hi[2] = fmaxf(hi[2], sz[p]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = -wave_max_f32(-lo[a]);
+      hi[a] = wave_max_f32(hi[a]);
+      if (lane == 0) red[wave * 6 + a] = lo[a], red[wave * 6 + 3 + a] = hi[a];
+    }
+    for (int c = tid; c < PE_GCELLS; c += PE_NW * 64) cnt32[c] = 0u;
+    __syncthreads();
+    float org[3], ih[3];
+    int nd[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float l = red[a], h = red[3 + a];
+      for (int w = 1; w < PE_NW; ++w) l = fminf(l, red[w * 6 + a]), h = fmaxf(h, red[w * 6 + 3 + a]);
+      const float ext = h - l, h0 = radius * 1.001f;  // (cells a little wider than the radius: a neighbour is at most ONE cell away under fp rounding)
+      int n = (int)(ext / h0) + 1;
+      float edge = h0;
+      if (!(n <= PE_GDIM)) n = PE_GDIM, edge = fmaxf(h0, ext / (float)PE_GDIM * 1.001f);
+      // (the same in every lane: kept in scalar registers)
+      org[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(l)));
+      ih[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.f / edge)));
+      nd[a] = __builtin_amdgcn_readfirstlane(max(n, 1));
+    }
+    grid.ox = org[0], grid.oy = org[1], grid.oz = org[2], grid.ihx = ih[0], grid.ihy = ih[1], grid.ihz = ih[2];
+    grid.nx = nd[0], grid.ny = nd[1], grid.nz = nd[2];
+    grid.start = gstart, grid.order = gorder, grid.bits = reinterpret_cast<uint32_t *>(stage);
+    auto cell_of = [&](int p) {
+      return (pe_cell(sz[p], grid.oz, grid.ihz, grid.nz) * grid.ny + pe_cell(sy[p], grid.oy, grid.ihy, grid.ny)) * grid.nx +
+             pe_cell(sx[p], grid.ox, grid.ihx, grid.nx);
+    };
+    for (int p = tid; p < N; p += PE_NW * 64) atomicAdd(&cnt32[cell_of(p)], 1u);
+    __syncthreads();
+    {  // exclusive scan of the PE_GCELLS counters: PE_GCELLS / (PE_NW * 64) consecutive cells per thread, wave scan, wave totals through LDS
+      constexpr int CPT = PE_GCELLS / (PE_NW * 64);
+      static_assert(CPT * PE_NW * 64 == PE_GCELLS, "cells divide among the threads");
+      uint32_t c[CPT], sum = 0;
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) c[e] = cnt32[tid * CPT + e], sum += c[e];
+      uint32_t incl = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+      }
+      uint32_t *wtot = reinterpret_cast<uint32_t *>(red) + 32;
+      if (lane == 63) wtot[wave] = incl;
+      __syncthreads();
+      uint32_t base = incl - sum;
+      for (int w = 0; w < wave; ++w) base += wtot[w];
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) {
+        gstart[tid * CPT + e] = (u16)base;
+        cnt32[tid * CPT + e] = base;  // the fill pass's cursor
+        base += c[e];
+      }
+      if (tid == PE_NW * 64 - 1) gstart[PE_GCELLS] = (u16)base;
+    }
+    __syncthreads();
+    for (int p = tid; p < N; p += PE_NW * 64) gorder[atomicAdd(&cnt32[cell_of(p)], 1u)] = (u16)p;
+    __syncthreads();
+  }
 
   for (int ci = 0; ci < cpw; ++ci) {
-    const int j = (blockIdx.x * 4 + wave) * cpw + ci;
+    const int j = (blockIdx.x * PE_NW + wave) * cpw + ci;
     if (j >= N) break;  // wave-uniform
     const float cx = sx[j], cy = sy[j], cz = sz[j];
     Vec3 xp, yp, zp;
@@ -388,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void pe_group_mlp_max_bf16x3_kernel(
       ncand = cand_cnt_in[(size_t)b * N + j];  // -1: the producer's list overflowed, scan everything
       cand = cand_in + ((size_t)b * N + j) * cand_stride;
     }
-    const int cnt = pe_centre_frame(sx, sy, sz, N, S, radius, r2, lane, cx, cy, cz, nbr, xp, yp, zp, cand, ncand);
+    const int cnt = pe_centre_frame(sx, sy, sz, N, S, radius, r2, lane, cx, cy, cz, nbr, xp, yp, zp, cand, ncand, use_grid ? &grid : nullptr);
     if (cand_out) {
       int *co = cand_out + ((size_t)b * N + j) * S;
       for (int l = lane; l < S; l += 64) co[l] = nbr[l];
@@ -650,15 +804,21 @@ int unopose_pe_group_mlp_max_packed_out(const float *xyz, int B, int N, float ra
   UNOPOSE_REQUIRE(B >= 0 && N >= 1 && nsample >= 32 && nsample % 32 == 0 && B <= 65535,
                   "pe_group_mlp_max_packed: nsample must be a positive multiple of 32 (got %d)", nsample);
   if (B == 0) return UNOPOSE_OK;
-  const size_t lds = sizeof(PeLdsB) + ((size_t)3 * N + 4 * (size_t)nsample + 4 * 128) * 4;
-  UNOPOSE_REQUIRE(lds <= 160 * 1024, "pe_group_mlp_max_packed: N=%d nsample=%d exceed the LDS tile", N, nsample);
+  // cloud (3 N floats) + staging + 16-bit neighbour lists; the ball query's grid (cell starts + the cell-sorted point ids) when the
+  // cloud's bit map fits a wave's staging row and the whole still leaves room for two workgroups per CU or the cloud is large anyway
+  size_t lds = sizeof(PeLdsB) + ((size_t)3 * N + PE_NW * 128) * 4 + (size_t)PE_NW * nsample * 2;
+  UNOPOSE_REQUIRE(N < 65536 && lds <= 160 * 1024, "pe_group_mlp_max_packed: N=%d nsample=%d exceed the LDS tile", N, nsample);
+  const size_t grid_bytes = ((size_t)PE_GCELLS + 2 + (size_t)N) * 2;
+  const int use_grid = PE_GRID && N <= 4096 && N >= 256 && lds + grid_bytes <= 160 * 1024 && (lds + grid_bytes <= 80 * 1024 || lds > 80 * 1024);
+  if (use_grid) lds += grid_bytes;
+  lds = (lds + 15) & ~(size_t)15;
   static bool opt[64];
   if (lds_optin(opt, (const void *)pe_group_mlp_max_bf16x3_kernel, 160 * 1024, "pe_group_mlp_max_packed") != UNOPOSE_OK) return UNOPOSE_ELAUNCH;
   const long centres = (long)B * N;
   const int cpw = centres >= 65536 ? 16 : centres >= 32768 ? 8 : centres >= 8192 ? 4 : centres >= 2048 ? 2 : 1;
-  dim3 grid(cdiv(N, 4 * cpw), B);
-  hipLaunchKernelGGL(pe_group_mlp_max_bf16x3_kernel, grid, dim3(256), lds, (hipStream_t)stream, xyz, N, radius, nsample,
-                     cpw, (const uint4 *)image, cand_in, cand_cnt_in, cand_stride, cand_out, cand_cnt_out, (float *)out, out_ld, out_split);
+  dim3 grid(cdiv(N, PE_NW * cpw), B);
+  hipLaunchKernelGGL(pe_group_mlp_max_bf16x3_kernel, grid, dim3(PE_NW * 64), lds, (hipStream_t)stream, xyz, N, radius, nsample,
+                     cpw, (const uint4 *)image, cand_in, cand_cnt_in, cand_stride, cand_out, cand_cnt_out, (float *)out, out_ld, out_split, use_grid);
   return check_launch("pe_group_mlp_max_packed");
 }
 
