@@ -410,12 +410,18 @@ class _BNReLUTrain(torch.autograd.Function):
         return dx, dgamma, dbeta, None
 
 
+def _aligned16(x):
+    """16-byte aligned storage once contiguous (the streaming kernels move float4 / float2 per lane)."""
+    return (x.data_ptr() % 16 == 0) if x.is_contiguous() else True  # (_c() copies a non-contiguous view into a fresh, aligned buffer)
+
+
 def bn_relu(x, bn):
     """F.relu(bn(x)) for an nn.BatchNorm2d: the fused training form (csrc/bn_train.hip) when `bn` is in train mode on fp32 CUDA data
     with affine parameters, else the modules themselves (eval statistics, CPU, other dtypes)."""
     L = x[0, 0].numel() if x.dim() >= 3 else 0
-    if (USE_FUSED_BN_RELU and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and L % 4 == 0 and L >= 4
-            and bn.weight is not None and bn.bias is not None and x.shape[0] <= 65535 and x.shape[1] <= 65535):
+    if (USE_FUSED_BN_RELU and bn.training and type(bn) is torch.nn.BatchNorm2d and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3
+            and L % 4 == 0 and L >= 4 and bn.weight is not None and bn.bias is not None and x.shape[0] <= 65535 and x.shape[1] <= 65535
+            and _aligned16(x)):  # (exactly nn.BatchNorm2d: a SyncBatchNorm's statistics are not per rank; 16-byte loads)
         return _BNReLUTrain.apply(x, bn.weight, bn.bias, bn)
     return F.relu(bn(x))
 
@@ -465,8 +471,9 @@ class _BNReLUMaxPoolTrain(torch.autograd.Function):
 def bn_relu_maxpool(x, bn):
     """F.relu(bn(x)).max(dim=3)[0] for x (B, C, N, S): fused (csrc/bn_train.hip) when `bn` is in train mode on fp32 CUDA data with
     S in {32, 64, 128, 256}, else `bn_relu` followed by torch's max."""
-    if (USE_FUSED_BN_RELU and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[3] in (32, 64, 128, 256)
-            and bn.weight is not None and bn.bias is not None and x.shape[0] <= 65535 and x.shape[1] <= 65535):
+    if (USE_FUSED_BN_RELU and bn.training and type(bn) is torch.nn.BatchNorm2d and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and x.shape[3] in (32, 64, 128, 256) and bn.weight is not None and bn.bias is not None and x.shape[0] <= 65535
+            and x.shape[1] <= 65535 and _aligned16(x)):
         return _BNReLUMaxPoolTrain.apply(x, bn.weight, bn.bias, bn)[0]
     return bn_relu(x, bn).max(dim=3)[0]
 
@@ -527,7 +534,7 @@ def conv1x1(x, conv):
     L = x[0, 0].numel() if x.dim() >= 3 else 0
     if (TRAIN_OWN_CONV and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and conv.bias is None
             and w.shape[2:] == (1, 1) and x.dim() == 4 and L % 64 == 0 and 64 <= L < (1 << 28) and _conv1x1_pair_ok(cin, cout)
-            and (not x.requires_grad or _conv1x1_pair_ok(cout, cin)) and cout in (32, 64, 128)):
+            and (not x.requires_grad or _conv1x1_pair_ok(cout, cin)) and cout in (32, 64, 128) and _aligned16(x)):
         return _Conv1x1Fn.apply(x, w)
     return conv(x)
 
@@ -1879,8 +1886,8 @@ def scale_residual_layernorm_f32_(x, y, gamma, norm):
 def vit_f32_fused_ok(x, vit):
     """The no-autocast ViT on the fused fp32-class path (split-layout LayerNorm outputs feeding csrc/gemm_f32.hip directly)?"""
     C = x.shape[-1]
-    return (x.is_cuda and x.dtype == torch.float32 and not _DIFF and not torch.is_autocast_enabled() and USE_F32X3 and C % 32 == 0 and C <= 1024
-            and C % 64 == 0 and f32x3_ok(x.numel() // C, 3 * C, C) and f32x3_ok(x.numel() // C, C, 4 * C))
+    return (x.is_cuda and x.dtype == torch.float32 and not _DIFF and _no_autograd() and not torch.is_autocast_enabled() and USE_F32X3 and C % 32 == 0
+            and C <= 1024 and C % 64 == 0 and f32x3_ok(x.numel() // C, 3 * C, C) and f32x3_ok(x.numel() // C, C, 4 * C))
 
 
 def scale_residual_layernorm_(x, y, gamma, norm):
