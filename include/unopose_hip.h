@@ -249,6 +249,13 @@ int unopose_conv1x1_train_wgrad_blocks(void);
 int unopose_conv1x1_train_forward(const float *x, int B, int cin, long L, const float *w, int cout, float *y, unopose_stream_t stream);
 int unopose_conv1x1_train_wgrad(const float *dy, const float *x, int B, int cout, int cin, long L, float *workspace, float *dw,
                                 unopose_stream_t stream);
+
+/* Weight gradient of a trainable nn.Linear of the matcher (the `grad_output^T @ input` of torch.nn.functional.linear's backward):
+ * dw[n, k] = sum_r g[r, n] x[r, k], g (rows, N) and x (rows, K) float32 row-major, N and K multiples of 128; fp32 products and
+ * accumulation on v_mfma_f32_32x32x2_f32 over slices of the rows, slices combined in double (deterministic).
+ * workspace = unopose_linear_wgrad_f32_splits(rows, N, K) * N * K floats. */
+int unopose_linear_wgrad_f32_splits(long rows, int N, int K);
+int unopose_linear_wgrad_f32(const float *g, const float *x, long rows, int N, int K, float *workspace, float *dw, unopose_stream_t stream);
 int unopose_assign_labels(const float *atten, int B, int R, int C, const float *score1,
                           const float *score2, float *stats_ws, float *w1, float *w2,
                           unopose_stream_t stream);

@@ -190,6 +190,43 @@ def test_trainable_linear_on_own_gemm_matches_torch_autograd(amp, relu, monkeypa
         assert float((g.double() - w.double()).abs().max()) < tol * scale, (name, float((g.double() - w.double()).abs().max()), scale)
 
 
+@pytest.mark.parametrize("rows,N,K", [(20000, 256, 256), (16411, 128, 384), (65536, 512, 256), (513, 256, 128)])
+def test_own_linear_weight_gradient_matches_float64(rows, N, K, monkeypatch):
+    """csrc/conv_train.hip::linear_wgrad_f32_kernel (dW = dY^T X on the fp32 matrix instruction, row slices combined in double) against
+    float64: 2e-6 of the result's scale, odd row counts and a last row pair that is half empty included; then through `ops.linear`'s
+    backward (the path the training step takes for its large projections)."""
+    from unopose_amd import ops
+    from unopose_amd._lib import call, lib, ptr, stream_ptr
+
+    g = torch.Generator().manual_seed(rows + N)
+    gy = torch.randn(rows, N, generator=g).cuda()
+    x = torch.randn(rows, K, generator=g).cuda()
+    splits = lib().unopose_linear_wgrad_f32_splits(rows, N, K)
+    assert 1 <= splits <= 1024
+    ws = torch.empty(splits * N * K, device="cuda")
+    dw = torch.empty(N, K, device="cuda")
+    call("unopose_linear_wgrad_f32", ptr(gy), ptr(x), rows, N, K, ptr(ws), ptr(dw), stream_ptr())
+    want = gy.double().t() @ x.double()
+    assert float((dw.double() - want).abs().max()) < 2e-6 * float(want.abs().max())
+    if rows >= ops.TRAIN_OWN_WGRAD_MIN_ROWS and N % 256 == 0 and K % 256 == 0:  # (shapes the forward's own GEMM takes)
+        monkeypatch.setattr(ops, "TRAIN_OWN_GEMM_MIN_FLOP", 0.0)
+        lin = torch.nn.Linear(K, N).cuda()
+        xin = x.clone().requires_grad_(True)
+        with ops.differentiable():
+            y = ops.linear(xin, lin)
+        assert type(y.grad_fn).__name__ == "_LinearFnBackward"
+        y.backward(gy)
+        assert float((lin.weight.grad.double() - want).abs().max()) < 2e-6 * float(want.abs().max())
+        ops.TRAIN_OWN_WGRAD = False
+        try:
+            lin.weight.grad = None
+            with ops.differentiable():
+                ops.linear(xin, lin).backward(gy)
+        finally:
+            ops.TRAIN_OWN_WGRAD = True
+        assert float((lin.weight.grad.double() - want).abs().max()) < 1e-4 * float(want.abs().max())  # the library's fp32 GEMM (its own summation order)
+
+
 def test_fused_infonce_matches_cross_entropy_pair():
     """ops.infonce_two_way (csrc/posehead.hip statistics + one gradient pass) against the two F.cross_entropy calls of
     loss_utils.py:181-187 in float64: values and the gradient w.r.t. the similarity, ragged sizes, labels incl. background."""

@@ -64,6 +64,8 @@ SIGNATURES = {
     "unopose_conv1x1_train_wgrad_blocks": [],
     "unopose_conv1x1_train_forward": [_P, _I, _I, ctypes.c_long, _P, _I, _P, _P],
     "unopose_conv1x1_train_wgrad": [_P, _P, _I, _I, _I, ctypes.c_long, _P, _P, _P],
+    "unopose_linear_wgrad_f32_splits": [ctypes.c_long, _I, _I],
+    "unopose_linear_wgrad_f32": [_P, _P, ctypes.c_long, _I, _I, _P, _P, _P],
     "unopose_vit_attention": [_P, _I, _I, _I, _P, _P],
     "unopose_add_layernorm": [_P, _I, _P, _I, _P, _P, ctypes.c_long, _I, _F, _P, _I, _P],
     "unopose_add_layernorm_strided": [_P, _I, _P, _I, _P, _P, ctypes.c_long, _I, _F, _P, _I, ctypes.c_long, _P],

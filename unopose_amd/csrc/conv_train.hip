@@ -169,15 +169,87 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_kernel(const float *__re
   }
 }
 
-// dW[m][k] = sum over workgroups of part[wg][m][k] (double), k < cin
+// dW[m][k] = sum over workgroups of part[wg][m][k] (double), k < cin.  64 outputs per workgroup, the partials of an output split over
+// the four waves (wave q takes wg = q, q + 4, ...: four independent load streams per output instead of one chain of nwg dependent
+// loads), the four sums combined in a fixed order: deterministic.
 __global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float *__restrict__ part, int nwg, int CO, int CIP, int cin,
                                                                    float *__restrict__ dw) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= CO * cin) return;
-  const int m = e / cin, k = e - m * cin;
-  double s = 0.0;
-  for (int g = 0; g < nwg; ++g) s += (double)part[((size_t)g * CO + m) * CIP + k];
-  dw[e] = (float)s;
+  __shared__ double red[4][64];
+  const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + o;
+  const bool ok = e < CO * cin;
+  const int m = ok ? e / cin : 0, k = ok ? e - m * cin : 0;
+  const float *p = part + (size_t)m * CIP + k;
+  const size_t stride = (size_t)CO * CIP;
+  double s0 = 0.0, s1 = 0.0;
+  int g = q;
+  for (; g + 4 < nwg; g += 8) {
+    s0 += (double)p[(size_t)g * stride];
+    s1 += (double)p[(size_t)(g + 4) * stride];
+  }
+  if (g < nwg) s0 += (double)p[(size_t)g * stride];
+  red[q][o] = s0 + s1;
+  __syncthreads();
+  if (q == 0 && ok) dw[e] = (float)((red[0][o] + red[1][o]) + (red[2][o] + red[3][o]));
+}
+
+// ---------------------------------------------------------------------------------------------------------------- nn.Linear weight gradient
+// dW[n][k] = sum_r g[r][n] x[r][k] for row-major g (rows, N) and x (rows, K): the reduction runs along the ROWS and the channels are
+// contiguous, i.e. both operands of v_mfma_f32_32x32x2_f32 have their lanes along contiguous memory as they are (A: lane = column of g,
+// k-step = row; B: lane = column of x) -- no LDS, no transposes.  A workgroup owns a 128 x 128 tile of dW over one slice of the rows, a wave
+// 64 x 64 of it (even / odd columns from one 8-byte load per lane); per-slice partials, reduced in double by conv1x1_wgrad_reduce_kernel.
+__global__ __launch_bounds__(256, 2) void linear_wgrad_f32_kernel(const float *__restrict__ g, const float *__restrict__ x, long rows, int N, int K,
+                                                                  float *__restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 31, kh = lane >> 5;
+  const int tiles_k = K >> 7, tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+  const int n0 = tn * 128 + (wave >> 1) * 64, k0 = tk * 128 + (wave & 1) * 64;
+  long per = (rows + gridDim.y - 1) / gridDim.y;
+  per = (per + 1) & ~1L;
+  const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const float *gp = g + (size_t)(r0 + kh) * N + n0 + 2 * col, *xp = x + (size_t)(r0 + kh) * K + k0 + 2 * col;
+  long r = r0;
+#pragma unroll 1
+  for (; r + 16 <= r1; r += 16) {  // eight row pairs per trip: sixteen loads in flight
+    float2 a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = *reinterpret_cast<const float2 *>(gp + (size_t)(2 * u) * N);
+      b[u] = *reinterpret_cast<const float2 *>(xp + (size_t)(2 * u) * K);
+    }
+    gp += (size_t)16 * N, xp += (size_t)16 * K;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].y, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc[1][1], 0, 0, 0);
+    }
+  }
+  for (; r < r1; r += 2) {  // the last pairs; a row past the slice contributes zeros
+    float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
+    if (r + kh < r1) a = *reinterpret_cast<const float2 *>(gp), b = *reinterpret_cast<const float2 *>(xp);
+    gp += (size_t)2 * N, xp += (size_t)2 * K;
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+  }
+  // D[m][n]: m = the A lane's column of g (n0 + 2 m + i), n = the B lane's column of x (k0 + 2 col + j)
+  float *out = part + (size_t)blockIdx.y * N * K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int m = (rr & 3) + 8 * (rr >> 2) + 4 * kh;
+      *reinterpret_cast<float2 *>(out + (size_t)(n0 + 2 * m + i) * K + k0 + 2 * col) = make_float2(acc[i][0][rr], acc[i][1][rr]);
+    }
 }
 
 static int conv_grid(long units, int per_block) {
@@ -229,7 +301,7 @@ int unopose_conv1x1_train_wgrad(const float *dy, const float *x, int B, int cout
   if (cout == CO && cin <= CIP) {                                                                                                        \
     hipLaunchKernelGGL((conv1x1_wgrad_kernel<CO, CIP>), dim3(grid), dim3(256), 0, s, dy, x, cin, B, L, workspace);                        \
     if (check_launch("conv1x1_train_wgrad")) return UNOPOSE_ELAUNCH;                                                                     \
-    hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(cdiv(CO * cin, 256)), dim3(256), 0, s, (const float *)workspace, grid, CO, CIP, cin, dw); \
+    hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(cdiv(CO * cin, 64)), dim3(256), 0, s, (const float *)workspace, grid, CO, CIP, cin, dw); \
     return check_launch("conv1x1_train_wgrad_reduce");                                                                                   \
   }
   UNOPOSE_WGRAD_CASE(32, 32)
@@ -240,6 +312,25 @@ int unopose_conv1x1_train_wgrad(const float *dy, const float *x, int B, int cout
 #undef UNOPOSE_WGRAD_CASE
   UNOPOSE_REQUIRE(false, "conv1x1_train_wgrad: no kernel for %d x %d weights", cout, cin);
   return UNOPOSE_EINVAL;
+}
+
+int unopose_linear_wgrad_f32_splits(long rows, int N, int K) {  // row slices = workspace / (N * K) floats
+  const long tiles = (long)(N >> 7) * (K >> 7);
+  long sp = tiles > 0 ? (1024 + tiles - 1) / tiles : 1;  // about four workgroups per CU
+  const long cap = rows / 512 > 0 ? rows / 512 : 1;  // at least 512 rows per slice
+  return (int)(sp < cap ? (sp < 1 ? 1 : sp) : cap);
+}
+
+int unopose_linear_wgrad_f32(const float *g, const float *x, long rows, int N, int K, float *workspace, float *dw, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(g && x && workspace && dw, "linear_wgrad_f32: null pointer");
+  UNOPOSE_REQUIRE(rows >= 1 && N >= 128 && K >= 128 && N % 128 == 0 && K % 128 == 0 && (long)N * K < (1L << 31),
+                  "linear_wgrad_f32: features must be multiples of 128 (rows=%ld N=%d K=%d)", rows, N, K);
+  hipStream_t s = (hipStream_t)stream;
+  const int splits = unopose_linear_wgrad_f32_splits(rows, N, K);
+  hipLaunchKernelGGL(linear_wgrad_f32_kernel, dim3((N >> 7) * (K >> 7), splits), dim3(256), 0, s, g, x, rows, N, K, workspace);
+  if (check_launch("linear_wgrad_f32")) return UNOPOSE_ELAUNCH;
+  hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(cdiv(N * K, 64)), dim3(256), 0, s, (const float *)workspace, splits, N, K, K, dw);
+  return check_launch("linear_wgrad_f32_reduce");
 }
 
 }  // extern "C"

@@ -539,6 +539,8 @@ def conv1x1(x, conv):
     return conv(x)
 
 
+TRAIN_OWN_WGRAD = True  # A/B attribute: False = the linears' weight gradients through the library (dY^T @ X)
+TRAIN_OWN_WGRAD_MIN_ROWS = 16384
 TRAIN_OWN_GEMM = True  # A/B attribute: False = nn.Linear through the library
 # The persistent 256 x 256-tile kernels pay off from a few tens of GFLOP per launch (measured at the training shapes: a
 # 32 776 x 256 x 256 linear takes 38 us on csrc/gemm_f32.hip and 17 us on the library, the 4096 x 3072 x 4096 up-projection
@@ -606,7 +608,18 @@ class _LinearFn(torch.autograd.Function):
                 gx = g.to(lin.weight.dtype) @ lin.weight.detach()
             gx = gx.reshape(ctx.shape).to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:
-            gw = (g.t() @ x2.to(g.dtype)).to(lin.weight.dtype)
+            if (TRAIN_OWN_WGRAD and not ctx.bf16 and g.dtype == torch.float32 and x2.dtype == torch.float32 and g.is_cuda and N % 128 == 0
+                    and K % 128 == 0 and rows >= TRAIN_OWN_WGRAD_MIN_ROWS and _aligned16(g) and _aligned16(x2)):
+                # dW = dY^T X on csrc/conv_train.hip::linear_wgrad_f32_kernel (fp32 matrix instruction straight from the row-major operands)
+                gc = _c(g)
+                splits = lib().unopose_linear_wgrad_f32_splits(rows, N, K)
+                ws = torch.empty(splits * N * K, dtype=torch.float32, device=g.device)
+                gw = torch.empty(N, K, dtype=torch.float32, device=g.device)
+                with torch.cuda.device(g.device):
+                    call("unopose_linear_wgrad_f32", ptr(gc), ptr(x2), rows, N, K, ptr(ws), ptr(gw), stream_ptr())
+                gw = gw.to(lin.weight.dtype)
+            else:
+                gw = (g.t() @ x2.to(g.dtype)).to(lin.weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.float().sum(0).to(lin.bias.dtype)
         return gx, gw, gb, None, None, None
