@@ -239,6 +239,13 @@ int unopose_bn_relu_maxpool_train_backward(const float *x, const float *g, const
                                            const float *beta, const float *mean, const float *rstd, float *workspace, float *dgamma, float *dbeta,
                                            float *dx, unopose_stream_t stream);
 
+/* Training labels (core/unopose/utils/loss_utils.py:150-176): for clouds a (B, n, 3) and b (B, m, 3), float32, the nearest partner of
+ * every point of one cloud in the other and whether ANY partner lies within thr, without forming the (B, n, m) distance matrix.
+ * over_b != 0: for every a_i over j (outputs of length n); else for every b_j over i (length m).  Entry values follow the reference's
+ * expansion sqrt(max(|a_i|^2 - 2 a_i.b_j + |b_j|^2, 0)) in both directions; ties: the first index.  any_close is one byte per point. */
+int unopose_nearest_partner(const float *a, const float *b, int B, int n, int m, int over_b, float thr, float *dmin, int32_t *arg,
+                            uint8_t *any_close, unopose_stream_t stream);
+
 /* nn.Conv2d(cin, cout, 1, bias=False) of the same SharedMLP under autograd (pytorch_utils.py:25-132 in train()), on (B, C, L) float32
  * slabs with L = N * S a multiple of 64 (v_mfma_f32_32x32x2_f32: fp32 products and accumulation).
  *   forward:  y[b, m, l] = sum_k w[m, k] x[b, k, l], w (cout, cin) row-major.  The input gradient is the same call on the transposed

@@ -278,3 +278,30 @@ def test_small_fp32_glue_kernels_vs_torch():
     out = torch.empty(3, 256, device="cuda")
     call("unopose_token_sum_bf16", ptr(x), 3, 2049, 256, ptr(out), stream_ptr())
     assert (out.double() - x.double().sum(1)).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("B,n,m", [(2, 196, 196), (3, 1000, 1300), (2, 4096, 4096), (1, 5, 700)])
+def test_nearest_partner_labels_vs_distance_matrix(B, n, m):
+    """csrc/glue.hip::nearest_partner_kernel (training labels without the (B, n, m) matrix) vs the reference's formulation on the
+    matrix (loss_utils.py:150-176, as unopose_amd/losses.py evaluates it on the CPU): minimum distances to 1e-6, the any-close flags and
+    the arg mins identical except where the two smallest distances are within rounding of each other (the matrix product's summation
+    order is the library's)."""
+    from unopose_amd import ops
+    from unopose_amd.losses import _pairwise_sq_dist
+
+    g = torch.Generator().manual_seed(B * 7 + n)
+    a = (torch.rand(B, n, 3, generator=g) - 0.5).cuda()
+    b = (a[:, torch.randint(0, n, (m,), generator=g)] + 0.02 * torch.randn(B, m, 3, generator=g).cuda()).contiguous()
+    thr = 0.03
+    dist = torch.sqrt(_pairwise_sq_dist(a, b))  # fp32, the formulation the kernel restates (the expansion cancels: only its own rounding is comparable)
+    for over_b, dim in ((True, 2), (False, 1)):
+        d, idx, anyc = ops.nearest_partner(a, b, thr, over_b=over_b)
+        dr, ir = dist.min(dim)
+        # squared distances agree to the rounding of one product sum (the library's K = 3 dot product may associate differently)
+        assert float((d.double() ** 2 - dr.double() ** 2).abs().max()) < 3e-7
+        other = dist.gather(dim, idx.unsqueeze(dim)).squeeze(dim)  # the matrix's distance of the partner the kernel chose
+        assert float((other.double() ** 2 - dr.double() ** 2).max()) < 3e-7  # a different index only among (near-)ties
+        assert (idx == ir).float().mean().item() > 0.99
+        close = (dist <= thr).any(dim)
+        border = ((dr.double() ** 2 - thr ** 2).abs() < 1e-6)
+        assert torch.equal(anyc[~border], close[~border])

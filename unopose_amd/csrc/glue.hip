@@ -177,6 +177,51 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t *__rest
   }
 }
 
+// ---- nearest partner + "any partner within a radius" of every point of one cloud in the other (training labels, loss_utils.py:150-176:
+//      `dist = sqrt(pairwise_distance(a, b)); close = dist <= thr; dist.min(2) / dist.min(1)`): the (B, n, m) distance matrix is never
+//      formed (537 MB per tensor and ~15 elementwise / reduction passes at 4096 x 4096).  The value of an entry is computed exactly as the
+//      reference's expansion does, whichever index is reduced: d(i, j) = sqrt(max((|a_i|^2 - 2 a_i.b_j) + |b_j|^2, 0)) with the squares and
+//      the dot product summed left to right; `over_b` = reduce over j for every i (rows), else over i for every j (columns).  Ties: the
+//      first index.
+__global__ __launch_bounds__(256) void nearest_partner_kernel(const float *__restrict__ a, const float *__restrict__ b, int n, int m, int over_b,
+                                                              float thr, float *__restrict__ dmin, int32_t *__restrict__ arg,
+                                                              uint8_t *__restrict__ anyc) {
+  __shared__ float4 tile[256];  // (x, y, z, |.|^2) of 256 points of the reduced cloud
+  const int bb = blockIdx.y, nout = over_b ? n : m, nred = over_b ? m : n;
+  const float *own = (over_b ? a : b) + (size_t)bb * nout * 3, *oth = (over_b ? b : a) + (size_t)bb * nred * 3;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (o < nout) px = own[o * 3], py = own[o * 3 + 1], pz = own[o * 3 + 2];
+  const float pp = (px * px + py * py) + pz * pz;
+  float best = 3.4e38f;
+  int bi = 0;
+  bool any = false;
+  for (int t0 = 0; t0 < nred; t0 += 256) {
+    __syncthreads();
+    const int q = t0 + threadIdx.x;
+    if (q < nred) {
+      const float x = oth[q * 3], y = oth[q * 3 + 1], z = oth[q * 3 + 2];
+      tile[threadIdx.x] = make_float4(x, y, z, (x * x + y * y) + z * z);
+    }
+    __syncthreads();
+    const int cnt = min(256, nred - t0);
+    for (int u = 0; u < cnt; ++u) {
+      const float4 c = tile[u];
+      // a is the FIRST operand of the reference's expansion whichever side this thread's point is on
+      const float dotv = over_b ? (px * c.x + py * c.y) + pz * c.z : (c.x * px + c.y * py) + c.z * pz;
+      const float aa = over_b ? pp : c.w, bbq = over_b ? c.w : pp;
+      const float d = sqrtf(fmaxf((aa - 2.f * dotv) + bbq, 0.f));
+      any |= d <= thr;
+      if (d < best) best = d, bi = t0 + u;
+    }
+  }
+  if (o < nout) {
+    dmin[(size_t)bb * nout + o] = best;
+    arg[(size_t)bb * nout + o] = bi;
+    anyc[(size_t)bb * nout + o] = any ? 1 : 0;
+  }
+}
+
 }  // namespace unopose
 
 using namespace unopose;
@@ -422,6 +467,16 @@ int unopose_pose_score(const float *dis, const float *w, int B, int N, float thr
   if (B == 0) return UNOPOSE_OK;
   hipLaunchKernelGGL(pose_score_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dis, w, N, thr, out);
   return check_launch("pose_score");
+}
+
+int unopose_nearest_partner(const float *a, const float *b, int B, int n, int m, int over_b, float thr, float *dmin, int32_t *arg, uint8_t *any_close,
+                            unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(a && b && dmin && arg && any_close, "nearest_partner: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && B <= 65535 && n >= 1 && m >= 1, "nearest_partner: bad sizes (B=%d n=%d m=%d)", B, n, m);
+  if (B == 0) return UNOPOSE_OK;
+  hipLaunchKernelGGL(nearest_partner_kernel, dim3(cdiv(over_b ? n : m, 256), B), dim3(256), 0, (hipStream_t)stream, a, b, n, m, over_b, thr, dmin, arg,
+                     any_close);
+  return check_launch("nearest_partner");
 }
 
 }  // extern "C"

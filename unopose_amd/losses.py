@@ -11,6 +11,9 @@ import torch
 import torch.nn.functional as F
 
 
+FUSED_LABELS = True  # A/B attribute: False = the (B, n1, n2) distance matrix through torch on the GPU as well
+
+
 def _pairwise_sq_dist(x, y):
     """|x_i - y_j|^2 in the reference's expansion (model_utils.py:230-257) -- the thresholds below sit on these values."""
     xy = x @ y.transpose(-1, -2)
@@ -52,17 +55,27 @@ def overlap_losses(end_points, atten_list, score_list, saliency_list, pts1, pts2
 def _overlap_losses(end_points, atten_list, score_list, saliency_list, pts1, pts2, gt_R, gt_t, predator_thres, dis_thres, prefix):
     n1 = pts1.shape[1]
     in_ref = (pts1 - gt_t.unsqueeze(1)) @ gt_R  # query points expressed in the reference frame
-    dist = torch.sqrt(_pairwise_sq_dist(in_ref, pts2))  # (B, n1, n2)
-    close = dist <= predator_thres
-    overlap = torch.cat([close.any(2), close.any(1)], 1).to(score_list[0].dtype)  # a point overlaps if ANY partner is close
+    fused = in_ref.is_cuda and FUSED_LABELS
+    if fused:
+        # csrc/glue.hip: nearest partner and "any partner close" per point, both directions, without the (B, n1, n2) matrix
+        from . import ops
+
+        d1, nn1, any1 = ops.nearest_partner(in_ref, pts2, predator_thres, over_b=True)
+        d2, nn2, any2 = ops.nearest_partner(in_ref, pts2, predator_thres, over_b=False)
+        overlap = torch.cat([any1, any2], 1).to(score_list[0].dtype)
+    else:
+        dist = torch.sqrt(_pairwise_sq_dist(in_ref, pts2))  # (B, n1, n2)
+        close = dist <= predator_thres
+        overlap = torch.cat([close.any(2), close.any(1)], 1).to(score_list[0].dtype)  # a point overlaps if ANY partner is close
     for i, score in enumerate(score_list):
         end_points[f"{prefix}_score_loss{i}"] = weighted_bce(score.float(), overlap)
     for i, sal in enumerate(saliency_list):
         end_points[f"{prefix}_saliency_loss{i}"] = weighted_bce(sal.float(), overlap)
     # nearest partner as the class label, 0 = background (no partner within dis_thres)
-    d1, nn1 = dist.min(2)
+    if not fused:
+        d1, nn1 = dist.min(2)
+        d2, nn2 = dist.min(1)
     label1 = torch.where(d1 <= dis_thres, nn1 + 1, torch.zeros_like(nn1))
-    d2, nn2 = dist.min(1)
     label2 = torch.where(d2 <= dis_thres, nn2 + 1, torch.zeros_like(nn2))
     for i, atten in enumerate(atten_list):
         end_points[f"{prefix}_atten_loss{i}"] = _infonce(atten, label1, label2)

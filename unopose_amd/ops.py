@@ -478,6 +478,21 @@ def bn_relu_maxpool(x, bn):
     return bn_relu(x, bn).max(dim=3)[0]
 
 
+def nearest_partner(a, b, thr, over_b=True):
+    """(min distance, arg min, any partner within thr) of every point of `a` (B, n, 3) over the points of `b` (B, m, 3) -- or, with
+    over_b=False, of every point of b over a -- as the training labels need them (loss_utils.py:150-176), on csrc/glue.hip: one launch,
+    no (B, n, m) matrix.  No gradient (labels)."""
+    a, b = _c(a.detach().float()), _c(b.detach().float())
+    B, n, m = a.shape[0], a.shape[1], b.shape[1]
+    nout = n if over_b else m
+    d = torch.empty(B, nout, dtype=torch.float32, device=a.device)
+    idx = torch.empty(B, nout, dtype=torch.int32, device=a.device)
+    anyc = torch.empty(B, nout, dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device):
+        call("unopose_nearest_partner", ptr(a), ptr(b), B, n, m, int(over_b), float(thr), ptr(d), ptr(idx), ptr(anyc), stream_ptr())
+    return d, idx.long(), anyc.bool()
+
+
 TRAIN_OWN_CONV = True  # A/B attribute: False = nn.Conv2d (MIOpen) for the PE's 1 x 1 convolutions under train()
 _CONV_FWD_PAIRS = ((8, (32,)), (32, (32, 64)), (64, (32, 64, 128)), (128, (64, 128)))  # (cin up to, couts): csrc/conv_train.hip
 
