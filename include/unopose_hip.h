@@ -239,6 +239,18 @@ int unopose_bn_relu_maxpool_train_backward(const float *x, const float *g, const
                                            const float *beta, const float *mean, const float *rstd, float *workspace, float *dgamma, float *dbeta,
                                            float *dx, unopose_stream_t stream);
 
+/* Saliency of the matchers' training branch (oneref_predator_coarse_point_matching.py:68-76 / _fine_point_matching.py:91-99 under
+ * train()): with inner = atten[:, 1:, 1:] of the (B, n1 + 1, n2 + 1) float32 similarity,
+ *   m1 = softmax(inner, dim=2) @ s2   (B, n1),     m2 = softmax(inner^T, dim=2) @ s1   (B, n2),
+ * forward (row / column softmax statistics rmax, rsum (B, n1) and cmax, csum (B, n2) are returned for backward) and backward
+ * (d_atten (B, n1 + 1, n2 + 1) with zero first row / column, ds1 (B, n1), ds2 (B, n2) from the gradients g1, g2 of m1, m2).
+ * Nothing of the matrix's size is written forward; deterministic reductions. */
+int unopose_saliency_train_forward(const float *atten, const float *s1, const float *s2, int B, int n1, int n2, float *m1, float *m2, float *rmax,
+                                   float *rsum, float *cmax, float *csum, unopose_stream_t stream);
+int unopose_saliency_train_backward(const float *atten, const float *s1, const float *s2, const float *m1, const float *m2, const float *rmax,
+                                    const float *rsum, const float *cmax, const float *csum, const float *g1, const float *g2, int B, int n1, int n2,
+                                    float *d_atten, float *ds1, float *ds2, unopose_stream_t stream);
+
 /* Training labels (core/unopose/utils/loss_utils.py:150-176): for clouds a (B, n, 3) and b (B, m, 3), float32, the nearest partner of
  * every point of one cloud in the other and whether ANY partner lies within thr, without forming the (B, n, m) distance matrix.
  * over_b != 0: for every a_i over j (outputs of length n); else for every b_j over i (length m).  Entry values follow the reference's

@@ -227,6 +227,39 @@ def test_own_linear_weight_gradient_matches_float64(rows, N, K, monkeypatch):
         assert float((lin.weight.grad.double() - want).abs().max()) < 1e-4 * float(want.abs().max())  # the library's fp32 GEMM (its own summation order)
 
 
+@pytest.mark.parametrize("B,n1,n2", [(2, 196, 196), (3, 1000, 1300), (2, 4096, 4096), (2, 5, 300)])
+def test_fused_saliency_pair_matches_torch_autograd(B, n1, n2):
+    """csrc/saliency_train.hip (softmax(inner, 2) @ s2 and softmax(inner^T, 2) @ s1 for inner = atten[:, 1:, 1:], forward + backward)
+    against the reference's expression under torch autograd in float64: values and all three gradients to 2e-5 of their scale;
+    row 0 / column 0 of the similarity (the background class) receive exactly zero."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(B + n1 + n2)
+    atten = (6 * torch.randn(B, n1 + 1, n2 + 1, generator=g)).cuda().requires_grad_()
+    s1 = torch.randn(B, n1, 1, generator=g).cuda().requires_grad_()
+    s2 = torch.randn(B, n2, 1, generator=g).cuda().requires_grad_()
+    g1, g2 = torch.randn(B, n1, 1, generator=g).cuda(), torch.randn(B, n2, 1, generator=g).cuda()
+    m1, m2 = ops.saliency_pair(atten, s1, s2)
+    assert "SaliencyFn" in type(m1.grad_fn).__name__
+    torch.autograd.backward([m1, m2], [g1, g2])
+    ad, d1, d2 = (t.detach().double().requires_grad_() for t in (atten, s1, s2))
+    inner = ad[:, 1:, 1:]
+    r1 = torch.matmul(torch.softmax(inner, dim=2), d2)
+    r2 = torch.matmul(torch.softmax(inner.transpose(1, 2), dim=2), d1)
+    torch.autograd.backward([r1, r2], [g1.double(), g2.double()])
+    for name, got, want in (("m1", m1, r1), ("m2", m2, r2), ("d_atten", atten.grad, ad.grad), ("ds1", s1.grad, d1.grad), ("ds2", s2.grad, d2.grad)):
+        sc = float(want.detach().abs().max())
+        e = float((got.detach().double() - want.detach()).abs().max())
+        assert e < 2e-5 * sc + 1e-12, (name, e, sc)
+    assert float(atten.grad[:, 0].abs().max()) == 0.0 and float(atten.grad[:, :, 0].abs().max()) == 0.0
+    ops.TRAIN_FUSED_SALIENCY = False
+    try:
+        t1, t2 = ops.saliency_pair(atten.detach(), s1.detach(), s2.detach())
+    finally:
+        ops.TRAIN_FUSED_SALIENCY = True
+    assert float((t1 - m1.detach()).abs().max()) < 2e-5 * float(t1.abs().max())
+
+
 def test_fused_infonce_matches_cross_entropy_pair():
     """ops.infonce_two_way (csrc/posehead.hip statistics + one gradient pass) against the two F.cross_entropy calls of
     loss_utils.py:181-187 in float64: values and the gradient w.r.t. the similarity, ragged sizes, labels incl. background."""

@@ -62,6 +62,8 @@ SIGNATURES = {
     "unopose_bn_relu_maxpool_train_forward": [_P, _I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "unopose_bn_relu_maxpool_train_backward": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "unopose_nearest_partner": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
+    "unopose_saliency_train_forward": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "unopose_saliency_train_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "unopose_conv1x1_train_wgrad_blocks": [],
     "unopose_conv1x1_train_forward": [_P, _I, _I, ctypes.c_long, _P, _I, _P, _P],
     "unopose_conv1x1_train_wgrad": [_P, _P, _I, _I, _I, ctypes.c_long, _P, _P, _P],

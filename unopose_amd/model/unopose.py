@@ -35,9 +35,7 @@ def _block_outputs(out_proj, score_head, f1, f2, n1, temp):
     scores = score_head(torch.cat((f1, f2), dim=1))
     atten = ops.feature_similarity(ops.linear(f1, out_proj), ops.linear(f2, out_proj), temp)
     s1, s2 = scores[:, 1:(n1 + 1)], scores[:, (n1 + 2):]
-    inner = atten[:, 1:, 1:]
-    m1 = torch.matmul(F.softmax(inner, dim=2), s2)
-    m2 = torch.matmul(F.softmax(inner.transpose(1, 2), dim=2), s1)
+    m1, m2 = ops.saliency_pair(atten, s1, s2)  # softmax(atten[:, 1:, 1:]) @ s2 and its transposed twin (csrc/saliency_train.hip under train())
     score = torch.clamp(torch.sigmoid(torch.cat((s1, s2), dim=1).squeeze(-1)), min=0, max=1)
     saliency = torch.clamp(torch.sigmoid(torch.cat((m1, m2), dim=1).squeeze(-1)), min=0, max=1)
     return atten, score, saliency

@@ -478,6 +478,51 @@ def bn_relu_maxpool(x, bn):
     return bn_relu(x, bn).max(dim=3)[0]
 
 
+TRAIN_FUSED_SALIENCY = True  # A/B attribute: False = the two softmax + matmul pairs of the reference through torch
+
+
+class _SaliencyFn(torch.autograd.Function):
+    """(softmax(inner, 2) @ s2, softmax(inner^T, 2) @ s1) for inner = atten[:, 1:, 1:] (C:68-76 / Fi:91-99 under train()) on
+    csrc/saliency_train.hip: a row pass and a column pass forward (statistics + weighted sums, no softmax-sized tensor), a pass that writes
+    the similarity's gradient and a column pass backward."""
+
+    @staticmethod
+    def forward(ctx, atten, s1, s2):
+        B, n1, n2 = atten.shape[0], atten.shape[1] - 1, atten.shape[2] - 1
+        a, v1, v2 = _c(atten.float()), _c(s1.float().reshape(B, n1)), _c(s2.float().reshape(B, n2))
+        dev = a.device
+        m1, rmax, rsum = (torch.empty(B, n1, dtype=torch.float32, device=dev) for _ in range(3))
+        m2, cmax, csum = (torch.empty(B, n2, dtype=torch.float32, device=dev) for _ in range(3))
+        with torch.cuda.device(dev):
+            call("unopose_saliency_train_forward", ptr(a), ptr(v1), ptr(v2), B, n1, n2, ptr(m1), ptr(m2), ptr(rmax), ptr(rsum), ptr(cmax), ptr(csum),
+                 stream_ptr())
+        ctx.save_for_backward(a, v1, v2, m1, m2, rmax, rsum, cmax, csum)
+        ctx.meta = (atten.dtype, s1.dtype, s2.dtype, s1.shape, s2.shape)
+        return m1.reshape(s1.shape).to(s1.dtype), m2.reshape(s2.shape).to(s2.dtype)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        a, v1, v2, m1, m2, rmax, rsum, cmax, csum = ctx.saved_tensors
+        B, n1, n2 = a.shape[0], a.shape[1] - 1, a.shape[2] - 1
+        g1, g2 = _c(g1.float().reshape(B, n1)), _c(g2.float().reshape(B, n2))
+        da = torch.empty_like(a)
+        ds1, ds2 = torch.empty_like(v1), torch.empty_like(v2)
+        with torch.cuda.device(a.device):
+            call("unopose_saliency_train_backward", ptr(a), ptr(v1), ptr(v2), ptr(m1), ptr(m2), ptr(rmax), ptr(rsum), ptr(cmax), ptr(csum), ptr(g1),
+                 ptr(g2), B, n1, n2, ptr(da), ptr(ds1), ptr(ds2), stream_ptr())
+        ad, d1, d2, sh1, sh2 = ctx.meta
+        return da.to(ad), ds1.reshape(sh1).to(d1), ds2.reshape(sh2).to(d2)
+
+
+def saliency_pair(atten, s1, s2):
+    """m1 = softmax(atten[:, 1:, 1:], dim=2) @ s2 and m2 = softmax(atten[:, 1:, 1:].transpose(1, 2), dim=2) @ s1 (s1 (B, n1, 1),
+    s2 (B, n2, 1)): fused with its backward on fp32 CUDA data, the reference's expression otherwise."""
+    if TRAIN_FUSED_SALIENCY and atten.is_cuda and atten.dtype == torch.float32 and s1.shape[-1] == 1 and s2.shape[-1] == 1 and atten.dim() == 3:
+        return _SaliencyFn.apply(atten, s1, s2)
+    inner = atten[:, 1:, 1:]
+    return torch.matmul(F.softmax(inner, dim=2), s2), torch.matmul(F.softmax(inner.transpose(1, 2), dim=2), s1)
+
+
 def nearest_partner(a, b, thr, over_b=True):
     """(min distance, arg min, any partner within thr) of every point of `a` (B, n, 3) over the points of `b` (B, m, 3) -- or, with
     over_b=False, of every point of b over a -- as the training labels need them (loss_utils.py:150-176), on csrc/glue.hip: one launch,
