@@ -23,11 +23,13 @@ __global__ __launch_bounds__(256) void saliency_rows_kernel(const float *__restr
   const float *row = atten + ((size_t)b * (n1 + 1) + i + 1) * (n2 + 1) + 1;
   const float *sv = s2 + (size_t)b * n2;
   float mx = -3.4e38f;
+#pragma unroll 8
   for (int j = lane; j < n2; j += 64) mx = fmaxf(mx, row[j]);
   mx = wave_max_f32(mx);
   float z = 0.f, acc = 0.f;
+#pragma unroll 8
   for (int j = lane; j < n2; j += 64) {
-    const float e = expf(row[j] - mx);
+    const float e = __expf(row[j] - mx);
     z += e;
     acc += e * sv[j];
   }
@@ -53,19 +55,21 @@ __global__ __launch_bounds__(256) void saliency_cols_kernel(const float *__restr
   float m = -3.4e38f, l = 0.f, acc = 0.f;
   if (BWD) {
     const float *rm = rmax + (size_t)b * n1, *rs = rsum + (size_t)b * n1;
-    for (int i = ph; i < n1; i += 4) acc += vv[i] * (expf(col[(size_t)i * (n2 + 1)] - rm[i]) / rs[i]);
+#pragma unroll 8
+    for (int i = ph; i < n1; i += 4) acc += vv[i] * (__expf(col[(size_t)i * (n2 + 1)] - rm[i]) / rs[i]);
     sa[ph][c] = acc;
     __syncthreads();
     if (ph == 0 && ok) out[(size_t)b * n2 + j] = (sa[0][c] + sa[1][c]) + (sa[2][c] + sa[3][c]);
     return;
   }
+#pragma unroll 8
   for (int i = ph; i < n1; i += 4) {
     const float a = col[(size_t)i * (n2 + 1)];
     if (a > m) {
-      const float r = expf(m - a);
+      const float r = __expf(m - a);
       l *= r, acc *= r, m = a;
     }
-    const float e = expf(a - m);
+    const float e = __expf(a - m);
     l += e;
     acc += e * vv[i];
   }
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void saliency_cols_kernel(const float *__restr
     float M = fmaxf(fmaxf(sm[0][c], sm[1][c]), fmaxf(sm[2][c], sm[3][c])), L = 0.f, A = 0.f;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const float r = expf(sm[p][c] - M);
+      const float r = __expf(sm[p][c] - M);
       L += sl[p][c] * r;
       A += sa[p][c] * r;
     }
@@ -105,9 +109,10 @@ __global__ __launch_bounds__(256) void saliency_bwd_rows_kernel(const float *__r
   const float R = rmax[bi], iz = 1.f / rsum[bi], mm1 = m1[bi], s1i = s1[bi], g1i = g1[bi];
   float acc = 0.f;
   if (lane == 0) drow[0] = 0.f;
+#pragma unroll 4
   for (int j = lane; j < n2; j += 64) {
     const float a = row[j];
-    const float p = expf(a - R) * iz, q = expf(a - cmax[b2 + j]) / csum[b2 + j];
+    const float p = __expf(a - R) * iz, q = __expf(a - cmax[b2 + j]) / csum[b2 + j];
     const float gq = g2[b2 + j] * q;
     drow[1 + j] = g1i * p * (s2[b2 + j] - mm1) + gq * (s1i - m2[b2 + j]);
     acc += gq;
