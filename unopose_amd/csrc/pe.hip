@@ -22,7 +22,7 @@
 #define PE_GRID 1  // uniform grid for the bf16x3 kernel's ball query (A/B: -DPE_GRID=0 = the index-order scan over the whole cloud)
 #endif
 #ifndef PE_ABL
-#define PE_ABL 0  // timing probes (scripts/ubench/pe_ab.py; wrong results): 1 no MLP tiles, 2 no frame (eigen-solver, sign vote, x axis), 3 ball query over 64 points only
+#define PE_ABL 0  // timing probes (scripts/ubench/pe_ab.py; wrong results): 1 no MLP tiles, 2 no frame (eigen-solver, sign vote, x axis), 3 ball query over 64 points only, 4 no eigen-solver
 #endif
 
 namespace unopose {
@@ -179,7 +179,10 @@ __device__ __forceinline__ int pe_centre_frame(const float *sx, const float *sy,
   a11 = wave_sum_f32(a11) * inv_s; a12 = wave_sum_f32(a12) * inv_s; a22 = wave_sum_f32(a22) * inv_s;
   Vec3 e0, e1, z0;
   float l0, l1, l2;
-  eig_sym3(a00, a01, a02, a11, a12, a22, e0, e1, z0, l0, l1, l2);
+  if (PE_ABL == 4)  // (timing probe: no eigen-solver)
+    z0 = v3(a00 + 1e-3f, a01, a02), z0 = scale(z0, __builtin_amdgcn_rsqf(dot(z0, z0)));
+  else
+    eig_sym3(a00, a01, a02, a11, a12, a22, e0, e1, z0, l0, l1, l2);
   int vote = 0;
   for (int l0i = 0; l0i < S; l0i += 64) {
     const int l = l0i + lane;
