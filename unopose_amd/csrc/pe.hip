@@ -812,7 +812,7 @@ int unopose_pe_group_mlp_max_packed_out(const float *xyz, int B, int N, float ra
   size_t lds = sizeof(PeLdsB) + ((size_t)3 * N + PE_NW * 128) * 4 + (size_t)PE_NW * nsample * 2;
   UNOPOSE_REQUIRE(N < 65536 && lds <= 160 * 1024, "pe_group_mlp_max_packed: N=%d nsample=%d exceed the LDS tile", N, nsample);
   const size_t grid_bytes = ((size_t)PE_GCELLS + 2 + (size_t)N) * 2;
-  const int use_grid = PE_GRID && N <= 4096 && N >= 256 && lds + grid_bytes <= 160 * 1024 && (lds + grid_bytes <= 80 * 1024 || lds > 80 * 1024);
+  const int use_grid = PE_GRID && radius > 0.f && N <= 4096 && N >= 256 && lds + grid_bytes <= 160 * 1024 && (lds + grid_bytes <= 80 * 1024 || lds > 80 * 1024);
   if (use_grid) lds += grid_bytes;
   lds = (lds + 15) & ~(size_t)15;
   static bool opt[64];
