@@ -260,6 +260,39 @@ def test_geo_embedding_table_kernel_vs_matrix_core_kernel(model, n, scale, mean)
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("kind", ["unit", "wide", "clumped", "flat", "identical", "n256", "n4096"])
+def test_pe_grid_ball_query_lists_equal_the_index_order_scan(model, kind):
+    """The fused PE kernel's ball query (uniform grid + bit map, csrc/pe.hip) hands out the SAME neighbour lists as the reference-order scan
+    of `unopose_ball_query` (pointnet2.hip: the first nsample hits by index, padded with the first): clouds of unit extent, clouds
+    much wider than 8 cells of the radius (enlarged cells), a clump that puts hundreds of points into one cell (lists overflow nsample),
+    a degenerate flat cloud (one cell along z), all points identical, and the smallest / largest point counts the grid takes."""
+    from unopose_amd import ops
+    from unopose_amd.pointnet2 import _ext
+
+    g = torch.Generator().manual_seed(len(kind))
+    N = {"n256": 256, "n4096": 4096}.get(kind, 2048)
+    x = torch.rand(2, N, 3, generator=g) * 2 - 1
+    if kind == "wide":
+        x = x * 7.0
+    elif kind == "clumped":
+        x[:, : N // 2] = x[:, : N // 2] * 0.05 + 0.3
+    elif kind == "flat":
+        x[:, :, 2] = 0.25
+    elif kind == "identical":
+        x[:] = 0.125
+    x = x.cuda().contiguous()
+    mlp = model.fine_point_matching.PE.mlp2
+    for r, S in ((0.2, 256), (0.1, 64)):
+        _, (lists, cnt) = ops.pe_group_mlp_max(x, r, S, mlp, bf16x3=True, want_cand=True)
+        ref = _ext.ball_query(x, x, r, S)
+        assert torch.equal(lists, ref), (kind, r, S, int((lists != ref).sum()))
+        d = torch.cdist(x.double(), x.double())
+        true_cnt = (d < r).sum(2)
+        full = cnt >= 0
+        assert torch.equal(cnt[full].long(), true_cnt[full]) and bool((true_cnt[~full] > S).all())
+
+
+@torch.no_grad()
 @pytest.mark.parametrize("r,ns", [(0.1, 64), (0.2, 256), (0.3, 32)])
 def test_fused_pe_kernel_vs_unfused(model, r, ns):
     """Fused ball-query+LRF+MLP+max kernel (fp32 MFMA) vs the materialised path (same HIP grouping
