@@ -112,7 +112,13 @@ static int g_use_4w = GEMM_4W;
 static int linear_bf16_dispatch(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, long M, int N, int K,
                                 int epilogue, hipStream_t s, const char *what) {
   const int tiles_n = N / GEMM_BN;
+#ifdef GEMM_PROBE_SKIP_TAIL  // timing probe (WRONG results): the tiles past the last whole round of the CUs are not computed -- what a perfect
+                             // split of the tail could gain in the pipelined step (scripts/build_variant.py notail -DGEMM_PROBE_SKIP_TAIL)
+  const int tiles_all = cdiv(M, GEMM_BM) * tiles_n, ncu_p = gemm_cu_count();
+  const int tiles = (tiles_all > ncu_p && tiles_all % ncu_p <= ncu_p / 8) ? tiles_all - tiles_all % ncu_p : tiles_all;
+#else
   const int tiles = cdiv(M, GEMM_BM) * tiles_n;
+#endif
   if (g_use_4w == 2 && gemm4w_ok(M, N, K, lda, ldw, ldc, epilogue)) {  // (forced: tests drive small tile counts through the stream as well)
     if (int *const sched4 = gemm_sched_slot(s)) {
       gemm4w_linear(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, use_nt_store(M, N), sched4, s);
