@@ -51,6 +51,7 @@ def parse(argv=None):
                          "0.027 pairs/s -- profiles/r03_bench_n1_bf16_s518_first_with_all_cores.json holds that run)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the extra fp32 (reference default precision) leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the bounded extra legs (`ref_cached`, `contract_224`, `train`)")
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (BASELINE configs[3]: --batch 8 pairs per rank, --train-pts 4096 points per cloud, "
                          "224x224 crops, frozen backbone, Adam; N > 1: DistributedDataParallel, gradient all-reduce over RCCL).  A step = "
@@ -322,9 +323,9 @@ def _cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline_leg(img, batches=(1, 8), timed=2, all_cores=False):
-    # (bounded: B = 1 gets one warm-up + `timed` forwards; larger batches run ONE timed forward with no warm-up of their own -- the code paths
-    #  and the allocator are warm by then -- so that the leg is ~35 s of a default run instead of ~95 s)
+def cpu_baseline_leg(img, batches=(1, 4), timed=2, all_cores=False):
+    # (bounded to ~35 s of a default run: B = 1 gets one warm-up + `timed` forwards, the larger batch one warm-up + ONE timed forward --
+    #  every number that can become `value` is a warmed one, first-touch allocations of a new batch size are not in it)
     """The oracle (torch-CPU port of the reference forward + the C `_ext` port; kind "port": the reference's
     Python cannot travel) timed on this host's cores on a bounded sample of the same workload
     (SURVEY.md 8(d)): per batch size one warm-up forward, then `timed` timed forwards; value = the best
@@ -359,17 +360,140 @@ def cpu_baseline_leg(img, batches=(1, 8), timed=2, all_cores=False):
         med = times[len(times) // 2]
         return dict(pairs_per_s=b / med, median_s=med, min_s=times[0], max_s=times[-1], timed=n_timed, warmup=warm)
 
-    by_batch = {str(b): (run(b, threads, timed) if b == min(batches) else run(b, threads, 1, warm=0)) for b in sorted(batches)}
+    by_batch = {str(b): run(b, threads, timed if b == min(batches) else 1) for b in sorted(batches)}
     best = max(by_batch.values(), key=lambda r: r["pairs_per_s"])
     out = dict(value=best["pairs_per_s"], unit="pairs/s", cores=threads, host_cores=host, kind="port",
                cpu_model=_cpu_model_name(), by_batch=by_batch,
                sample=f"batches of {list(batches)} pairs (2048 query / 5000 reference points, {img}x{img} crops): B={min(batches)} 1 warm-up + "
-                      f"{timed} timed forwards, larger batches one timed forward; fp32, torch {threads} threads + C `_ext` port; value = best rate")
+                      f"{timed} timed forwards, larger batches 1 warm-up + 1 timed forward; fp32, torch {threads} threads + C `_ext` port; value = best rate")
     if all_cores and host > threads:
         b = max(batches)
         r = run(b, host, 1)
         out["all_cores"] = dict(threads=host, batch=b, **r)
     return out
+
+
+def _timed_steps(pipe, make_inputs, steps, warm, sync):
+    """`warm` untimed + `steps` timed submits through a PipelinedForward, bracketed by synchronisations; -> (seconds, last output)."""
+    for _ in range(warm):
+        get = pipe.submit(make_inputs()).result
+    pipe.drain()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        get = pipe.submit(make_inputs()).result
+    out = get()
+    pipe.drain()
+    sync()
+    return time.perf_counter() - t0, out
+
+
+def contract_224_leg(dev, sync, steps=20, warm=3):
+    """The reference's OWN test contract (configs/main_cfg.py:87-92,130-131 + save_unopose.sh): 224 x 224 crops, instance batch 16,
+    2048 query / 5000 -> 2048 reference points, fp32 (`test.amp.enabled=False`, the default) and bf16 autocast.  A step is one
+    forward over one instance batch, inputs resident; bounded (~1 s)."""
+    import torch
+
+    from unopose_amd.model import UNOPose, default_model_cfg
+    from unopose_amd.pipeline import PipelinedForward
+    from unopose_amd.synthetic import make_batch, trained_like_
+
+    B = 16
+    model = trained_like_(UNOPose(default_model_cfg(feature_extraction=dict(img_size=224)))).to(dev).eval()
+    batch, R_gt, _ = make_batch(B, 2048, 5000, 224, seed=700, device=dev)
+    batch["coarse_rand"] = torch.rand(B, 18000, device=dev)
+    out = {"workload": "UNOPose.forward at the reference's test contract: instance batch 16, 224x224 crops, 2048 query pts, 5000->2048 "
+                       "reference pts (configs/main_cfg.py:87-92,130-131)", "batch": B, "steps": steps, "warmup": warm}
+    for name, amp, depth in (("fp32", None, 1), ("bf16", torch.bfloat16, 2)):
+        pipe = PipelinedForward(model, depth=depth, autocast_dtype=amp)
+        dt, o = _timed_steps(pipe, lambda: dict(batch), steps, warm, sync)
+        pipe.close()
+        err = (o["pred_R"] - R_gt).abs().amax(dim=(1, 2))
+        out[name] = {"value": B * steps / dt, "unit": "pairs/s", "ms_per_step": dt / steps * 1e3, "forwards_in_flight": pipe.depth,
+                     "median_rot_err_vs_gt": err.median().item()}
+    del model, batch
+    torch.cuda.empty_cache()
+    return out
+
+
+def ref_cached_leg(model, args, dev, sync, steps=20, warm=3, per_ref=8):
+    """The step with the reference side served by `runner.ReferenceCache` (the reference's precomputed
+    `dense_po` / `dense_fo` shortcut, oneref_feature_extraction.py:252-263): one reference view per `per_ref` queries, the views
+    encoded once before the timed region (`UNOPose.encode_reference` through the pipeline), every timed step = cache lookup (hits) +
+    forward over B pairs whose ViT sees the B query crops only.  Same model, batch size and crop side as the headline."""
+    import torch
+
+    from unopose_amd.pipeline import PipelinedForward
+    from unopose_amd.runner import ReferenceCache
+    from unopose_amd.synthetic import make_shared_reference_batch
+
+    B = args.batch
+    batch, keys, R_gt, _ = make_shared_reference_batch(B, per_ref, 2048, 5000, args.img, seed=800, device=dev)
+    batch["coarse_rand"] = torch.rand(B, 18000, device=dev)
+    pipe = PipelinedForward(model, depth=args.inflight, autocast_dtype=torch.bfloat16)
+    cache = ReferenceCache(model)
+    t0 = time.perf_counter()
+    cache.lookup(keys, batch["tem1_rgb"], batch["tem1_choose"], batch["tem1_pts"], pipe.encode_reference)
+    sync()
+    encode_ms = (time.perf_counter() - t0) * 1e3
+    query_side = {k: batch[k] for k in ("pts", "rgb", "rgb_choose", "coarse_rand")}
+
+    def inputs():
+        ep = dict(query_side)
+        ep.update(cache.lookup(keys, batch["tem1_rgb"], batch["tem1_choose"], batch["tem1_pts"], pipe.encode_reference))
+        return ep
+
+    dt, o = _timed_steps(pipe, inputs, steps, warm, sync)
+    pipe.close()
+    err = (o["pred_R"] - R_gt).abs().amax(dim=(1, 2))
+    return {"value": B * steps / dt, "unit": "pairs/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warm, "dtype": "bf16",
+            "queries_per_reference": per_ref, "distinct_references": len(set(keys)), "cache_hits": cache.hits, "cache_misses": cache.misses,
+            "encode_references_ms_once": encode_ms, "forwards_in_flight": pipe.depth,
+            "median_rot_err_vs_gt": err.median().item(), "frac_pairs_solved(<0.05)": (err < 0.05).float().mean().item(),
+            "workload": f"UNOPose.forward, batch {B}, {args.img}x{args.img} crops, reference features from runner.ReferenceCache "
+                        f"(one view per {per_ref} queries; lookup inside the timed step, encoding outside)"}
+
+
+def train_leg(dev, sync, steps=3, warm=2):
+    """The training step of BASELINE configs[3] on ONE GPU, bounded (2 warm-up + 3 steps): 8 pairs, 4096 points per cloud, 224 x 224
+    crops, frozen backbone, fp32, Adam -- forward in train mode + process_loss + backward + gradient hygiene + optimiser step
+    (`bench.py --train` is the full-length form and the N > 1 DDP form)."""
+    import torch
+
+    from unopose_amd.model import UNOPose, default_model_cfg
+    from unopose_amd.synthetic import make_train_batch, trained_like_
+    from unopose_amd.train import build_optimizer, freeze_backbone, train_step
+
+    B, npts, img = 8, 4096, 224
+    nt = npts + npts // 2
+    rng = torch.get_rng_state(), torch.cuda.get_rng_state(dev)
+    torch.manual_seed(0)
+    with torch.enable_grad():
+        model = freeze_backbone(trained_like_(UNOPose(default_model_cfg(fine_npoint=npts, feature_extraction=dict(img_size=img)))).to(dev))
+        batch = make_train_batch(B, npts, nt, img, seed=300, device=dev)
+        opt, sched = build_optimizer(model, lr=1e-4, total_iters=188340)
+        losses = []
+        for _ in range(warm):
+            losses.append(float(train_step(model, batch, opt, sched)["loss"]))
+        sync()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for a, b in evs:
+            a.record()
+            losses.append(float(train_step(model, batch, opt, sched)["loss"]))
+            b.record()
+        sync()
+        dt = time.perf_counter() - t0
+    per = sorted(a.elapsed_time(b) for a, b in evs)
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    del model, batch, opt, sched
+    torch.cuda.empty_cache()
+    torch.set_rng_state(rng[0])
+    torch.cuda.set_rng_state(rng[1], dev)
+    return {"value": B * steps / dt, "unit": "pairs/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warm, "dtype": "fp32",
+            "step_ms_hip_events": {"median": per[len(per) // 2], "min": per[0], "max": per[-1]}, "loss_first_last": [losses[0], losses[-1]],
+            "workload": f"UNOPose training step (BASELINE configs[3], one rank): {B} pairs, {npts} query pts, {nt}->{npts} reference pts, "
+                        f"{img}x{img} crops, frozen DINOv2 ViT-B/14, {n_train / 1e6:.1f} M trainable parameters, Adam"}
 
 
 def train_main(args, world, rank, dev, sync):
@@ -679,6 +803,17 @@ def main():
                                          "frames, Procrustes, assignment statistics) and the small contractions of bmm_f32 in exact fp32; the "
                                          "geometric embedding's two projections of sinusoids by 6-point Lagrange interpolation (fp32 arithmetic) on "
                                          "fp32 tables of the projected functions (interpolation error ~1e-6 of the weights' scale)"}
+        if not args.no_extra and graphed is None and amp:
+            if pipe is not None:
+                pipe.close()
+            # bounded, driver-visible legs at the reference's own contract (each ~1-2 s): see the three functions
+            res["ref_cached"] = ref_cached_leg(model, args, dev, sync)
+            log("ref_cached leg done")
+            res["contract_224"] = contract_224_leg(dev, sync)
+            log("contract_224 leg done")
+            res["train"] = train_leg(dev, sync)
+            torch.set_grad_enabled(False)
+            log("train leg done")
         if not args.no_roofline:
             res.update(roofline_leg(model, batch, args.img))
             log("roofline leg done")

@@ -15,7 +15,7 @@ for img in 518 224; do
   for fl in 2 1; do
     sfx=$([ $fl = 1 ] && echo _isolated || echo "")
     rm -rf /tmp/ks
-    rocprofv3 --kernel-trace --stats -d /tmp/ks -o ks -- python3 $R/bench.py --img $img --steps 6 --warmup 2 --inflight $fl --no-cpu-baseline --no-roofline --no-fp32 > $R/gpurun_out/${TAG}_bench_under_rocprof${sfx}_s$img.json 2>/dev/null
+    rocprofv3 --kernel-trace --stats -d /tmp/ks -o ks -- python3 $R/bench.py --img $img --steps 6 --warmup 2 --inflight $fl --no-cpu-baseline --no-roofline --no-fp32 --no-extra > $R/gpurun_out/${TAG}_bench_under_rocprof${sfx}_s$img.json 2>/dev/null
     python3 $R/scripts/rocpd_stats.py $(find /tmp/ks -name "*.db" | head -1) 60 > $R/gpurun_out/${TAG}_kernel_stats${sfx}_b32_s$img.csv
   done
 done

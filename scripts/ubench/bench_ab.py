@@ -13,7 +13,7 @@ rest = sys.argv[2:]
 for rep in range(2):
     for val in (False, True):
         setattr(ops, name, val)
-        sys.argv = ["bench.py", "--no-cpu-baseline", "--no-fp32", "--no-roofline", "--steps", "30"] + rest
+        sys.argv = ["bench.py", "--no-cpu-baseline", "--no-fp32", "--no-extra", "--no-roofline", "--steps", "30"] + rest
         buf = io.StringIO()
         with redirect_stdout(buf):
             bench.main()

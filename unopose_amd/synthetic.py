@@ -53,6 +53,32 @@ def make_batch(B, nq=2048, nt=5000, S=224, seed=0, noise=5e-4, device="cpu"):
     return out, torch.stack(Rs).to(device), torch.stack(ts).to(device)
 
 
+def make_shared_reference_batch(B, per_ref=8, nq=2048, nt=5000, S=224, seed=0, noise=5e-4, device="cpu"):
+    """B pairs in groups of `per_ref` queries that look at the SAME reference view (the BOP one-reference test set pairs
+    many query instances with few reference views: oneref_feature_extraction.py:252-263) -- every group is one
+    ellipsoid + one reference pose, each of its queries an own pose and an own subset of the surface points.
+    Returns (end_points, ref_keys (one hashable per pair), R_gt, t_gt)."""
+    gen = torch.Generator().manual_seed(seed)
+    eps, Rs, ts, keys = [], [], [], []
+    for b in range(B):
+        if b % per_ref == 0:
+            ep0, _, _ = congruent_pair(gen, nq, nt, S, noise)
+        # a fresh query of the same object: re-pose the reference cloud (noise-free surface = R_r^T (r - t_r) up to its noise)
+        Rq = random_rotation(gen, 25.0)
+        tq = torch.tensor([0.02, -0.03, 0.8]) + 0.05 * torch.randn(3, generator=gen)
+        sel = torch.randperm(nt, generator=gen)[:nq]
+        r = ep0["tem1_pts"][0]
+        c = r.mean(0)
+        q = (r[sel] - c) @ Rq.T + tq + noise * torch.randn(nq, 3, generator=gen)  # p_q = Rq (p_r - c) + tq
+        ep = dict(ep0, pts=q[None].contiguous(), rgb_choose=ep0["tem1_choose"][:, sel].contiguous())
+        eps.append(ep)
+        Rs.append(Rq)
+        ts.append(tq - Rq @ c)
+        keys.append(("view", seed, b // per_ref))
+    out = {k: torch.cat([e[k] for e in eps], 0).to(device) for k in eps[0]}
+    return out, keys, torch.stack(Rs).to(device), torch.stack(ts).to(device)
+
+
 def make_train_batch(B, nq=2048, nt=5000, S=224, seed=0, noise=5e-4, device="cpu"):
     """`make_batch` + the two labels a training item carries (`rotation_label` (B,3,3), `translation_label` (B,3):
     pfoneref_training_dataset_v2.py:560-590); the pose noise of the coarse stage is drawn inside the forward."""
