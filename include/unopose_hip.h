@@ -503,6 +503,23 @@ int unopose_gemm_bf16_tile(void);
  * order; GELU is evaluated on the bf16-rounded pre-activation by the four-wave kernel, on the fp32 accumulator by the 8-wave one. */
 int unopose_gemm4w_enable(int on);
 
+/* The residual + LayerNorm passes of a timm Block (x + ls(f(norm(x))), oneref_feature_extraction.py:24-42) folded into the GEMMs
+ * around them (bf16 autocast forward).
+ * _residual (proj / fc2, LayerScale folded into W and bias by the caller):  xres (M,N) fp32 += A (M,K) . W (N,K)^T + bias, in place;
+ *     xb (M,N) bf16 = the updated rows; stats[(row * N/256 + t) * 2 + {0,1}] = (sum, sum of squares) of the row's columns 256 t .. 256 t + 255
+ *     (stats holds ceil(M/256)*256 rows: whole tiles are written).
+ * _lnfold (qkv / fc1 reading those un-normalised rows against W' = ln_weight (.) W):
+ *     C (M,N) bf16 = act( rstd_r (A W'^T - mean_r cvec) + dvec ),  cvec[n] = sum_k W'[n][k],  dvec[n] = sum_k ln_bias[k] W[n][k] + b[n],
+ *     mean_r / rstd_r from the `nparts` partial sums of row r (LayerNorm over the K columns, eps), gelu = 1: erf-class GELU.
+ * Both need N % 256 == 0 and K % 64 == 0. */
+int unopose_linear_bf16_residual(const void *A, const void *W, const float *bias, float *xres, void *xb, float *stats, long M, int N, int K,
+                                 unopose_stream_t stream);
+int unopose_linear_bf16_lnfold(const void *A, const void *W, const float *dvec, const float *cvec, const float *stats, int nparts, float eps,
+                               void *C, long M, int N, int K, int gelu, unopose_stream_t stream);
+/* Start offset of every second workgroup of `_residual`, in 1/8 ticks of the 100 MHz clock per 64-wide K step (0: all start together;
+ * < 0 only queries); returns the previous value.  A tuning knob of the tile schedule: results do not depend on it. */
+int unopose_gemm_fold_stagger(int eighth_ticks_per_ktile);
+
 /* Small batched float32 contraction on the exact-fp32 matrix instruction (an fma chain, one rounding per product):
  *     C[(bo,bi)][i][j] = alpha * sum_k A[bo sab + bi sah + i sai + k sak] * Bm[bo sbb + bi sbh + j sbj + k sbk],  C (bo*bi, n, m) row-major.
  * The coarse feature similarity (model_utils.py:260-282), the focused linear attention's k^T v (transformer.py:560-566). */

@@ -301,3 +301,49 @@ def test_four_wave_kernel_many_launches_back_to_back():
     assert torch.equal(outs[0], outs[1])
     ref = a.float() @ w.float().t() + b
     assert ((outs[0].float() - ref).abs() <= ref.abs() * 2.0 ** -8 + 2e-3).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Kp,Nc,gelu", [(256 * 5 + 77, 768, 2304, 0), (256 * 3, 3072, 3072, 1), (70000, 768, 768, 0), (300, 768, 1024, 1)])
+def test_residual_and_layernorm_fold_vs_fp32_composite(M, Kp, Nc, gelu):
+    """Round 6: `unopose_linear_bf16_residual` (proj / fc2 with the LayerScale residual on the fp32 stream in its epilogue) and
+    `unopose_linear_bf16_lnfold` (qkv / fc1 with LayerNorm applied algebraically in the epilogue) against the fp32 composite
+    x' = x + gamma (a W^T + b);  out = act(LayerNorm(x') W2^T + b2)  (timm Block, oneref_feature_extraction.py:24-42): the residual
+    stream to fp32 accuracy of a bf16-operand GEMM, the bf16 rows bit-equal to bf16(x'), the row partial sums exact to fp32 summation,
+    the consumer's output at the bf16 level of the unfused chain.  Ragged last tiles, one-tile and many-round grids."""
+    import torch.nn as nn
+    from unopose_amd import ops
+
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(M + Nc)
+    C = 768
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
+    a = rn(M, Kp).bfloat16()
+    lin_p, lin_c, norm = nn.Linear(Kp, C).to(dev), nn.Linear(C, Nc).to(dev), nn.LayerNorm(C, eps=1e-6).to(dev)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.3 * rn(C))
+        norm.bias.copy_(0.2 * rn(C))
+    gamma = nn.Parameter(0.05 + 0.45 * torch.rand(C, device=dev, generator=g))
+    x0 = (rn(M, C) * 2 + 0.5 * rn(1, C)).contiguous()
+    x = x0.clone()
+    with torch.no_grad():
+        xb, stats = ops.linear_residual_(x, a, lin_p, gamma)
+        out = ops.linear_lnfold(xb, stats, lin_c, norm, gelu=bool(gelu))
+        xr = x0 + gamma * (a.float() @ lin_p.weight.T + lin_p.bias)
+        ref = torch.nn.functional.layer_norm(xr, (C,), norm.weight, norm.bias, 1e-6) @ lin_c.weight.T + lin_c.bias
+        if gelu:
+            ref = torch.nn.functional.gelu(ref)
+    assert (x - xr).abs().max().item() < 2e-2 and (x - xr).abs().mean().item() < 1.5e-3  # bf16 operands, fp32 accumulation and residual
+    assert torch.equal(xb, x.bfloat16())
+    st = stats[:M].sum(1)
+    assert (st[:, 0] - x.sum(1)).abs().max().item() < 1e-2 and ((st[:, 1] - (x * x).sum(1)).abs() / (x * x).sum(1)).max().item() < 1e-5
+    e = (out.float() - ref).abs()
+    assert e.max().item() < 8e-2 and e.mean().item() < 5e-3, (e.max().item(), e.mean().item())
+    # the weight caches follow an in-place edit of ANY tensor they are derived from (LayerScale, LayerNorm bias)
+    with torch.no_grad():
+        norm.bias.add_(1.0)
+        out2 = ops.linear_lnfold(xb, stats, lin_c, norm, gelu=bool(gelu))
+        ref2 = torch.nn.functional.layer_norm(xr, (C,), norm.weight, norm.bias, 1e-6) @ lin_c.weight.T + lin_c.bias
+        if gelu:
+            ref2 = torch.nn.functional.gelu(ref2)
+    assert (out2.float() - ref2).abs().mean().item() < 5e-3

@@ -455,6 +455,41 @@ def test_vit_autocast_fused_path_matches_unfused(tamed):
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("tame", [0.1, 1.0])
+def test_vit_layernorm_fold_matches_separate_passes_and_fp32(tame):
+    """Round 6: the ViT with the residual + LayerNorm passes folded into the GEMM epilogues (ops.USE_LN_FOLD, csrc/gemm_kernel.h EPI
+    5 / 6 / 7) against (a) the same forward with the separate `scale_residual_layernorm` passes and (b) the fp32 ViT, on 56 crops of
+    224 x 224 (14 616 rows: the smallest batch the fold takes) with tamed and UNTAMED (default-init, tame = 1) weights: the folded path
+    must be as close to fp32 as the separate passes are (it rounds the un-normalised rows to bf16 where they round the normalised ones --
+    the same relative error per element as long as the row mean is small against the row's spread, which is also measured here).
+    timm Block, oneref_feature_extraction.py:24-42."""
+    from oracle.unopose_ref import default_cfg, random_state_dict
+    from unopose_amd import ops
+    from unopose_amd.model import UNOPose, default_model_cfg
+
+    m = UNOPose(default_model_cfg(fine_npoint=1024))
+    m.load_state_dict(random_state_dict(default_cfg(), seed=0, tame=tame), strict=True)
+    vit = m.cuda().eval().feature_extraction.rgb_net.vit
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(56, 3, 224, 224, generator=g).cuda()
+    ref = vit(img)  # fp32-class path
+    assert ops.ln_fold_ok(56 * 261, 768)
+    outs = {}
+    for fold in (True, False):
+        ops.USE_LN_FOLD = fold
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                outs[fold] = vit(img)
+        finally:
+            ops.USE_LN_FOLD = True
+    scale = sum(r.abs().mean().item() for r in ref) / len(ref)
+    e_fold = sum((a.float() - r).abs().mean().item() for a, r in zip(outs[True], ref)) / len(ref) / scale
+    e_sep = sum((a.float() - r).abs().mean().item() for a, r in zip(outs[False], ref)) / len(ref) / scale
+    d = sum((a.float() - b.float()).abs().mean().item() for a, b in zip(outs[True], outs[False])) / len(ref) / scale
+    assert e_fold < 2e-2 and e_fold < 1.25 * e_sep + 1e-3 and d < 2e-2, (e_fold, e_sep, d)
+
+
+@torch.no_grad()
 def test_fused_linear_attention_kernel(model):
     """Fused focused-linear-attention core (bf16 MFMA) vs the fp32 composite: 2048 dense x 196 sparse."""
     from unopose_amd import ops

@@ -212,4 +212,61 @@ int unopose_linear_bf16_gather(const void *A, long M, int K, const void *W, int 
   return check_launch("linear_bf16_gather");
 }
 
+// ---- round 6: the ViT's residual + LayerNorm passes folded into the GEMMs around them (gemm_kernel.h EPI 5 / 6 / 7) -------------------
+static int fold_launch_shape(long M, int N, int *grid, int *tiles, int *tiles_n) {
+  *tiles_n = N / GEMM_BN;
+  *tiles = cdiv(M, GEMM_BM) * *tiles_n;
+  const int n_cu = gemm_cu_count();
+  *grid = *tiles >= n_cu ? n_cu : ((*tiles + 7) & ~7);
+  return use_nt_store(M, N);
+}
+
+// Start offset of every second workgroup of the residual-epilogue GEMM, in 1/8 ticks (100 MHz) per K-tile: half a tile's K loop (a K-tile
+// takes ~2.1 us on this part) = 8 * 105.  Tuned / measured in scripts/ubench/lnfold_ab.py.
+static int g_fold_stagger = 8 * 105;
+int unopose_gemm_fold_stagger(int eighth_ticks_per_ktile) {
+  const int was = g_fold_stagger;
+  if (eighth_ticks_per_ktile >= 0) g_fold_stagger = eighth_ticks_per_ktile;
+  return was;
+}
+
+int unopose_linear_bf16_residual(const void *A, const void *W, const float *bias, float *xres, void *xb, float *stats, long M, int N, int K,
+                                 unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(A && W && bias && xres && xb && stats, "linear_bf16_residual: null pointer");
+  UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && K >= GEMM_BK && K % GEMM_BK == 0,
+                  "linear_bf16_residual: needs N %% 256 == 0 and K %% 64 == 0 (got M=%ld N=%d K=%d)", M, N, K);
+  UNOPOSE_REQUIRE((size_t)M * K * 2 < (1UL << 32) && (size_t)N * K * 2 < (1UL << 32) && (size_t)M * N * 4 < (1UL << 31), "linear_bf16_residual: operand too large for 32-bit buffer offsets");
+  int grid, tiles, tiles_n;
+  const int nt = fold_launch_shape(M, N, &grid, &tiles, &tiles_n);
+  hipStream_t s = (hipStream_t)stream;
+  int *const sched = tiles > grid ? gemm_sched_slot(s) : nullptr;
+  hipLaunchKernelGGL((gemm256_kernel<5>), dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)xb, (int)M, N, K, tiles_n, tiles, nt,
+                     (const int *)nullptr, (const int *)nullptr, (const u16 *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f, 0, 0, 0, sched,
+                     (void *)xres, (const float *)nullptr, (float2 *)stats, 0, tiles > grid ? g_fold_stagger * (K / GEMM_BK) / 8 : 0);
+  return check_launch("linear_bf16_residual");
+}
+
+int unopose_linear_bf16_lnfold(const void *A, const void *W, const float *dvec, const float *cvec, const float *stats, int nparts, float eps, void *C,
+                               long M, int N, int K, int gelu, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(A && W && dvec && cvec && stats && C, "linear_bf16_lnfold: null pointer");
+  UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= GEMM_BN && N % GEMM_BN == 0 && K >= GEMM_BK && K % GEMM_BK == 0,
+                  "linear_bf16_lnfold: needs N %% 256 == 0 and K %% 64 == 0 (got M=%ld N=%d K=%d)", M, N, K);
+  UNOPOSE_REQUIRE(nparts >= 1 && nparts <= GEMM_LNF_MAXPARTS && nparts * GEMM_BN == K, "linear_bf16_lnfold: needs nparts = K / 256 <= %d (got nparts=%d K=%d)", GEMM_LNF_MAXPARTS, nparts, K);
+  UNOPOSE_REQUIRE((size_t)M * K * 2 < (1UL << 32) && (size_t)N * K * 2 < (1UL << 32) && (size_t)M * N * 2 < (1UL << 32), "linear_bf16_lnfold: operand larger than 4 GiB");
+  int grid, tiles, tiles_n;
+  const int nt = fold_launch_shape(M, N, &grid, &tiles, &tiles_n);
+  hipStream_t s = (hipStream_t)stream;
+  int *const sched = tiles > grid ? gemm_sched_slot(s) : nullptr;
+#define UNOPOSE_LNF_LAUNCH(E)                                                                                                                      \
+  hipLaunchKernelGGL((gemm256_kernel<E>), dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, dvec, (u16 *)C, (int)M, N, K, tiles_n, tiles, nt, \
+                     (const int *)nullptr, (const int *)nullptr, (const u16 *)nullptr, (const float *)nullptr, (const float *)nullptr, eps, 0, 0, 0, sched, \
+                     (void *)nullptr, cvec, (float2 *)stats, nparts)
+  if (gelu)
+    UNOPOSE_LNF_LAUNCH(7);
+  else
+    UNOPOSE_LNF_LAUNCH(6);
+#undef UNOPOSE_LNF_LAUNCH
+  return check_launch("linear_bf16_lnfold");
+}
+
 }  // extern "C"

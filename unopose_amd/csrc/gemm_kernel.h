@@ -26,6 +26,9 @@ namespace unopose {
 #ifndef GEMM_PRIO
 #define GEMM_PRIO 0  // 1 = s_setprio 1 around the MFMA segment (measured: -1..2 % with 16-MFMA segments; scripts/ubench/gemm_r04_variants.hip)
 #endif
+#ifndef GEMM_LNF_ABL
+#define GEMM_LNF_ABL 0  // EPI 6 / 7 timing ablations (wrong results): 1 = no LayerNorm math in the epilogue, 2 = no c / row-partial DMA, 3 = both
+#endif
 #define GEMM_BK 64
 constexpr bool kMfma = GEMM_ABL != 2, kFrag = GEMM_ABL != 3, kDma = GEMM_ABL != 1;
 
@@ -46,6 +49,8 @@ constexpr bool kMfma = GEMM_ABL != 2, kFrag = GEMM_ABL != 3, kDma = GEMM_ABL != 
 #define GEMM_LDS_LNW (GEMM_LDS_MBOX + 16)
 #define GEMM_LDS_LNB (GEMM_LDS_LNW + 1024)
 #define GEMM_LDS_LNPART (GEMM_LDS_LNB + 1024)
+#define GEMM_LDS_STATS GEMM_LDS_LNPART     // EPI 6 / 7: the tile's 256 x nparts row partials (sum, sum of squares), 2 parities x 8 KiB (nparts <= 4)
+#define GEMM_LNF_MAXPARTS 4
 
 // GATHER (grouped, row-gathered form; unopose_linear_bf16_gather): output row r of tile t is A row row_list[256 t + r]
 // times the 256-row weight block of the group tile t belongs to (tile_info[1 + g] = first tile of group g, g = 0..N/256;
@@ -66,7 +71,15 @@ constexpr bool kMfma = GEMM_ABL != 2, kFrag = GEMM_ABL != 3, kDma = GEMM_ABL != 
 // fragment pair (hi.hi + hi.lo + lo.hi), epilogues: EPI 0 / 1 / 2 -> C fp32 and / or C2 in the split layout (bias / exact-erf GELU /
 // ReLU); EPI 4 -> C = bf16(resid + bf16(x W^T + b)).  Its epilogue stages C through a WHOLE buffer (8 KiB per wave), so the next
 // tile's K-tile 1 is put in flight after the epilogue instead of before it.
-template <int EPI, bool GATHER = false, bool F32 = false>  // EPI 0: bias; 1: bias + GELU; 2: bias + ReLU; 3: bias + residual + LayerNorm
+// ROUND 6 -- the ViT's residual + LayerNorm passes folded into the GEMMs around them (timm Block: x + ls(f(norm(x))),
+// oneref_feature_extraction.py:24-42; bf16 form only):
+//   EPI 5 (producer: proj / fc2 with LayerScale folded into W and b): x = xres + acc on the FP32 residual stream, in place (`C2v`),
+//         C = bf16(x) (the un-normalised rows the next GEMM reads) and per (row, column tile) the partial sums (sum x, sum x^2) of the
+//         tile's 256 columns into `stats[row * tiles_n + tn]` -- the four column waves combined through LDS, no atomics;
+//   EPI 6 / 7 (consumer: qkv / fc1 + GELU on W' = g (.) W): acc = x_bf16 W'^T starts at zero and the epilogue applies LayerNorm
+//         algebraically, out = rstd_r (acc - mean_r c_n) + d_n with c_n = sum_k W'[n][k] (`aux_vec`), d_n = sum_k beta_k W[n][k] + b_n
+//         (`bias`), mean_r / rstd_r from the `nparts` partials of row r in `stats` (ln_eps; the LayerNorm width is K).
+template <int EPI, bool GATHER = false, bool F32 = false>  // EPI 0: bias; 1: bias + GELU; 2: bias + ReLU; 3: bias + residual + LayerNorm; 5 / 6 / 7: above
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void gemm256_kernel(const void *__restrict__ Av, const void *__restrict__ Wv,
                                                            const float *__restrict__ bias, void *__restrict__ Cv, int M,
                                                            int N, int K, int tiles_n, int tiles_arg, int nt_store,
@@ -75,8 +88,11 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
                                                            const u16 *__restrict__ resid = nullptr, const float *__restrict__ ln_w = nullptr,
                                                            const float *__restrict__ ln_b = nullptr, float ln_eps = 0.f, int lda = 0,
                                                            int ldw = 0, int ldc = 0, int *__restrict__ sched = nullptr,
-                                                           void *__restrict__ C2v = nullptr) {
+                                                           void *__restrict__ C2v = nullptr, const float *__restrict__ aux_vec = nullptr,
+                                                           float2 *__restrict__ stats = nullptr, int nparts = 0, int stagger = 0) {
   static_assert(!(F32 && (EPI == 3 || GATHER)), "the fp32-class form has no LayerNorm epilogue / gathered rows");
+  static_assert(!((F32 || GATHER) && EPI >= 5), "the residual / LayerNorm-fold epilogues belong to the dense bf16 form");
+  constexpr bool LNF = EPI == 6 || EPI == 7;  // consumer of the folded LayerNorm
   static_assert(F32 || EPI != 4, "EPI 4 (bf16 + residual out of fp32-class operands) is an F32 epilogue");
   constexpr int ESZ = F32 ? 4 : 2;                        // bytes per k of an operand row
   constexpr int KT = F32 ? 32 : 64;                       // k per K-tile (128-byte rows either way)
@@ -84,7 +100,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
   // row strides in elements (0 = dense; unopose_linear_bf16_ld)
   const int LDA = lda ? lda : K, LDW = ldw ? ldw : K, LDC = ldc ? ldc : N;
   const int tiles = GATHER ? __builtin_amdgcn_readfirstlane(tile_info[0]) : tiles_arg;
-  __shared__ __attribute__((aligned(1024))) char smem[GEMM_LDS_BIAS + 2048 + 16 + (EPI == 3 ? 2048 + 8192 : 0)];
+  __shared__ __attribute__((aligned(1024))) char smem[GEMM_LDS_BIAS + 2048 + 16 + (EPI == 3 || EPI == 5 ? 2048 + 8192 : LNF ? 2048 + 2 * 8192 : 0)];
   float *const lnw_lds = reinterpret_cast<float *>(smem + GEMM_LDS_LNW), *const lnb_lds = reinterpret_cast<float *>(smem + GEMM_LDS_LNB);
   float2 *const ln_part = reinterpret_cast<float2 *>(smem + GEMM_LDS_LNPART);  // [wm][mb][row][wn]: (sum, sum of squares) of 64 columns
   if (EPI == 3 && threadIdx.x < GEMM_BN) {  // visible after the first barrier of the tile loop
@@ -215,8 +231,35 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
   };
   // the tile's 256 bias values (1 KiB) by LDS-DMA as well: no ordinary load sits between the stream's counted waits.  Every wave
   // issues the same piece (same bytes, same place), so each wave's own vmcnt covers the copy it reads and the counts stay uniform.
-  auto stage_bias = [&](const TileP &p, int bsel) { gemm_dma16(lds0 + GEMM_LDS_BIAS + bsel * 1024, (uint32_t)(lane * 16), b_rs, __builtin_amdgcn_readfirstlane(p.n0 * 4)); };
-
+  // (EPI 6 / 7: the tile's 256 column sums c_n ride with the bias slice, into the slot pair EPI 3 keeps its LayerNorm weights in)
+  const __amdgpu_buffer_rsrc_t cv_rs = __builtin_amdgcn_make_buffer_rsrc((void *)(LNF ? aux_vec : bias), 0, N * 4, 0x00020000);
+  // and so do the row partials of the tile's 256 rows (256 x nparts x 8 bytes, contiguous: 2 nparts pieces), so that the epilogue finds
+  // them in LDS instead of paying an L2 round trip per tile (the stats buffer holds whole tiles of rows: no bounds)
+  const __amdgpu_buffer_rsrc_t st_rs = __builtin_amdgcn_make_buffer_rsrc((void *)stats, 0, LNF ? (int)((size_t)((M + GEMM_BM - 1) / GEMM_BM) * GEMM_BM * nparts * 8) : 0, 0x00020000);
+  auto stage_bias = [&](const TileP &p, int bsel) {
+    if (!LNF) {
+      gemm_dma16(lds0 + GEMM_LDS_BIAS + bsel * 1024, (uint32_t)(lane * 16), b_rs, __builtin_amdgcn_readfirstlane(p.n0 * 4));
+      return;
+    }
+    // EPI 6 / 7 read all of this in the EPILOGUE only (the accumulators start at zero), many barriers after the issuing wave's counted waits
+    // have retired it: the 2 + 2 nparts pieces (d slice, c slice, row partials) are dealt over the waves, ONE per wave and slot (a wave
+    // whose piece index is past the end repeats piece 0, so that every wave issues the same number of loads and the counted waits stay
+    // uniform) instead of every wave fetching everything (+7 % on the L2 -> LDS stream of a K = 768 tile)
+    const int total = (GEMM_LNF_ABL & 2) ? 1 : 2 + 2 * nparts;
+#pragma unroll
+    for (int rep = 0; rep < (2 + 2 * GEMM_LNF_MAXPARTS + 7) / 8; ++rep) {
+      if (rep * 8 >= total) break;  // (uniform)
+      int pc = rep * 8 + wave;
+      if (pc >= total) pc = 0;
+      if (pc == 0)
+        gemm_dma16(lds0 + GEMM_LDS_BIAS + bsel * 1024, (uint32_t)(lane * 16), b_rs, __builtin_amdgcn_readfirstlane(p.n0 * 4));
+      else if (pc == 1)
+        gemm_dma16(lds0 + GEMM_LDS_LNW + bsel * 1024, (uint32_t)(lane * 16), cv_rs, __builtin_amdgcn_readfirstlane(p.n0 * 4));
+      else
+        gemm_dma16(lds0 + GEMM_LDS_STATS + bsel * 8192 + (pc - 2) * 1024, (uint32_t)(lane * 16), st_rs,
+                   __builtin_amdgcn_readfirstlane(p.m0 * nparts * 8 + (pc - 2) * 1024));
+    }
+  };
   // The stream continues across tiles when the tile has >= 2 K-tiles and the epilogue leaves the registers for the next
   // tile's offsets (EPI 3, the LayerNorm epilogue, does not: every tile then starts from an empty pipeline).
   const bool can_stream = EPI != 3 && nk >= 2;
@@ -231,6 +274,12 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
     if (tid == 0) mbox[0] = atomicAdd(sched + xcd, 1);
     __syncthreads();
     ti = __builtin_amdgcn_readfirstlane(mbox[0]);
+  }
+  if (EPI == 5 && stagger > 0 && (slot & 1)) {
+    // STAGGER (see gemm.hip): every second workgroup of an XCD starts `stagger` ticks of the 100 MHz clock late -- about half a tile -- so that
+    // the HBM-sized residual epilogues of one half of the chip run beside the K loops of the other half instead of all 256 at once
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int64_t)(__builtin_amdgcn_s_memrealtime() - t0) < (int64_t)stagger) __builtin_amdgcn_s_sleep(8);
   }
   for (; ti < chunk_len;) {
     const int step = dyn ? ti / nslots : (ti - slot) / nslots;  // tiles an XCD runs together share the K rotation
@@ -266,7 +315,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 bv = EPI == 3 || GEMM_EABL == 3 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(bias_lds + wn * 64 + nb * 32 + 8 * g + 4 * hi);
+        const float4 bv = EPI == 3 || LNF || GEMM_EABL == 3 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(bias_lds + wn * 64 + nb * 32 + 8 * g + 4 * hi);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
           acc[nb][mb][4 * g + 0] = bv.x;
@@ -396,7 +445,11 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
           stage_half(nxt, H_A0, 0, par);
           stage_half(nxt, H_B0, 0, par);
           stage_half(nxt, H_B1, 0, par);
-          GEMM_WAIT_VM(8);
+          if (LNF) {  // the column sums and the row partials issued with the bias slice stay in flight too: they have until the next phase's wait
+            if (nparts <= 3) GEMM_WAIT_VM(9);   // one piece per wave (8 pieces in all)
+            else GEMM_WAIT_VM(10);              // two
+          } else
+            GEMM_WAIT_VM(8);
         } else if (F32) {
           GEMM_WAIT_VM(2);  // (this epilogue stages C through the whole buffer: the next tile's K-tile 1 follows after it)
         } else {
@@ -464,7 +517,127 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
           }
       }
     }
-    if constexpr (!F32) {
+    if constexpr (LNF && !(GEMM_LNF_ABL & 1)) {
+      // ---- LayerNorm applied algebraically on the accumulators: out = rstd_r * acc - (rstd_r * mean_r) * c_n + d_n
+      int l31 = l31_, hi = hi_;
+      asm volatile("" : "+v"(l31), "+v"(hi));
+      const float *c_lds = reinterpret_cast<const float *>(smem + GEMM_LDS_LNW + bsel * 1024);
+      const float inv_k = 1.f / (float)K;
+      float rs[4], nm[4];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const float2 *sp = reinterpret_cast<const float2 *>(smem + GEMM_LDS_STATS + bsel * 8192) + (wm * 128 + mb * 32 + l31) * nparts;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < GEMM_LNF_MAXPARTS; ++i)
+          if (i < nparts) {
+            const float2 q = sp[i];
+            t1 += q.x;
+            t2 += q.y;
+          }
+        const float mean = t1 * inv_k;
+        rs[mb] = rsqrtf(fmaxf(t2 * inv_k - mean * mean, 0.f) + ln_eps);
+        nm[mb] = -mean * rs[mb];
+      }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = wn * 64 + nb * 32 + 8 * g + 4 * hi;
+          const float4 cv = *reinterpret_cast<const float4 *>(c_lds + nl), dv = *reinterpret_cast<const float4 *>(bias_lds + nl);
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) {
+            acc[nb][mb][4 * g + 0] = fmaf(rs[mb], acc[nb][mb][4 * g + 0], fmaf(nm[mb], cv.x, dv.x));
+            acc[nb][mb][4 * g + 1] = fmaf(rs[mb], acc[nb][mb][4 * g + 1], fmaf(nm[mb], cv.y, dv.y));
+            acc[nb][mb][4 * g + 2] = fmaf(rs[mb], acc[nb][mb][4 * g + 2], fmaf(nm[mb], cv.z, dv.z));
+            acc[nb][mb][4 * g + 3] = fmaf(rs[mb], acc[nb][mb][4 * g + 3], fmaf(nm[mb], cv.w, dv.w));
+          }
+        }
+    }
+    if constexpr (EPI == 5) {
+      // ---- residual epilogue: x = xres + acc on the fp32 residual stream in place, C = bf16(x), row partial sums of x.
+      // The fp32 stream must move in WHOLE cache lines (a first form that read and wrote it in the accumulator layout -- 32 bytes per row
+      // and instruction -- cost as much as the separate LayerNorm pass it replaces: 128 us per launch).  So the accumulators go through
+      // the wave's 4-KiB staging slot 16 rows x 64 columns at a time ([row][256 B], 16-byte slots XOR-swizzled by row) and come back
+      // row-major: 16 lanes x 16 bytes = one row's 256 contiguous bytes per DPP row -- the load of the old x, the store of the new x
+      // (2 full lines) and the bf16 store (1 full line) are all contiguous, and the row sums are DPP-row reductions.  Three rounds of
+      // loads (12 KiB per wave) are kept in flight ahead of the staging.
+      int l31 = l31_, hi = hi_, lane = lane_;
+      asm volatile("" : "+v"(l31), "+v"(hi), "+v"(lane));
+      char *cw = smem + par + (wave < 4 ? 8192 + (wave & 1) * 4096 + (wave >> 1) * 16384 : GEMM_OPBYTES + 4096 + (wave - 4) * 8192);
+      const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(C2v, 0, (int)((size_t)M * N * 4), 0x00020000);
+      const int r4 = lane >> 4, q = lane & 15;
+      const uint32_t x_v0 = (uint32_t)((((size_t)m0 + wm * 128 + r4) * N + n0 + wn * 64 + q * 4) * 4);
+      const uint32_t c_v0 = (uint32_t)((((size_t)m0 + wm * 128 + r4) * LDC + n0 + wn * 64 + q * 4) * 2);
+      const uint32_t x_rowb = (uint32_t)(N * 4), c_rowb = (uint32_t)(LDC * 2);
+      constexpr int PF = 3;  // rounds of loads in flight (4 spills 56 VGPRs)
+      f32x4 rv[PF][4];
+      auto load_round = [&](int r, f32x4(&dst)[4]) {  // round r = rows r * 16 .. + 15 of the wave's 128
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          dst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, x_v0 + (uint32_t)(r * 16 + it * 4) * x_rowb, 0, 0));
+      };
+#pragma unroll
+      for (int r = 0; r < PF; ++r) load_round(r, rv[r]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int mb = r >> 1, h = r & 1;
+        if ((l31 >> 4) == h) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int s16 = (nb * 8 + 2 * g + hi) ^ (l31 & 15);
+              *reinterpret_cast<float4 *>(cw + (l31 & 15) * 256 + s16 * 16) =
+                  make_float4(acc[nb][mb][4 * g + 0], acc[nb][mb][4 * g + 1], acc[nb][mb][4 * g + 2], acc[nb][mb][4 * g + 3]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 4 + r4;
+          const f32x4 a = *reinterpret_cast<const f32x4 *>(cw + row * 256 + ((q ^ row) << 4));
+          const f32x4 o = rv[r % PF][it];
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = a[e] + o[e];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), x_rs, x_v0 + (uint32_t)(r * 16 + it * 4) * x_rowb, 0, 0);
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 pk = {cvt_pk_bf16_f32(v[0], v[1]), cvt_pk_bf16_f32(v[2], v[3])};
+          if (nt_store)
+            __builtin_amdgcn_raw_buffer_store_b64(pk, c_rs, c_v0 + (uint32_t)(r * 16 + it * 4) * c_rowb, 0, 2);
+          else
+            __builtin_amdgcn_raw_buffer_store_b64(pk, c_rs, c_v0 + (uint32_t)(r * 16 + it * 4) * c_rowb, 0, 0);
+          float a1 = (v[0] + v[1]) + (v[2] + v[3]), a2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          a1 += dpp_f32<0x111, 0xF>(a1, 0.f);  // row_shr 1, 2, 4, 8: the 16 lanes of a DPP row hold one matrix row; the sum lands in lane 15
+          a2 += dpp_f32<0x111, 0xF>(a2, 0.f);
+          a1 += dpp_f32<0x112, 0xF>(a1, 0.f);
+          a2 += dpp_f32<0x112, 0xF>(a2, 0.f);
+          a1 += dpp_f32<0x114, 0xF>(a1, 0.f);
+          a2 += dpp_f32<0x114, 0xF>(a2, 0.f);
+          a1 += dpp_f32<0x118, 0xF>(a1, 0.f);
+          a2 += dpp_f32<0x118, 0xF>(a2, 0.f);
+          if (q == 15) ln_part[((wm * 4 + mb) * 32 + h * 16 + row) * 4 + wn] = make_float2(a1, a2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (r + PF < 8) load_round(r + PF, rv[r % PF]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // (raw: the next tile's LDS-DMA stream stays in flight)
+      if (wn == 0 && hi == 0) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          const float2 *pp = ln_part + ((wm * 4 + mb) * 32 + l31) * 4;
+          const float4 p01 = *reinterpret_cast<const float4 *>(pp), p23 = *reinterpret_cast<const float4 *>(pp + 2);
+          // (the stats buffer is padded to whole 256-row tiles: no bounds test)
+          stats[(size_t)(m0 + wm * 128 + mb * 32 + l31) * tiles_n + (n0 >> 8)] = make_float2((p01.x + p01.z) + (p23.x + p23.z), (p01.y + p01.w) + (p23.y + p23.w));
+        }
+      }
+    } else if constexpr (!F32) {
     // (lane-derived addresses recomputed per tile from laundered values: see the fp32-class epilogue below)
     int l31 = l31_, hi = hi_, lane = lane_;
     asm volatile("" : "+v"(l31), "+v"(hi), "+v"(lane));
@@ -490,7 +663,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
         for (int g = 0; g < 4; ++g) {
           const int nl = nb * 32 + 8 * g + 4 * hi;  // local column of the 4 values
           float v0 = acc[nb][mb][4 * g + 0], v1 = acc[nb][mb][4 * g + 1], v2 = acc[nb][mb][4 * g + 2], v3 = acc[nb][mb][4 * g + 3];
-          if (EPI == 1 && GEMM_EABL != 3) {
+          if ((EPI == 1 || EPI == 7) && GEMM_EABL != 3) {
             v0 = gelu_bf16_class(v0);
             v1 = gelu_bf16_class(v1);
             v2 = gelu_bf16_class(v2);

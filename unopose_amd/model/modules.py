@@ -68,6 +68,16 @@ class _Block(nn.Module):
             return x, None
         return x, ops.scale_residual_layernorm_(x, y, self.ls2.gamma, next_norm)
 
+    def forward_folded(self, x, n1, xb, stats):
+        """autocast path with the residual + LayerNorm passes folded into the GEMMs (ops.linear_residual_ / ops.linear_lnfold): the block
+        reads either `n1` = norm1(x) in bf16 (the first block, from the ViT prologue) or the previous block's un-normalised bf16 rows `xb`
+        with their row partial sums, updates the fp32 residual stream `x` in place twice and returns (xb, stats) of its output."""
+        a = self.attn
+        qkv = ops.linear(n1, a.qkv) if n1 is not None else ops.linear_lnfold(xb, stats, a.qkv, self.norm1)
+        xb, stats = ops.linear_residual_(x, ops.vit_attention(qkv, a.heads), a.proj, self.ls1.gamma)
+        h = ops.linear_lnfold(xb, stats, self.mlp.fc1, self.norm2, gelu=True)
+        return ops.linear_residual_(x, h, self.mlp.fc2, self.ls2.gamma)
+
     def forward_fused_f32(self, x, n1s, next_norm):
         """The same without autocast (the reference's default precision): `n1s` = norm1(x) in the split layout of csrc/gemm_f32.hip;
         qkv, fc1 and fc2 read split operands directly (fc1 hands its GELU output to fc2 in that layout too), the attention core and
@@ -175,9 +185,15 @@ def _vit_fused_blocks(self, x, n1, taps_side_by_side):
     outs = []
     B, _, D = x.shape
     wide = torch.empty(B, x.shape[1], len(taps) * D, dtype=torch.bfloat16, device=x.device) if taps_side_by_side else None
+    fold = ops.ln_fold_ok(B * x.shape[1], D)
+    xb = stats = None
     for i, blk in enumerate(self.blocks):
         nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None
-        x, n1 = blk.forward_fused(x, n1, nxt)
+        if fold:  # the LayerNorms live in the GEMM epilogues: the residual stream is only touched by proj / fc2
+            xb, stats = blk.forward_folded(x, n1, xb, stats)
+            n1 = None
+        else:
+            x, n1 = blk.forward_fused(x, n1, nxt)
         if i in taps:
             k = len(outs)
             outs.append(ops.add_layernorm(x, None, self.norm, out=None if wide is None else wide[:, :, k * D:(k + 1) * D]))

@@ -1974,3 +1974,79 @@ def scale_residual_layernorm_(x, y, gamma, norm):
         call("unopose_scale_residual_layernorm", ptr(x), ptr(y), ptr(gamma), ptr(norm.weight), ptr(norm.bias),
              x.numel() // C, C, float(norm.eps), ptr(out), stream_ptr())
     return out
+
+
+# ---- round 6: the ViT's residual + LayerNorm passes folded into the GEMMs around them (csrc/gemm_kernel.h EPI 5 / 6 / 7) -------------
+# timm Block under autocast (oneref_feature_extraction.py:24-42):  x = x + ls1(attn(norm1(x)));  x = x + ls2(mlp(norm2(x))).
+# Producer (proj / fc2, LayerScale folded into its weights): the epilogue updates the fp32 residual stream in place and emits the updated
+# rows in bf16 + per-row partial sums.  Consumer (qkv / fc1 on W' = norm.weight (.) W): reads the UN-normalised bf16 rows and applies
+# LayerNorm algebraically in its epilogue.  No separate residual / LayerNorm pass: 23 launches and 270 MB of the 1080 MB per (GEMM, LN,
+# GEMM) link are gone (same-box A/B: scripts/ubench/lnfold_ab.py, profiles/r06_ln_fold_ab.txt).
+USE_LN_FOLD = True  # A/B attribute: False = scale_residual_layernorm_ between the GEMMs (round 5's path)
+
+
+def ln_fold_ok(rows, C):
+    """The fold runs on the 256 x 256-tile kernel only: shapes whose proj / fc2 grid the small-tile kernel would take keep the separate pass."""
+    if not (USE_LN_FOLD and USE_HIP_GEMM and HIP_GEMM_ALL) or C % 256 != 0 or C // 256 > 4 or rows * C * 4 >= 2 ** 31:
+        return False
+    n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count & ~7
+    return ((rows + 255) // 256) * (C // 256) >= n_cu * 5 // 8
+
+
+def _fold_producer_weights(lin, gamma):
+    """(gamma (.) W) bf16, gamma (.) b fp32 of a LayerScale-d linear, cached on the module (keyed on every tensor they are derived from)."""
+    key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.device, None if lin.bias is None else lin.bias._version, gamma._version, gamma.data_ptr())
+    cache = getattr(lin, "_fold_prod_cache", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            g = gamma.detach().float()
+            w = (lin.weight.detach().float() * g[:, None]).to(torch.bfloat16).contiguous()
+            b = (torch.zeros_like(g) if lin.bias is None else lin.bias.detach().float() * g).contiguous()
+        cache = (key, w, b)
+        lin._fold_prod_cache = cache
+    return cache
+
+
+def _fold_consumer_weights(lin, norm):
+    """W' = W (.) norm.weight (bf16), c_n = sum_k W'[n][k] (of the ROUNDED W': what the matrix cores multiply), d_n = sum_k norm.bias[k] W[n][k] + b[n]."""
+    key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.device, None if lin.bias is None else lin.bias._version,
+           norm.weight._version, norm.weight.data_ptr(), norm.bias._version)
+    cache = getattr(lin, "_fold_cons_cache", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            w32 = lin.weight.detach().float()
+            w = (w32 * norm.weight.detach().float()[None, :]).to(torch.bfloat16).contiguous()
+            c = w.float().sum(1).contiguous()
+            d = (w32.double() @ norm.bias.detach().double()).float()
+            if lin.bias is not None:
+                d = d + lin.bias.detach().float()
+            d = d.contiguous()
+        cache = (key, w, c, d)
+        lin._fold_cons_cache = cache
+    return cache
+
+
+def linear_residual_(x, a, lin, gamma):
+    """x (rows, C) fp32 += gamma * lin(a) IN PLACE (a: bf16 (rows, K)); -> (bf16 copy of the updated rows, row partial sums (rows_padded, C/256, 2))."""
+    note_mutation()
+    _, w, b = _fold_producer_weights(lin, gamma)
+    C, K = w.shape
+    rows = x.numel() // C
+    assert x.dtype == torch.float32 and x.is_contiguous() and a.dtype == torch.bfloat16 and a.numel() == rows * K
+    a = _c(a)
+    xb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    stats = torch.empty((rows + 255) // 256 * 256, C // 256, 2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        call("unopose_linear_bf16_residual", ptr(a), ptr(w), ptr(b), ptr(x), ptr(xb), ptr(stats), rows, C, K, stream_ptr())
+    return xb, stats
+
+
+def linear_lnfold(xb, stats, lin, norm, gelu=False):
+    """lin(LayerNorm(x)) [-> GELU] from the un-normalised bf16 rows `xb` and the row partial sums of `linear_residual_`; bf16 out."""
+    _, w, c, d = _fold_consumer_weights(lin, norm)
+    N, K = w.shape
+    rows = xb.numel() // K
+    out = torch.empty(*xb.shape[:-1], N, dtype=torch.bfloat16, device=xb.device)
+    with torch.cuda.device(xb.device):
+        call("unopose_linear_bf16_lnfold", ptr(xb), ptr(w), ptr(d), ptr(c), ptr(stats), K // 256, float(norm.eps), ptr(out), rows, N, K, int(gelu), stream_ptr())
+    return out
