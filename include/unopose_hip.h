@@ -497,11 +497,6 @@ int unopose_pose_score(const float *dis, const float *w, int B, int N, float thr
 int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C, long M, int N, int K,
                         int epilogue, unopose_stream_t stream);
 int unopose_gemm_bf16_tile(void);
-/* Kernel choice of unopose_linear_bf16(_ld) for the shapes both forms support: 0 (default) = the 8-wave kernel, 1 = the four-wave
- * one-wave-per-SIMD kernel (csrc/gemm4w.hip) where a launch gives every CU a tile, 2 = the four-wave kernel for every shape its stream
- * supports (K >= 512; with GELU K >= 768).  on < 0 only queries.  Returns the previous setting.  Same results up to the summation
- * order; GELU is evaluated on the bf16-rounded pre-activation by the four-wave kernel, on the fp32 accumulator by the 8-wave one. */
-int unopose_gemm4w_enable(int on);
 
 /* The residual + LayerNorm passes of a timm Block (x + ls(f(norm(x))), oneref_feature_extraction.py:24-42) folded into the GEMMs
  * around them (bf16 autocast forward).

@@ -1,17 +1,18 @@
-"""Variants of the four-wave GEMM stream (unopose_amd/gen4w) as stand-alone libraries, and their check / A-B on the GPU.
+"""Variants of the four-wave GEMM stream (scripts/ubench/gemm4w/gen4w) as stand-alone libraries, and their check / A-B on the GPU.
 
-Build (CPU):  python scripts/ubench/g4w_var.py build base cap6=cap:6 n316=n3_mid:16 ...      (name=key:value,key:value generator arguments)
-Run (GPU):    python scripts/ubench/g4w_var.py run base cap6 ...          correctness on a set of shapes, then interleaved timing rounds
+Build (CPU):  python scripts/ubench/gemm4w/g4w_var.py build base cap6=cap:6 n316=n3_mid:16 ...      (name=key:value,key:value generator arguments)
+Run (GPU):    python scripts/ubench/gemm4w/g4w_var.py run base cap6 ...          correctness on a set of shapes, then interleaved timing rounds
               against the 8-wave kernel (the same library with the four-wave path switched off)."""
 import ctypes, os, shutil, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(os.path.dirname(HERE))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
 CSRC = os.path.join(ROOT, "unopose_amd/csrc")
 def so(n): return os.path.join(HERE, f"_g4w_{n}.so")
 if sys.argv[1] == "build":
-    from unopose_amd.gen4w import emit
+    from gen4w import emit
     def one(spec):
         name, _, kv = spec.partition("=")
         kw = {}
@@ -22,9 +23,9 @@ if sys.argv[1] == "build":
         os.makedirs(os.path.join(d, "_gen"), exist_ok=True)
         emit.write_all(os.path.join(d, "_gen"), **kw)
         for f in ("gemm4w.hip", "gemm4w_clobbers.h"):
-            shutil.copy(os.path.join(CSRC, f), os.path.join(d, f))
+            shutil.copy(os.path.join(HERE, f), os.path.join(d, f))
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-honor-nans", "-ffp-contract=off",
-               "-fno-slp-vectorize", "-fno-vectorize", "-I", CSRC, os.path.join(d, "gemm4w.hip"), os.path.join(CSRC, "gemm.hip"),
+               "-fno-slp-vectorize", "-fno-vectorize", "-DUNOPOSE_PROBE_GEMM4W", "-I", CSRC, os.path.join(d, "gemm4w.hip"), os.path.join(CSRC, "gemm.hip"),
                os.path.join(CSRC, "gemm_small.hip"), os.path.join(CSRC, "abi.hip"), "-o", so(name)]
         subprocess.check_call(cmd)
         return name

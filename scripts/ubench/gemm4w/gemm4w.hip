@@ -1,6 +1,6 @@
 // bf16 "linear" GEMM, FOUR-WAVE form (round 5): one 256-thread workgroup per CU, ONE wavefront per SIMD, each wave owning the whole
 // 512-entry register file of its SIMD -- 128 x 128 outputs per wave in a[0:255] -- with the instruction stream HAND-PLACED by a generator
-// (unopose_amd/gen4w/kernel.py, included below as the body of one asm statement per epilogue variant; the C++ around it only
+// (gen4w/kernel.py beside this file, included below as the body of one asm statement per epilogue variant; the C++ around it only
 // declares the kernel, its LDS and its kernarg block).  What it changes against the 8-wave kernel of gemm_kernel.h:
 //   * the epilogue of tile i runs INSIDE the K loop of tile i + 1.  At the seam the accumulators are drained into 128 VGPRs as packed
 //     bf16 (v_accvgpr_read + v_cvt_pk in the MFMA gaps of the seam's two K-tiles, whose MFMA order is quadrant-major so that the 16
@@ -11,7 +11,7 @@
 //   * the bias enters through the matrix pipe (first MFMA of a block: bias-as-three-bf16 x ones, C = 0), GELU is evaluated on the
 //     bf16-rounded pre-activation (torch autocast's own order of operations: nn.Linear rounds to bf16, GELU follows).
 // Same LDS image, swizzle, LDS-DMA pieces, tile walk, K rotation and ticket scheduling as gemm_kernel.h.  The stream was checked
-// on a functional emulator before it ever ran (tests/test_gemm4w_emu_cpu.py).
+// on a functional emulator before it ever ran (test_emu_cpu.py beside this file).
 #include <hip/hip_runtime.h>
 
 #include "_gen/gemm4w_gen.h"
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 static inline uint32_t g4w_magic31(uint32_t d) { return (uint32_t)(((1ull << 31) + d - 1) / d); }
 
 // Launch parameters: the tile walk of gemm_kernel.h (XCD chunks of a row-major tile sequence; column blocks when W exceeds an XCD's L2)
-// as per-XCD tables and division magics for the scalar code of the stream.  Python twin: unopose_amd/gen4w/host.py.
+// as per-XCD tables and division magics for the scalar code of the stream.  Python twin: gen4w/host.py.
 static void g4w_fill_args(G4wArgs &a, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, long M, int N, int K,
                           int grid, int *sched) {
   for (int i = 0; i < G4W_KARG_DWORDS; ++i) a.w[i] = 0;

@@ -1,9 +1,13 @@
-"""The generated gemm4w instruction stream on the functional emulator (unopose_amd/gen4w/emu.py): results against numpy,
+"""The generated gemm4w instruction stream on the functional emulator (gen4w/emu.py): results against numpy,
 with LDS-DMA data landing early and late and the waves of a workgroup emulated in both orders (none may matter)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
-from unopose_amd.gen4w import emu, host, kernel
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gen4w import emu, host, kernel  # noqa: E402
 
 
 def bf16(x):
@@ -71,7 +75,7 @@ def test_gelu_and_relu():
 
 def test_wait_counts_do_not_rely_on_store_order():
     """a stream whose counted waits include younger stores fails once acknowledgements overtake loads: the emulator must see that"""
-    from unopose_amd.gen4w import isa
+    from gen4w import isa
     seq = [isa.Ins("buffer_load_dwordx4", isa.V(2, 2), isa.S(28, 4), isa.S(91), addr="idxen offen", tag="g"),
            isa.Ins("buffer_store_dwordx4", isa.V(4, 4), isa.V(2, 2), isa.S(36, 4), isa.S(89), addr="idxen offen", tag="st"), isa.wait_vm("g")]
     out, vm, _ = isa.resolve_waits(seq)

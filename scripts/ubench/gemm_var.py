@@ -16,7 +16,7 @@ if sys.argv[1] == "build":
         flags = [f for f in flags if not f.startswith("@")]
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-honor-nans", "-ffp-contract=off",
                "-I", os.path.join(ROOT, "unopose_amd/csrc"), *flags, src, os.path.join(ROOT, "unopose_amd/csrc/gemm_small.hip"), os.path.join(ROOT, "unopose_amd/csrc/abi.hip"),
-               *([] if any(f == "-DNO4W" for f in flags) else [os.path.join(ROOT, "unopose_amd/csrc/gemm4w.hip")]), "-o", so(name)]
+               "-o", so(name)]
         subprocess.check_call(cmd)
         return name
     with ThreadPoolExecutor(6) as ex:

@@ -83,7 +83,6 @@ SIGNATURES = {
     "unopose_gemm_fold_stagger": [_I],
     "unopose_linear_bf16_residual": [_P, _P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _P],
     "unopose_linear_bf16_lnfold": [_P, _P, _P, _P, _P, _I, _F, _P, ctypes.c_long, _I, _I, _I, _P],
-    "unopose_gemm4w_enable": [_I],
     "unopose_patchify_bf16": [_P, _I, _P, _I, _I, _I, _P, _P],
     "unopose_vit_tokens_layernorm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P],
     "unopose_row_dot": [_P, _I, _P, _F, ctypes.c_long, _I, _P, _I, _P],

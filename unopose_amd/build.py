@@ -49,29 +49,11 @@ def _newer(src, dst, extra=()):
     return any(os.path.getmtime(p) > t for p in (src, *extra))
 
 
-def generate():
-    """the hand-placed instruction stream of csrc/gemm4w.hip (unopose_amd/gen4w): csrc/_gen/*.inc, rewritten only when it changes"""
-    import importlib.util
-    here = os.path.join(HERE, "gen4w")
-    mods = {}
-    for name in ("isa", "kernel", "emit"):   # (loaded by path: building must not import the package, which loads the library)
-        spec = importlib.util.spec_from_file_location(f"_g4w.{name}", os.path.join(here, name + ".py"), submodule_search_locations=None)
-        mods[name] = spec
-    import types
-    pkg = types.ModuleType("_g4w")
-    pkg.__path__ = [here]
-    sys.modules["_g4w"] = pkg
-    emit = importlib.import_module("_g4w.emit")
-    return emit.write_all(os.path.join(CSRC, "_gen"))
-
-
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    generate()
     hipcc = _hipcc()
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hdrs += [os.path.join(CSRC, "_gen", f) for f in os.listdir(os.path.join(CSRC, "_gen"))]
     hdrs.append(os.path.join(HERE, "..", "include", "unopose_hip.h"))
     jobs = []
     objs = []

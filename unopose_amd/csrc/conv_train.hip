@@ -277,13 +277,14 @@ int unopose_conv1x1_train_forward(const float *x, int B, int cin, long L, const 
     hipLaunchKernelGGL((conv1x1_f32_kernel<KP, MM>), dim3(grid), dim3(256), 0, s, x, w, cin, B, L, y);              \
     return check_launch("conv1x1_train_forward");                                                                   \
   }
+  // (per output width the tightest K first: a 32 -> 32 layer must not run zero-padded to K = 64)
   UNOPOSE_CONV_CASE(8, 32)
-  UNOPOSE_CONV_CASE(32, 64)
-  UNOPOSE_CONV_CASE(64, 128)
-  UNOPOSE_CONV_CASE(128, 64)
-  UNOPOSE_CONV_CASE(64, 32)
   UNOPOSE_CONV_CASE(32, 32)
+  UNOPOSE_CONV_CASE(64, 32)
+  UNOPOSE_CONV_CASE(32, 64)
   UNOPOSE_CONV_CASE(64, 64)
+  UNOPOSE_CONV_CASE(128, 64)
+  UNOPOSE_CONV_CASE(64, 128)
   UNOPOSE_CONV_CASE(128, 128)
 #undef UNOPOSE_CONV_CASE
   UNOPOSE_REQUIRE(false, "conv1x1_train_forward: no kernel for %d -> %d channels (built: <=8->32, <=32->{32,64}, <=64->{32,64,128}, <=128->{64,128})", cin,

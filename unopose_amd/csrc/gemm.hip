@@ -98,16 +98,22 @@ int *gemm_sched_slot(hipStream_t stream) {
 }
 }  // namespace unopose
 
-// Round 5: the four-wave kernel (gemm4w.hip) takes the shapes its stream supports when a ticket slot is at hand.
+// The four-wave, one-wave-per-SIMD kernel of round 5 (a generated, hand-placed instruction stream; it TIES this kernel on the ViT shapes:
+// profiles/r05_gemm4w_ablate.txt) lives under scripts/ubench/gemm4w/ with its generator and emulator; its variant builds
+// (scripts/ubench/gemm4w/g4w_var.py) compile this file with -DUNOPOSE_PROBE_GEMM4W to route the entry points to it.
+#ifdef UNOPOSE_PROBE_GEMM4W
 namespace unopose {
 bool gemm4w_ok(long M, int N, int K, int lda, int ldw, int ldc, int epilogue);
 int gemm4w_linear(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, long M, int N, int K, int epilogue, int nt,
                   int *sched, hipStream_t s);
 }  // namespace unopose
-#ifndef GEMM_4W
-#define GEMM_4W 0  // default: the 8-wave kernel (same-box A/Bs put the two within +-3 % of each other on the ViT shapes: profiles/r05_gemm4w_ablate.txt)
+static int g_use_4w = 0;
+extern "C" int unopose_gemm4w_enable(int on) {
+  const int was = g_use_4w;
+  if (on >= 0) g_use_4w = on > 2 ? 2 : on;  // 0: off, 1: shapes with at least one tile per CU, 2: every shape the stream supports
+  return was;
+}
 #endif
-static int g_use_4w = GEMM_4W;
 
 static int linear_bf16_dispatch(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, long M, int N, int K,
                                 int epilogue, hipStream_t s, const char *what) {
@@ -119,12 +125,14 @@ static int linear_bf16_dispatch(const void *A, int lda, const void *W, int ldw, 
 #else
   const int tiles = cdiv(M, GEMM_BM) * tiles_n;
 #endif
-  if (g_use_4w == 2 && gemm4w_ok(M, N, K, lda, ldw, ldc, epilogue)) {  // (forced: tests drive small tile counts through the stream as well)
+#ifdef UNOPOSE_PROBE_GEMM4W
+  if (g_use_4w == 2 && gemm4w_ok(M, N, K, lda, ldw, ldc, epilogue)) {  // (forced: small tile counts go through the stream as well)
     if (int *const sched4 = gemm_sched_slot(s)) {
       gemm4w_linear(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, use_nt_store(M, N), sched4, s);
       return check_launch(what);
     }
   }
+#endif
   if (tiles < small_tiles_limit()) return gemm_small_linear(A, W, bias, C, M, N, K, lda, ldw, ldc, epilogue, s);
   const int n_cu = gemm_cu_count();
   const int grid = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
@@ -133,12 +141,14 @@ static int linear_bf16_dispatch(const void *A, int lda, const void *W, int ldw, 
   hipLaunchKernelGGL(gemm256_kernel<E>, dim3(grid), dim3(512), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N, K, tiles_n, \
                      tiles, nt, (const int *)nullptr, (const int *)nullptr, (const u16 *)nullptr, (const float *)nullptr,                     \
                      (const float *)nullptr, 0.f, lda, ldw, ldc, sched)
+#ifdef UNOPOSE_PROBE_GEMM4W
   if (g_use_4w && tiles >= n_cu && gemm4w_ok(M, N, K, lda, ldw, ldc, epilogue)) {
     if (int *const sched4 = gemm_sched_slot(s)) {
       gemm4w_linear(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, nt, sched4, s);
       return check_launch(what);
     }
   }
+#endif
   int *const sched = tiles > grid ? gemm_sched_slot(s) : nullptr;  // (one tile per workgroup: nothing to schedule)
   if (epilogue == 1)
     UNOPOSE_LD_LAUNCH(1);
@@ -153,12 +163,6 @@ static int linear_bf16_dispatch(const void *A, int lda, const void *W, int ldw, 
 extern "C" {
 
 int unopose_gemm_bf16_tile(void) { return GEMM_BM; }
-
-int unopose_gemm4w_enable(int on) {
-  const int was = g_use_4w;
-  if (on >= 0) g_use_4w = on > 2 ? 2 : on;  // 0: off, 1: shapes with at least one tile per CU, 2: every shape the stream supports
-  return was;
-}
 
 int unopose_linear_bf16(const void *A, const void *W, const float *bias, void *C, long M, int N, int K, int epilogue,
                         unopose_stream_t stream) {

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void pe_group_mlp_max_kernel(
     // Neighbour-list entries past the `cnt` points inside the radius are copies of the FIRST neighbour (ball_query_gpu.cu:14-49): their
     // MLP rows equal row 0's and cannot change the maximum -- tiles that hold nothing but such copies are skipped (bit-identical result).
     // The frame above is computed over all S entries, copies included, as the reference does.
-    const int S_eff = min(S, (min(cnt_nb, S) + 31) & ~31);
+    const int S_eff = min(S, (max(min(cnt_nb, S), 1) + 31) & ~31);  // (no point inside the radius -- a NaN centre: the list is S copies of point 0, run one tile like the reference)
 
     // ---- MLP over tiles of 32 neighbours, running max over tiles
     f32x16 rmax[4];
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(PE_NW * 64, 8 / PE_NW) void pe_group_mlp_max_bf16x3
       for (int r = 0; r < 16; ++r) rmax[t][r] = 0.f;  // post-ReLU values are >= 0
     // (tiles of nothing but copies of the first neighbour -- the padding of a list with fewer than S points inside the radius -- are
     //  skipped: their rows equal row 0's, the maximum cannot change; round 5)
-    const int S_eff = PE_ABL == 1 ? 0 : min(S, (min(cnt, S) + 31) & ~31);
+    const int S_eff = PE_ABL == 1 ? 0 : min(S, (max(min(cnt, S), 1) + 31) & ~31);  // (cnt == 0, a NaN centre: one tile of the all-point-0 list, like the reference)
     for (int t0 = 0; t0 < S_eff; t0 += 32) {
       // keep the weight fragments in LDS (re-read per tile) instead of letting the compiler hoist ~170
       // registers of loop-invariant operands: leaves room for 2 waves / SIMD so one wave's VALU phases

@@ -4,6 +4,7 @@ Each function cites the reference Python it replaces.  Inputs must be CUDA
 float32 tensors; there is no CPU path (RuntimeError).
 """
 import ctypes
+import itertools
 import os
 
 import torch
@@ -104,7 +105,7 @@ def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
 
 
 # =============================================================================
-# Dense-math operators.  Every GEMM of the eval path -- bf16 under autocast (csrc/gemm.hip, gemm_small.hip, gemm4w.hip), fp32-class
+# Dense-math operators.  Every GEMM of the eval path -- bf16 under autocast (csrc/gemm.hip, gemm_small.hip), fp32-class
 # without (csrc/gemm_f32.hip, bmm_f32.hip) -- and everything with structure (attention, sampling, assignment, pose hypotheses) is a
 # hand-written HIP kernel behind the C ABI; the `*_torch` composites below are the training path's differentiable forms and the
 # fall-backs for shapes the kernels refuse (each warns once through note_fallback).
@@ -122,7 +123,6 @@ USE_HIP_GEMM = True
 # every ViT-sized linear on csrc/gemm.hip (no library stream-K kernels, i.e. no kernel with inter-workgroup waits, on the path)
 # (measured 0.6 % behind the library at one forward in flight; it is what makes two forwards in flight safe: pipeline.py)
 HIP_GEMM_ALL = True
-HIP_GEMM_MIN_ROWS = 4096  # below this a 256 x 256 tile grid cannot fill 256 CUs: library GEMM
 
 
 _fallbacks_seen = set()
@@ -148,35 +148,14 @@ def linear_backend():
     return "hipBLASLt (through torch)"
 
 
-# ---- several forwards in flight on different HIP streams (bench.py --inflight N, a production runner that pipelines
-# batches): hipBLASLt picks stream-K kernels ("..._SK3_...") for the large ViT linears, whose workgroups spin on
-# partner workgroups' partial tiles; two of them co-scheduled from different streams can each hold CUs the other's
-# partners need (observed as a GPU hang in round 1).  With SERIALIZE_BIG_GEMMS set, every large library GEMM waits
-# for the previous one -- whichever stream it ran on -- so at most ONE kernel with inter-workgroup waits is ever in
-# flight; every other kernel on the path (all hand-written ones, the small non-stream-K library GEMMs) is free of
-# such waits and overlaps freely.
-SERIALIZE_BIG_GEMMS = False
-_big_gemm_last = None  # (event, stream) of the last large library GEMM
-
-
-def _big_gemm_enter():
-    if SERIALIZE_BIG_GEMMS and _big_gemm_last is not None:
-        cur = torch.cuda.current_stream()
-        if _big_gemm_last[1] != cur:
-            cur.wait_event(_big_gemm_last[0])
-
-
-def _big_gemm_exit():
-    global _big_gemm_last
-    if SERIALIZE_BIG_GEMMS:
-        cur = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        _big_gemm_last = (ev, cur)
+def _params_key(mod, *extra):
+    """Cache key of state derived from a module's tensors: version and address of EVERY parameter and buffer of the module, so that an
+    in-place edit of any of them -- a bias alone included -- rebuilds the derived state."""
+    return tuple((t._version, t.data_ptr()) for t in itertools.chain(mod.parameters(), mod.buffers())) + extra
 
 
 def _bf16_weights(lin):
-    key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.device)
+    key = _params_key(lin)
     cache = getattr(lin, "_bf16_cache", None)
     if cache is None or cache[0] != key:
         with torch.no_grad():
@@ -205,7 +184,7 @@ def own_gemm_ok(rows, N, K):
     MFMA kernel -- the library is built without them now, see build.py.)"""
     if not USE_HIP_GEMM or N % 256 != 0 or K % 64 != 0 or rows < 1:
         return False
-    return HIP_GEMM_ALL or rows >= HIP_GEMM_MIN_ROWS
+    return HIP_GEMM_ALL or rows >= 4096
 
 
 def bf16_linear_2d(x2, w, bias_f32, bias_bf16=None, relu=False):
@@ -249,13 +228,13 @@ def split_f32(x2, memo=False):
     returned as an (M, 2K) bf16 tensor (same bytes as the fp32 matrix).
     `memo=True` (the token projections of the matcher: the same tensor is projected two or three times, q / kv, k / v -- 49 of the 117
     splits of a forward, scripts/split_census.py): the last two SMALL results are remembered, keyed on storage, shape, strides, stream,
-    torch's version counter (absent on inference tensors) AND the mutation epoch -- every wrapper that writes a tensor through a raw
+    torch's version counter (inference tensors have none and are not remembered) AND the mutation epoch -- every wrapper that writes a tensor through a raw
     pointer calls note_mutation(), which empties the memo; the model empties it at the end of each forward half as well.  The entry holds
     the source tensor, so its address cannot be handed to another tensor while the entry lives."""
     M, K = x2.shape
-    memo = memo and not torch.is_grad_enabled() and M * K <= (8 << 20)
+    memo = memo and not torch.is_grad_enabled() and M * K <= (8 << 20) and not x2.is_inference()  # (no version counter on inference tensors)
     if memo:
-        ver = 0 if x2.is_inference() else x2._version
+        ver = x2._version
         key = (x2.data_ptr(), M, K, x2.stride(), ver, _MUTATION_EPOCH[0], torch.cuda.current_stream(x2.device).cuda_stream)
         for e in _SPLIT_MEMO:
             if e[0] == key:
@@ -306,7 +285,7 @@ def linear_f32_raw(x, w, b, owner, tag):
     rows = x.numel() // K
     if not (x.is_cuda and not _DIFF and f32x3_ok(rows, N, K)):
         return F.linear(x, w, b)
-    key = (w.data_ptr(), w._version, tag)
+    key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version), tag)
     caches = owner.__dict__.setdefault("_f32x3_raw", {})
     c = caches.get(tag)
     if c is None or c[0] != key:
@@ -542,8 +521,15 @@ TRAIN_OWN_CONV = True  # A/B attribute: False = nn.Conv2d (MIOpen) for the PE's 
 _CONV_FWD_PAIRS = ((8, (32,)), (32, (32, 64)), (64, (32, 64, 128)), (128, (64, 128)))  # (cin up to, couts): csrc/conv_train.hip
 
 
+_CONV_WGRAD_PAIRS = {32: 32, 64: 64, 128: 128}  # cout -> largest cin unopose_conv1x1_train_wgrad builds (csrc/conv_train.hip)
+
+
 def _conv1x1_pair_ok(cin, cout):
     return any(cin <= k and cout in ms for k, ms in _CONV_FWD_PAIRS)
+
+
+def _conv1x1_wgrad_ok(cin, cout):
+    return cin <= _CONV_WGRAD_PAIRS.get(cout, 0)
 
 
 class _Conv1x1Fn(torch.autograd.Function):
@@ -593,8 +579,10 @@ def conv1x1(x, conv):
     cout, cin = w.shape[0], w.shape[1]
     L = x[0, 0].numel() if x.dim() >= 3 else 0
     if (TRAIN_OWN_CONV and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and conv.bias is None
-            and w.shape[2:] == (1, 1) and x.dim() == 4 and L % 64 == 0 and 64 <= L < (1 << 28) and _conv1x1_pair_ok(cin, cout)
-            and (not x.requires_grad or _conv1x1_pair_ok(cout, cin)) and cout in (32, 64, 128) and _aligned16(x)):
+            and w.shape[2:] == (1, 1) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (0, 0) and tuple(conv.dilation) == (1, 1)
+            and conv.groups == 1 and x.dim() == 4 and L % 64 == 0 and 64 <= L < (1 << 28) and _conv1x1_pair_ok(cin, cout)
+            and (not x.requires_grad or _conv1x1_pair_ok(cout, cin)) and (not w.requires_grad or _conv1x1_wgrad_ok(cin, cout))
+            and cout in (32, 64, 128) and _aligned16(x)):
         return _Conv1x1Fn.apply(x, w)
     return conv(x)
 
@@ -775,13 +763,7 @@ def linear(x, lin, relu=False, gelu=False):
         if relu and cache[2] is not None:
             x2 = xb.reshape(-1, xb.shape[-1])
             return torch._addmm_activation(cache[2], x2, cache[1].t()).reshape(*xb.shape[:-1], cache[1].shape[0])
-        # stream-K candidates: the ViT-sized problems (hipBLASLt picks "..._SK3_MT256x256x64" for them)
-        big = rows >= HIP_GEMM_MIN_ROWS and min(N, K) >= 512
-        if big:
-            _big_gemm_enter()
         y = F.linear(xb, cache[1], cache[2])
-        if big:
-            _big_gemm_exit()
         return F.relu(y) if relu else (F.gelu(y) if gelu else y)
 
 
@@ -836,7 +818,7 @@ def patch_embed(patches, conv):
     if _f32_path(patches) and f32x3_ok(rows, D, 32):
         # fp32: K = 588 zero-padded to 608 (a multiple of the 32-wide stage of csrc/gemm_f32.hip)
         Kp = (K + 31) // 32 * 32
-        key = (conv.weight._version, conv.weight.data_ptr(), Kp, "f32")
+        key = _params_key(conv, Kp, "f32")
         cache = getattr(conv, "_f32x3_pad_cache", None)
         if cache is None or cache[0] != key:
             with torch.no_grad():
@@ -851,7 +833,7 @@ def patch_embed(patches, conv):
     if _DIFF or not (HIP_GEMM_ALL and patches.is_cuda and torch.is_autocast_enabled() and own_gemm_ok(rows, D, 64)):
         return F.linear(patches, w, conv.bias)
     Kp = (K + 63) // 64 * 64
-    key = (conv.weight._version, conv.weight.data_ptr(), Kp)
+    key = _params_key(conv, Kp)
     cache = getattr(conv, "_bf16_pad_cache", None)
     if cache is None or cache[0] != key:
         with torch.no_grad():
@@ -881,7 +863,7 @@ def vit_prologue(xa, xb, vit, norm1):
     w = conv.weight.reshape(conv.weight.shape[0], -1)
     D, K = w.shape
     Kp = (K + 63) // 64 * 64
-    key = (conv.weight._version, conv.weight.data_ptr(), Kp, vit.cls_token._version, vit.reg_token._version)
+    key = _params_key(conv, Kp, vit.cls_token._version, vit.reg_token._version)
     cache = getattr(conv, "_prologue_cache", None)
     if cache is None or cache[0] != key:
         with torch.no_grad():
@@ -952,8 +934,16 @@ def scale_by_radius(x, radius, multiply=False, eps=1e-6):
         return x * s if multiply else x / s
     xc = _c(x)
     out = torch.empty_like(xc)
+    B = xc.shape[0]
+    if xc.numel() == 0:
+        return out
+    r = radius.float().reshape(-1)
+    if r.numel() != B:  # (the torch expression broadcast a single radius over the batch: the kernel indexes radius[b])
+        if r.numel() != 1:
+            raise ValueError(f"scale_by_radius: {r.numel()} radii for a batch of {B}")
+        r = r.expand(B)
     with torch.cuda.device(x.device):
-        call("unopose_scale_by_radius", ptr(xc), xc.shape[0], xc.numel() // xc.shape[0], ptr(_c(radius.float())), float(eps), int(multiply), ptr(out), stream_ptr())
+        call("unopose_scale_by_radius", ptr(xc), B, xc.numel() // B, ptr(_c(r)), float(eps), int(multiply), ptr(out), stream_ptr())
     return out
 
 
@@ -1259,6 +1249,9 @@ _GEO_HINV = 4        # table nodes per unit index (csrc/embed.hip: GT_HINV)
 _GEO_D_RANGE = 64    # distance indices the table covers (the kernel evaluates larger ones from the defining sum)
 
 
+_GEO_TABLE_UNAVAILABLE = {}  # device -> True once the table kernel's LDS opt-in has failed there
+
+
 def _geo_tables(m, key, npoint=4):
     """proj_d(sinus(x)) and proj_a(sinus(x)) without their biases on the grid x = (r - (npoint / 2 - 1)) / 4 (fp64 sum, stored fp32),
     cached per weight version and interpolation order: what `unopose_geo_embedding_table` interpolates.  None when the angle table
@@ -1305,7 +1298,9 @@ def geo_embedding(points, m, out_dtype=None):
         out_dtype = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
     bf16_out = out_dtype == torch.bfloat16
     cache = getattr(m, "_hip_cache", None)
-    key = (m.proj_d.weight._version, m.proj_a.weight._version, m.proj_d.weight.data_ptr(), m.proj_d.weight.device)
+    # (every tensor / number the derived state is computed from: an in-place edit of a bias alone, or a changed factor_a, rebuilds it)
+    key = (m.proj_d.weight._version, m.proj_a.weight._version, m.proj_d.bias._version, m.proj_a.bias._version, m.proj_d.weight.data_ptr(),
+           m.proj_d.weight.device, float(m.factor_a), float(m.sigma_d))
     if cache is None or cache[0] != key:
         assert m.proj_d.weight.shape == (256, 256) and m.angle_k == 3, "kernel is built for hidden_dim=256, k=3"
         wdh, wdl = (_mfma_fragment_order(t) for t in _bf16_split(m.proj_d.weight.detach()))
@@ -1319,12 +1314,19 @@ def geo_embedding(points, m, out_dtype=None):
     if GEO_TABLE if bf16_out else GEO_TABLE_F32:
         npoint = 4 if bf16_out else 6
         tab = _geo_tables(m, key, npoint)
-        if tab is not None:
-            with torch.cuda.device(points.device):
-                call("unopose_geo_embedding_table", ptr(points), B, n, ptr(tab[0]), tab[0].shape[0], ptr(tab[1]), tab[1].shape[0],
-                     ptr(bias), ptr(tab[2]), ptr(div), _GEO_HINV, npoint, float(m.sigma_d), float(m.factor_a),
-                     int(m.reduction_a == "mean"), int(bf16_out), ptr(knn), ptr(out), stream_ptr())
-            return out
+        if tab is not None and not _GEO_TABLE_UNAVAILABLE.get(points.device, False):
+            try:
+                with torch.cuda.device(points.device):
+                    call("unopose_geo_embedding_table", ptr(points), B, n, ptr(tab[0]), tab[0].shape[0], ptr(tab[1]), tab[1].shape[0],
+                         ptr(bias), ptr(tab[2]), ptr(div), _GEO_HINV, npoint, float(m.sigma_d), float(m.factor_a),
+                         int(m.reduction_a == "mean"), int(bf16_out), ptr(knn), ptr(out), stream_ptr())
+                return out
+            except RuntimeError as e:
+                if "cannot reserve" not in str(e):
+                    raise
+                # a device that cannot give the table kernel its ~145 KiB of LDS: the matrix-core kernel below takes over, loudly, for good
+                _GEO_TABLE_UNAVAILABLE[points.device] = True
+                note_fallback("geo_embedding", f"table kernel unavailable on {points.device} ({e}): matrix-core kernel")
     with torch.cuda.device(points.device):
         call("unopose_geo_embedding", ptr(points), B, n, ptr(wdh), ptr(wdl), ptr(wah), ptr(wal), ptr(bias), ptr(div),
              float(m.sigma_d), float(m.factor_a), int(m.reduction_a == "mean"), int(not bf16_out), int(bf16_out),
@@ -1391,8 +1393,7 @@ def _token_attention_hip_f32(x, mem, att, embed):
     B, n, C = x.shape
     m = mem.shape[1]
     rpe = embed is not None
-    key = (att.proj_q.weight._version, att.proj_k.weight._version, att.proj_v.weight._version,
-           att.proj_q.weight.data_ptr(), rpe, "f32")
+    key = _params_key(att, rpe, "f32")
     cache = getattr(att, "_hip_cache_f32", None)
     if cache is None or cache[0] != key:
         with torch.no_grad():
@@ -1425,8 +1426,7 @@ def _attn_weights(att, rpe):
     """bf16 projection weights of one attention module, concatenated so that q | k | v (| the folded
     RPE query q W_p, 4 x 256) come out of as few GEMMs as possible.  Folding in fp32:
     (x Wq_h^T + bq_h) Wp_h = x (Wp_h^T Wq_h)^T + bq_h Wp_h."""
-    key = (att.proj_q.weight._version, att.proj_k.weight._version, att.proj_v.weight._version,
-           att.proj_q.weight.data_ptr(), att.proj_q.weight.device, rpe)
+    key = _params_key(att, rpe)
     cache = getattr(att, "_hip_cache", None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -1546,7 +1546,7 @@ def _focused_linear_attention_hip(xq, xkv, att, focusing):
     bf = torch.bfloat16
     B, N, C = xq.shape
     j = xkv.shape[1]
-    key = (att.proj_k.weight._version, att.proj_v.weight._version, att.scale._version, att.proj_k.weight.data_ptr())
+    key = _params_key(att)
     cache = getattr(att, "_hip_cache", None)
     if cache is None or cache[0] != key:
         with torch.no_grad():
@@ -1629,8 +1629,7 @@ def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None, cand_in=None, want_
     check_f32(pts, "pts")
     B, N, _ = pts.shape
     cache = getattr(mlp, "_hip_cache", None)
-    key = tuple((l.conv.weight._version, l.normlayer.bn.weight._version, l.normlayer.bn.running_mean._version,
-                 l.conv.weight.data_ptr()) for l in mlp.layers())
+    key = _params_key(mlp)  # (conv weights, BatchNorm affine AND running statistics)
     if cache is None or cache[0] != key:
         with torch.no_grad():
             flat = []

@@ -148,8 +148,7 @@ class PipelinedForward:
             for v in end_points.values():
                 if torch.is_tensor(v) and v.is_cuda:
                     v.record_stream(s)
-            prev, prev_forbid = ops.SERIALIZE_BIG_GEMMS, ops.FORBID_LIBRARY_BF16_GEMM
-            ops.SERIALIZE_BIG_GEMMS = ops.FORBID_LIBRARY_BF16_GEMM = True
+            prev_forbid, ops.FORBID_LIBRARY_BF16_GEMM = ops.FORBID_LIBRARY_BF16_GEMM, True
             try:
                 with torch.cuda.stream(s):
                     start = torch.cuda.Event(enable_timing=True) if self.timing else None
@@ -159,7 +158,7 @@ class PipelinedForward:
                     done = torch.cuda.Event(enable_timing=self.timing)
                     done.record(s)
             finally:
-                ops.SERIALIZE_BIG_GEMMS, ops.FORBID_LIBRARY_BF16_GEMM = prev, prev_forbid
+                ops.FORBID_LIBRARY_BF16_GEMM = prev_forbid
             t = Ticket(out, done, s)
             if self._warm is None:
                 self._warm = done
