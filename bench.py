@@ -147,28 +147,62 @@ def roofline_leg(model, batch, img):
         rows.append(r)
         return r
 
-    # the ViT linears: the four shapes of one block, bf16, M = 2B x T rows, T = 5 + (img/14)^2 tokens
+    # the ViT linears: the four shapes of one block, bf16, M = 2B x T rows, T = 5 + (img/14)^2 tokens -- in the form the step runs them.
+    # Round 6: with the residual + LayerNorm passes folded into the GEMMs (ops.USE_LN_FOLD; 47 of a forward's 48 launches) that is
+    # proj / fc2 with the fp32 residual stream in their epilogue (EPI 5) and qkv / fc1 with LayerNorm applied in theirs (EPI 6 / 7): the
+    # launches are longer than the plain-epilogue ones (timed beside them, `plain_epilogue_us`) because they absorb the 23
+    # scale_residual_layernorm launches of a forward (2.9 ms), and their algorithmic bytes include the residual stream
     T = 5 + (img // 14) ** 2
     M = 2 * B * T
-    shapes, flops, secs, alg_bytes = [], 0.0, 0.0, 0.0
+    fold = ops.ln_fold_ok(M, 768)
+    shapes, flops, secs, alg_bytes, secs_plain = [], 0.0, 0.0, 0.0, 0.0
+    import torch.nn as nn
+
+    norm = nn.LayerNorm(768, eps=1e-6).to(x.device)
+    gamma = nn.Parameter(0.05 + 0.45 * torch.rand(768, device=x.device))
     for name, K_, N_, gelu in (("qkv", 768, 2304, False), ("proj", 768, 768, False), ("fc1", 768, 3072, True),
                                ("fc2", 3072, 768, False)):
         a = torch.randn(M, K_, device=x.device).bfloat16()
         w = (torch.randn(N_, K_, device=x.device) / K_ ** 0.5).bfloat16()
         bias = torch.randn(N_, device=x.device)
-        t = hip_event_time(lambda: ops.linear_bf16_hip(a, w, bias, gelu), 20, stream, warm=3)
-        r = row("vit_linear_%s(M=%d,K=%d,N=%d%s)" % (name, M, K_, N_, ",+bias+GELU" if gelu else ""), "mfma",
-                2.0 * M * K_ * N_, 1e12, 2500.0, "TFLOP/s", t)
-        r["algorithmic_bytes"] = 2.0 * (M * K_ + N_ * K_ + M * N_) + 4.0 * N_  # A, W, C in bf16 + fp32 bias, each once
+        t_plain = hip_event_time(lambda: ops.linear_bf16_hip(a, w, bias, gelu), 20, stream, warm=3)
+        abytes = 2.0 * (M * K_ + N_ * K_ + M * N_) + 4.0 * N_  # A, W, C in bf16 + fp32 bias, each once
+        form = "bias" + ("+GELU" if gelu else "")
+        t = t_plain
+        if fold:
+            lin = nn.Linear(K_, N_).to(x.device)
+            if N_ == 768:  # producer: residual epilogue
+                xres = torch.randn(M, N_, device=x.device)
+                t = hip_event_time(lambda: ops.linear_residual_(xres, a, lin, gamma), 20, stream, warm=3)
+                abytes += 8.0 * M * N_ + 8.0 * M * (N_ // 256)  # + the fp32 residual stream read and written, the row partials
+                form = "LayerScale residual on the fp32 stream + bf16 rows + row partial sums (EPI 5)"
+                del xres
+            else:  # consumer: LayerNorm in the epilogue
+                _, st = ops.linear_residual_(torch.zeros(M, K_, device=x.device), a, nn.Linear(K_, K_).to(x.device), gamma)
+                t = hip_event_time(lambda: ops.linear_lnfold(a, st, lin, norm, gelu=gelu), 20, stream, warm=3)
+                abytes += 8.0 * M * (K_ // 256) + 4.0 * N_
+                form = "LayerNorm applied in the epilogue" + ("+GELU (EPI 7)" if gelu else " (EPI 6)")
+                del st
+            del lin
+        r = row("vit_linear_%s(M=%d,K=%d,N=%d; %s)" % (name, M, K_, N_, form), "mfma", 2.0 * M * K_ * N_, 1e12, 2500.0, "TFLOP/s", t)
+        r["algorithmic_bytes"] = abytes
+        r["hbm_gbps_algorithmic"] = abytes / t / 1e9
+        r["plain_epilogue_us"] = t_plain * 1e6
+        r["plain_epilogue_frac"] = 2.0 * M * K_ * N_ / t_plain / 1e12 / 2500.0
         shapes.append(r)
         flops += 2.0 * M * K_ * N_
         secs += t
-        alg_bytes += r["algorithmic_bytes"]
+        secs_plain += t_plain
+        alg_bytes += abytes
         del a, w, bias
     traffic = _pmc_traffic_gemm(B, T, alg_bytes)
-    gemm = dict(bound="mfma", kernel="gemm256_kernel<EPI, false, false> (bf16): the four linears of one ViT-B block at M=%d, flop-weighted" % M,
+    gemm = dict(bound="mfma", kernel="gemm256_kernel<EPI, false, false> (bf16): the four linears of one ViT-B block at M=%d as the step runs them%s, flop-weighted"
+                                      % (M, " (residual + LayerNorm folded into their epilogues)" if fold else ""),
                 achieved=flops / secs / 1e12, peak=2500.0, unit="TFLOP/s", frac=flops / secs / 1e12 / 2500.0, traffic=traffic,
                 launches=4, us=secs * 1e6, flop=flops, algorithmic_bytes=alg_bytes, shapes=shapes,
+                plain_epilogue=dict(us=secs_plain * 1e6, achieved=flops / secs_plain / 1e12, frac=flops / secs_plain / 1e12 / 2500.0,
+                                    what="the same four shapes with bias / bias + GELU epilogues only (round 5's launches; a forward then needs 23 separate "
+                                         "residual + LayerNorm passes of 810 MB each: 2.9 ms per step)"),
                 note="hand-written bf16 MFMA GEMM (256x256 tiles, half-tile LDS-DMA stream with counted waits, ping-pong wave groups, "
                      "persistent XCD-aware tile walk with dynamic tile tickets), bias / GELU in the epilogue; `achieved` = sum of the four shapes' flops / sum of their HIP-event launch times; "
                      "12 blocks x 4 launches per step")
@@ -281,7 +315,7 @@ def roofline_leg(model, batch, img):
 
 
 def _pmc_summary():
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd + "_pmc_summary.json")
         if os.path.exists(path):
             return json.load(open(path)), "profiles/%s_pmc_summary.json" % rnd

@@ -33,7 +33,7 @@ def load_dispatches(path, prefix):
 
 
 def gemm_shapes(fetch_csv, write_csv):
-    from pmc_gemm import ORDER, REPS
+    from pmc_gemm import FOLD, ORDER, REPS
 
     out = {}
     f, w = load_dispatches(fetch_csv, ", false, false>("), load_dispatches(write_csv, ", false, false>(")  # gemm256_kernel<EPI, false, false>: bf16
@@ -43,7 +43,9 @@ def gemm_shapes(fetch_csv, write_csv):
         fk, wk = sum(v for v, _ in fs) / REPS, sum(v for v, _ in ws) / REPS
         M = 64 * 1374
         out[name] = dict(M=M, K=K, N=N, fetch_KiB_raw=fk, write_KiB=wk, hbm_bytes_per_launch=(2.0 * fk + wk) * 1024.0,
-                         algorithmic_bytes=2.0 * (M * K + N * K + M * N) + 4.0 * N,
+                         # (fold: + the fp32 residual stream read and written by proj / fc2; the row partials either side)
+                         algorithmic_bytes=2.0 * (M * K + N * K + M * N) + 4.0 * N + (8.0 * M * N + 8.0 * M * 3 if FOLD and N == 768 else 8.0 * M * 3 + 4.0 * N if FOLD else 0.0),
+                         form=("EPI 5 (residual epilogue)" if N == 768 else "EPI 6 / 7 (LayerNorm in the epilogue)") if FOLD else "bias / bias + GELU",
                          mean_duration_us_under_pmc=sum(d for _, d in fs) / REPS / 1e3)
     f3 = load_dispatches(fetch_csv, ", false, true>(")  # gemm256_kernel<EPI, false, true>: fp32-class
     w3 = load_dispatches(write_csv, ", false, true>(")

@@ -17,5 +17,7 @@ rows = prof.key_averages(group_by_input_shape=True)
 rows = sorted(rows, key=lambda e: -e.self_device_time_total)
 tot = sum(e.self_device_time_total for e in rows)
 print(f"total device time {tot / 1e3:.1f} ms over 3 steps")
-for e in rows[:60]:
+for e in rows[:int(os.environ.get("TOP", "60"))]:
+    if os.environ.get("ATEN_ONLY") and not (e.key.startswith("aten::") or e.key.startswith("_") or "Backward" in e.key):
+        continue
     print(f"{e.self_device_time_total / 3e3:8.3f} ms/step  n/step {e.count / 3:6.1f}  {e.key[:50]:50s} {str(e.input_shapes)[:150]}")
