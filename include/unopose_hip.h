@@ -187,6 +187,21 @@ int unopose_geo_embedding_table(const float *points, int B, int n, const float *
                                 float factor_a, int reduce_mean, int out_bf16, int32_t *knn_ws, void *out,
                                 unopose_stream_t stream);
 
+/* The table form under autograd (the training step; gradients for proj_d / proj_a of transformer.py:303-350, the points are data):
+ * _train_forward = the 6-point float32 evaluation above, which also records per output element WHICH of the three angle terms was the
+ * maximum (amax: B*n*n*256 bytes, first maximum on ties; unused with reduce_mean) and keeps the neighbour lists in `knn`;
+ * _train_backward scatters dE (B,n,n,256) into table-shaped gradients: ws (workgroups, min(rows_d, 69) + rows_a, 256) float32, one slab per
+ * workgroup (unopose_geo_embedding_train_workgroups of them; the caller sums them: rows [0, min(rows_d, 69)) are distance rows, the rest
+ * angle rows), full_d (rows_d, 256) float32, ZEROED by the caller, for distance indices past the LDS-resident rows, and *past_table set to
+ * 1 if a distance index lies past the table altogether (its gradient is then missing).  dW = dT^T sinus(grid), db = sum_r dT[r]. */
+int unopose_geo_embedding_train_workgroups(int B, int n);
+int unopose_geo_embedding_train_forward(const float *points, int B, int n, const float *tab_d, int rows_d, const float *tab_a, int rows_a,
+                                        const float *bias_sum, const float *w_d, const float *div_term, int hinv, float sigma_d, float factor_a,
+                                        int reduce_mean, int32_t *knn, float *out, void *amax, unopose_stream_t stream);
+int unopose_geo_embedding_train_backward(const float *points, const int32_t *knn, int B, int n, int rows_d, int rows_a, int hinv, float sigma_d,
+                                         float factor_a, int reduce_mean, const float *dE, const void *amax, float *ws, float *full_d,
+                                         int *past_table, unopose_stream_t stream);
+
 /* One scale of the fine matcher's PositionalEncoding: QueryAndLRFGroup(radius, nsample,
  * use_xyz) -> SharedMLP[6,32,64,128] (1x1 conv + eval BatchNorm + ReLU) -> max over neighbours
  * (core/unopose/model/oneref_predator_fine_point_matching.py:167-174).  xyz (B,N,3) ->

@@ -392,3 +392,60 @@ def test_fused_bn_relu_train_matches_torch(shape):
     # eval mode and half the switch: the modules themselves
     bn.eval()
     assert torch.equal(ops.bn_relu(x.detach(), bn), torch.relu(bn(x.detach())))
+
+
+@pytest.mark.parametrize("B,n,reduction", [(2, 197, "max"), (3, 64, "max"), (2, 197, "mean"), (1, 5, "max")])
+def test_geo_embedding_under_autograd_matches_the_composite_in_float64(B, n, reduction):
+    """Round 6: GeometricStructureEmbedding under autograd on the table kernels (ops._GeoEmbedFn: csrc/embed.hip forward with the recorded
+    arg-max, backward = the table-shaped scatter) against torch autograd over the op-by-op composite (transformer.py:303-350) evaluated in
+    float64: the output and the four parameter gradients, for max and mean reduction, 197 / 64 / 5 tokens."""
+    import copy
+
+    from unopose_amd import ops
+    from unopose_amd.model import UNOPose, default_model_cfg
+
+    g = torch.Generator().manual_seed(B * 1000 + n)
+    torch.manual_seed(B * 1000 + n + 1)  # (the module's default init draws from the global generator)
+    m = UNOPose(default_model_cfg(fine_npoint=1024)).geo_embedding.cuda()
+    m.reduction_a = reduction
+    pts = torch.randn(B, n, 3, generator=g).cuda()
+    pts = pts / pts.norm(dim=2).max()  # radius-normalised, as the model feeds it
+    dE = torch.randn(B, n, n, 256, generator=g).cuda()
+    with ops.differentiable():
+        out = ops.geo_embedding(pts, m)
+    assert out.grad_fn is not None and "GeoEmbed" in type(out.grad_fn).__name__
+    out.backward(dE)
+    got = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m64 = copy.deepcopy(m).double()
+    for p in m64.parameters():
+        p.grad = None
+    # the composite in float64 (the ops of ops.geo_embedding_torch, transformer.py:303-350; neighbours from the fp32 distances like the kernel)
+    p64 = pts.double()
+    dist = torch.cdist(p64, p64)
+    knn = torch.cdist(pts, pts).topk(k=4, dim=2, largest=False)[1][:, :, 1:]
+    knn_pts = torch.gather(p64.unsqueeze(1).expand(B, n, n, 3), 2, knn.unsqueeze(3).expand(B, n, 3, 3))
+    rv = (knn_pts - p64.unsqueeze(2)).unsqueeze(2).expand(B, n, n, 3, 3)
+    av = (p64.unsqueeze(1) - p64.unsqueeze(2)).unsqueeze(3).expand(B, n, n, 3, 3)
+    a_idx = torch.atan2(torch.linalg.norm(torch.cross(rv, av, dim=-1), dim=-1), (rv * av).sum(-1)) * m.factor_a
+    div = m64.embedding.div_term
+
+    def sinus(idx):
+        om = idx.unsqueeze(-1) * div
+        return torch.stack([torch.sin(om), torch.cos(om)], dim=-1).reshape(*idx.shape, -1)
+
+    a_emb = m64.proj_a(sinus(a_idx))
+    ref = m64.proj_d(sinus(dist / m.sigma_d)) + (a_emb.max(dim=3)[0] if reduction == "max" else a_emb.mean(dim=3))
+    ref.backward(dE.double())
+    # forward: the table form is fp32-class (6-point interpolation); off-diagonal entries (the diagonal's d(i,i) is rounding noise of
+    # the composite's |x|^2 - 2 x.x + |x|^2, see _offdiag_err in test_model_gpu.py)
+    eye = torch.eye(n, dtype=torch.bool, device="cuda")
+    e = (out.double() - ref).abs().amax(-1)
+    assert e[:, ~eye].max().item() < 2e-4, e[:, ~eye].max().item()
+    # gradients: where two angle terms are within the interpolation error of each other the fp32 table form and the float64 composite can pick
+    # different maxima for a few (pair, channel) elements, and dE of those lands on other table rows -- an O(|dE|) difference in single
+    # entries (any two precisions of this function disagree like that): bounded in the Frobenius norm, and entry-wise at 1 % of the largest
+    for k, p in m64.named_parameters():
+        scale = p.grad.abs().max().item()
+        err = (got[k].double() - p.grad).abs().max().item()
+        fro = ((got[k].double() - p.grad).norm() / p.grad.norm()).item()
+        assert err < 1e-2 * scale + 1e-6 and fro < 3e-3, (k, err, scale, fro)

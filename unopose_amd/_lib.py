@@ -106,6 +106,9 @@ SIGNATURES = {
     "unopose_linear_f32x3_bf16": [_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _P],
     "unopose_pe_group_mlp_max": [_P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "unopose_geo_embedding": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P, _P, _P],
+    "unopose_geo_embedding_train_workgroups": [_I, _I],
+    "unopose_geo_embedding_train_forward": [_P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _F, _F, _I, _P, _P, _P, _P],
+    "unopose_geo_embedding_train_backward": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P],
     "unopose_geo_embedding_table": [_P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P],
 }
 

@@ -334,12 +334,14 @@ __device__ __forceinline__ void gt_weights(float f, float (&w)[NP]) {
   }
 }
 
-template <bool OUT_BF16, bool MEAN, int NP>
+// TRAIN (round 6, the forward of the training step): additionally writes, per output element, WHICH of the three angle terms was the
+// maximum (one byte per channel, first maximum on ties: where torch.max sends the gradient) for geo_embed_table_bwd_kernel.
+template <bool OUT_BF16, bool MEAN, int NP, bool TRAIN = false>
 __global__ __launch_bounds__(1024) void geo_embed_table_kernel(const float *__restrict__ pts, const int32_t *__restrict__ knn,
                                                                const float *__restrict__ tab_d, int rows_d, const float *__restrict__ tab_a,
                                                                int rows_a, const float *__restrict__ bias, const float *__restrict__ w_d,
                                                                const float *__restrict__ div_term, int B, int n, float sigma_d,
-                                                               float factor_a, void *__restrict__ out_) {
+                                                               float factor_a, void *__restrict__ out_, uint32_t *__restrict__ amax = nullptr) {
   extern __shared__ float4 gt_smem[];
   const int rd_l = min(rows_d, 16 * GT_HINV + NP - 1);  // distance rows [0, rd_l) (index range [0, 16)), then the angle rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -463,9 +465,135 @@ __global__ __launch_bounds__(1024) void geo_embed_table_kernel(const float *__re
         *reinterpret_cast<uint2 *>(orow + (size_t)l * 512) = make_uint2(cvt_pk_bf16(o[0], o[1]), cvt_pk_bf16(o[2], o[3]));
       else
         *reinterpret_cast<gt_f4 *>(orow + (size_t)l * 1024) = gt_f4{o[0], o[1], o[2], o[3]};
+      if (TRAIN && !MEAN) {
+        uint32_t am = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t k = (v[1][c] >= v[2][c] && v[1][c] >= v[3][c]) ? 0u : (v[2][c] >= v[3][c] ? 1u : 2u);
+          am |= k << (8 * c);
+        }
+        amax[((size_t)row * n + j0 + l) * 64 + lane] = am;
+      }
     }
     p += cols;
   }
+}
+
+// ---- Round 6: the gradient of the table form, for the training step (transformer.py:303-350 under autograd).  E = sum_m w_m T[r + m] is
+// linear in the tables, so dT[r + m][c] += w_m dE[p][c]: the backward pass is the forward kernel's mirror -- the same indices, rows and
+// Lagrange weights -- and instead of reading NP table rows per lookup it ADDS into a gradient table of the same shape that lives in LDS.
+// No atomics (a first form with ds_add_f32 from 16 waves took 9.4 ms per launch: ~190 cycles per LDS float-atomic instruction): a workgroup
+// is FOUR waves, wave w owns channels [64 w, 64 w + 64) of the table -- its own 256-byte column block of every row, one channel per lane --
+// and walks ALL pairs of the workgroup's share in order with plain ds_read / fma / ds_write (program order of one wave: deterministic).
+// The maximum over the three angle terms routes dE to the term the forward recorded (`amax`): a lane adds into the rows of ITS channel's
+// term only (per-lane row offset and weights).  The workgroup's table leaves as one coalesced copy into `ws[blockIdx.x]`; the host sums
+// the workgroups' tables and maps them back to the weights (dW = dT^T S_grid, db = sum_r dT[r]: the Lagrange weights of a lookup add
+// up to one).  Distance indices past the LDS-resident rows (radius-normalised clouds never have them) go to the full-size table `full_d`
+// with global atomics.  MEAN: a third of dE to each term.
+template <bool MEAN, int NP>
+__global__ __launch_bounds__(256) void geo_embed_table_bwd_kernel(const float *__restrict__ pts, const int32_t *__restrict__ knn, int rows_d, int rows_a, int B, int n,
+                                                                  float sigma_d, float factor_a, const float *__restrict__ dE, const uint8_t *__restrict__ amax,
+                                                                  float *__restrict__ ws, float *__restrict__ full_d, int *__restrict__ past_table) {
+  extern __shared__ float4 gt_smem[];
+  const int rd_l = min(rows_d, 16 * GT_HINV + NP - 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nrows = rd_l + rows_a;
+  for (int e = tid; e < nrows * 64; e += blockDim.x) gt_smem[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  float *const tab = reinterpret_cast<float *>(gt_smem) + wave * nrows * 64 + lane;  // this lane's channel of the wave's column block, row r at + 64 r
+  const int ch = wave * 64 + lane;
+  const float a_max = (float)(rows_a - NP) / (float)GT_HINV;
+  const float d_max = (float)(rows_d - NP) / (float)GT_HINV;
+  const long P = (long)B * n * n, per = (P + gridDim.x - 1) / gridDim.x;
+  const long p0 = (long)blockIdx.x * per, p1 = min(P, p0 + per);   // (all four waves walk the same pairs)
+  for (long p = p0; p < p1;) {
+    const long row = p / n;
+    const int j0 = (int)(p - row * n), cols = (int)min((long)min(64, n - j0), p1 - p);
+    const int b = (int)(row / n), i = (int)(row - (long)b * n);
+    const float *Pt = pts + (size_t)b * n * 3;
+    const int32_t *KNN = knn + (size_t)row * 3;
+    const float xi = Pt[i * 3], yi = Pt[i * 3 + 1], zi = Pt[i * 3 + 2];
+    const int j = min(j0 + lane, n - 1);
+    const float ax = Pt[j * 3] - xi, ay = Pt[j * 3 + 1] - yi, az = Pt[j * 3 + 2] - zi;
+    float idx[4];
+    idx[0] = sqrtf(ax * ax + ay * ay + az * az) / sigma_d;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int q = KNN[k];
+      const float rx = Pt[q * 3] - xi, ry = Pt[q * 3 + 1] - yi, rz = Pt[q * 3 + 2] - zi;
+      const float cx = ry * az - rz * ay, cy = rz * ax - rx * az, cz = rx * ay - ry * ax;
+      const float sinv = sqrtf(cx * cx + cy * cy + cz * cz);
+      const float cosv = 0.0f + (rx * ax + ry * ay + rz * az);
+      idx[1 + k] = fminf(atan2f(sinv, cosv) * factor_a, a_max);
+    }
+    int off[4];       // first of the NP rows in the gradient table, in rows (distance: < 0 = -1 - row of the full table; INT_MIN: past it)
+    float w[4][NP];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float x = idx[s4] * (float)GT_HINV, fl = floorf(x);
+      const int r0 = (int)fl;
+      gt_weights<NP>(x - fl, w[s4]);
+      if (s4 == 0)
+        off[0] = (idx[0] <= d_max) ? (r0 + NP - 1 < rd_l ? r0 : -1 - r0) : (int)0x80000000;
+      else
+        off[s4] = rd_l + r0;
+    }
+    const float *grow = dE + ((size_t)row * n + j0) * 256 + ch;
+    const uint8_t *arow = amax + ((size_t)row * n + j0) * 256 + ch;
+    float g_next = grow[0];
+    uint32_t am_next = MEAN ? 0u : arow[0];
+    for (int l = 0; l < cols; ++l) {
+      const float g = g_next;
+      const uint32_t am = am_next;
+      if (l + 1 < cols) {  // the next pair's gradient element rides under this pair's table updates
+        g_next = grow[(size_t)(l + 1) * 256];
+        if (!MEAN) am_next = arow[(size_t)(l + 1) * 256];
+      }
+      const int od = __builtin_amdgcn_readlane(off[0], l);
+      if (od >= 0) {
+        float *t = tab + od * 64;
+        float cur[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) cur[m] = t[m * 64];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) t[m * 64] = fmaf(gt_bcast(w[0][m], l), g, cur[m]);
+      } else if (od != (int)0x80000000) {
+        float *t = full_d + (size_t)(-1 - od) * 256 + ch;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) atomicAdd(t + m * 256, gt_bcast(w[0][m], l) * g);
+      } else if (lane == 0) {
+        *past_table = 1;  // a distance index past the table (never for radius-normalised clouds): the host refuses the result
+      }
+      if (MEAN) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float *t = tab + __builtin_amdgcn_readlane(off[1 + k], l) * 64;
+          float cur[NP];
+#pragma unroll
+          for (int m = 0; m < NP; ++m) cur[m] = t[m * 64];
+#pragma unroll
+          for (int m = 0; m < NP; ++m) t[m * 64] = fmaf(gt_bcast(w[1 + k][m], l), g * (1.f / 3.f), cur[m]);
+        }
+      } else {
+        // this lane's channel took its maximum from term `am`: that term's rows and weights (lane-varying)
+        const int o0 = __builtin_amdgcn_readlane(off[1], l), o1 = __builtin_amdgcn_readlane(off[2], l), o2 = __builtin_amdgcn_readlane(off[3], l);
+        float *t = tab + (am == 0 ? o0 : am == 1 ? o1 : o2) * 64;
+        float cur[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) cur[m] = t[m * 64];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+          const float s0 = gt_bcast(w[1][m], l), s1 = gt_bcast(w[2][m], l), s2 = gt_bcast(w[3][m], l);
+          t[m * 64] = fmaf(am == 0 ? s0 : am == 1 ? s1 : s2, g, cur[m]);
+        }
+      }
+    }
+    p += cols;
+  }
+  __syncthreads();
+  // ws[blockIdx.x][r][c]: the wave-major LDS image back to (rows, 256)
+  float *o = ws + (size_t)blockIdx.x * nrows * 256;
+  for (int r = 0; r < nrows; ++r) o[(size_t)r * 256 + ch] = tab[r * 64];
 }
 
 }  // namespace unopose
@@ -545,6 +673,65 @@ int unopose_geo_embedding_table(const float *points, int B, int n, const float *
 #undef UNOPOSE_GT_ORDER
 #undef UNOPOSE_GT_LAUNCH
   return check_launch("geo_embedding_table");
+}
+
+static int gt_train_grid(int B, int n) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+  const long pairs = (long)B * n * n;
+  return (int)(pairs < (long)cus * 256 ? (pairs + 255) / 256 : cus);
+}
+
+int unopose_geo_embedding_train_workgroups(int B, int n) { return gt_train_grid(B, n); }
+
+int unopose_geo_embedding_train_forward(const float *points, int B, int n, const float *tab_d, int rows_d, const float *tab_a, int rows_a, const float *bias_sum,
+                                        const float *w_d, const float *div_term, int hinv, float sigma_d, float factor_a, int reduce_mean, int32_t *knn,
+                                        float *out, void *amax, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(points && tab_d && tab_a && bias_sum && w_d && div_term && knn && out && amax, "geo_embedding_train_forward: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && n >= 4 && B <= 65535, "geo_embedding_train_forward: bad sizes (n must be >= 4 for 3-NN)");
+  UNOPOSE_REQUIRE(hinv == GT_HINV && rows_d >= 8 && rows_a >= 8, "geo_embedding_train_forward: tables must be spaced 1 / %d (got 1 / %d)", GT_HINV, hinv);
+  const int rdl = 16 * GT_HINV + 6 - 1;
+  const size_t lds = ((size_t)(rows_d < rdl ? rows_d : rdl) + rows_a) * 1024;
+  UNOPOSE_REQUIRE(lds <= 150 * 1024, "geo_embedding_train_forward: %d angle rows do not fit the LDS-resident table", rows_a);
+  if (B == 0) return UNOPOSE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(geo_knn_kernel, dim3(cdiv(n, 256), B), dim3(256), 0, s, points, n, knn);
+  int rc = check_launch("geo_knn");
+  if (rc) return rc;
+  const int grid = gt_train_grid(B, n);
+#define UNOPOSE_GTT_LAUNCH(MEAN)                                                                                                                          \
+  do {                                                                                                                                                    \
+    static bool opt[64];                                                                                                                                  \
+    if (lds_optin(opt, (const void *)geo_embed_table_kernel<false, MEAN, 6, true>, lds, "geo_embedding_train_forward") != UNOPOSE_OK) return UNOPOSE_ELAUNCH; \
+    hipLaunchKernelGGL((geo_embed_table_kernel<false, MEAN, 6, true>), dim3(grid), dim3(1024), lds, s, points, knn, tab_d, rows_d, tab_a, rows_a, bias_sum, w_d, \
+                       div_term, B, n, sigma_d, factor_a, (void *)out, (uint32_t *)amax);                                                                 \
+  } while (0)
+  if (reduce_mean) UNOPOSE_GTT_LAUNCH(true); else UNOPOSE_GTT_LAUNCH(false);
+#undef UNOPOSE_GTT_LAUNCH
+  return check_launch("geo_embedding_train_forward");
+}
+
+int unopose_geo_embedding_train_backward(const float *points, const int32_t *knn, int B, int n, int rows_d, int rows_a, int hinv, float sigma_d, float factor_a,
+                                         int reduce_mean, const float *dE, const void *amax, float *ws, float *full_d, int *past_table,
+                                         unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(points && knn && dE && amax && ws && full_d && past_table, "geo_embedding_train_backward: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && n >= 4 && B <= 65535 && hinv == GT_HINV && rows_d >= 8 && rows_a >= 8, "geo_embedding_train_backward: bad sizes");
+  const int rdl = 16 * GT_HINV + 6 - 1;
+  const size_t lds = ((size_t)(rows_d < rdl ? rows_d : rdl) + rows_a) * 1024;
+  UNOPOSE_REQUIRE(lds <= 150 * 1024, "geo_embedding_train_backward: %d angle rows do not fit the LDS-resident table", rows_a);
+  if (B == 0) return UNOPOSE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = gt_train_grid(B, n);
+#define UNOPOSE_GTB_LAUNCH(MEAN)                                                                                                                \
+  do {                                                                                                                                          \
+    static bool opt[64];                                                                                                                        \
+    if (lds_optin(opt, (const void *)geo_embed_table_bwd_kernel<MEAN, 6>, lds, "geo_embedding_train_backward") != UNOPOSE_OK) return UNOPOSE_ELAUNCH; \
+    hipLaunchKernelGGL((geo_embed_table_bwd_kernel<MEAN, 6>), dim3(grid), dim3(256), lds, s, points, knn, rows_d, rows_a, B, n, sigma_d, factor_a, dE, \
+                       (const uint8_t *)amax, ws, full_d, past_table);                                                                         \
+  } while (0)
+  if (reduce_mean) UNOPOSE_GTB_LAUNCH(true); else UNOPOSE_GTB_LAUNCH(false);
+#undef UNOPOSE_GTB_LAUNCH
+  return check_launch("geo_embedding_train_backward");
 }
 
 }  // extern "C"

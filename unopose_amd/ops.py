@@ -1287,6 +1287,8 @@ def geo_embedding(points, m, out_dtype=None):
     from the table-interpolated kernel (`unopose_geo_embedding_table`: fp32 Lagrange interpolation on tables of the
     two projections -- 4-point for the bf16 result, no bf16 operand rounding at all, 6-point (error ~1e-6) for the
     fp32 result; 3x / 5x faster than the contractions); `GEO_TABLE` / `GEO_TABLE_F32` switch back."""
+    if _DIFF and torch.is_grad_enabled() and geo_embedding_train_ok(points, m):
+        return _GeoEmbedFn.apply(_c(points.detach().float()), m.proj_d.weight, m.proj_d.bias, m.proj_a.weight, m.proj_a.bias, m)
     if _DIFF or m.proj_d.weight.shape != (256, 256) or m.angle_k != 3 or points.shape[1] < 4:
         if not _DIFF:
             note_fallback("geo_embedding", f"hidden_dim {tuple(m.proj_d.weight.shape)} / angle_k {m.angle_k} / {points.shape[1]} points (kernel: 256, 3, >= 4)")
@@ -2049,3 +2051,76 @@ def linear_lnfold(xb, stats, lin, norm, gelu=False):
     with torch.cuda.device(xb.device):
         call("unopose_linear_bf16_lnfold", ptr(xb), ptr(w), ptr(d), ptr(c), ptr(stats), K // 256, float(norm.eps), ptr(out), rows, N, K, int(gelu), stream_ptr())
     return out
+
+
+# ---- round 6: the geometric embedding under autograd on the table kernels (csrc/embed.hip) ---------------------------------------------
+TRAIN_OWN_GEO = True  # A/B attribute: False = the op-by-op composite (geo_embedding_torch) under autograd
+
+
+def _geo_grid(m, rows, npoint):
+    """sinus(x_r) on the table grid x_r = (r - (npoint / 2 - 1)) / 4, (rows, 256) float64: T = S W^T is the table, dW = dT^T S its gradient."""
+    div = m.embedding.div_term.detach().double()
+    x = (torch.arange(rows, device=div.device, dtype=torch.float64) - float(npoint // 2 - 1)) / _GEO_HINV
+    om = x[:, None] * div[None, :]
+    return torch.stack([torch.sin(om), torch.cos(om)], dim=-1).reshape(rows, -1)
+
+
+class _GeoEmbedFn(torch.autograd.Function):
+    """GeometricStructureEmbedding.forward (transformer.py:303-350) with gradients for proj_d / proj_a (the points carry none: they are
+    data).  Forward = the 6-point table kernel of the fp32 eval path (tables rebuilt from the current weights), which also records the
+    arg-max of the three angle terms; backward = its mirror, scattering dE into a table-shaped gradient in LDS (csrc/embed.hip
+    geo_embed_table_bwd_kernel), then dW = dT^T S_grid and db = sum_r dT[r] on the host side (two 256-wide matmuls)."""
+
+    @staticmethod
+    def forward(ctx, points, wd, bd, wa, ba, m):
+        import math
+
+        npoint = 6
+        B, n, _ = points.shape
+        rows_a = int(math.floor(math.pi * float(m.factor_a) * _GEO_HINV)) + npoint + 1
+        rows_d = _GEO_D_RANGE * _GEO_HINV + npoint
+        sd, sa = _geo_grid(m, rows_d, npoint), _geo_grid(m, rows_a, npoint)
+        td = (sd @ wd.detach().double().t()).float().contiguous()
+        ta = (sa @ wa.detach().double().t()).float().contiguous()
+        bias = (bd.detach().float() + ba.detach().float()).contiguous()
+        wdf = wd.detach().float().contiguous()
+        div = m.embedding.div_term.detach().float().contiguous()
+        out = torch.empty(B, n, n, 256, dtype=torch.float32, device=points.device)
+        amax = torch.empty(B, n, n, 64, dtype=torch.int32, device=points.device)
+        knn = torch.empty(B, n, 3, dtype=torch.int32, device=points.device)
+        mean = int(m.reduction_a == "mean")
+        with torch.cuda.device(points.device):
+            call("unopose_geo_embedding_train_forward", ptr(points), B, n, ptr(td), rows_d, ptr(ta), rows_a, ptr(bias), ptr(wdf), ptr(div), _GEO_HINV,
+                 float(m.sigma_d), float(m.factor_a), mean, ptr(knn), ptr(out), ptr(amax), stream_ptr())
+        ctx.save_for_backward(points, knn, amax, sd, sa)
+        ctx.meta = (rows_d, rows_a, float(m.sigma_d), float(m.factor_a), mean, npoint)
+        return out
+
+    @staticmethod
+    def backward(ctx, dE):
+        points, knn, amax, sd, sa = ctx.saved_tensors
+        rows_d, rows_a, sigma_d, factor_a, mean, npoint = ctx.meta
+        B, n, _ = points.shape
+        rd_l = min(rows_d, 16 * _GEO_HINV + npoint - 1)
+        dE = _c(dE.float())
+        G = lib().unopose_geo_embedding_train_workgroups(B, n)
+        ws = torch.empty(G, rd_l + rows_a, 256, dtype=torch.float32, device=dE.device)
+        full = torch.zeros(rows_d, 256, dtype=torch.float32, device=dE.device)
+        past = torch.zeros(1, dtype=torch.int32, device=dE.device)
+        with torch.cuda.device(dE.device):
+            call("unopose_geo_embedding_train_backward", ptr(points), ptr(knn), B, n, rows_d, rows_a, _GEO_HINV, sigma_d, factor_a, mean, ptr(dE), ptr(amax),
+                 ptr(ws), ptr(full), ptr(past), stream_ptr())
+        torch._assert_async(past == 0, "geo embedding backward: a distance index past the table (the clouds are not radius-normalised)")
+        dT = ws.double().sum(0)
+        dTd = full.double()
+        dTd[:rd_l] += dT[:rd_l]
+        dTa = dT[rd_l:]
+        dwd, dwa = (dTd.t() @ sd).float(), (dTa.t() @ sa).float()
+        dbd, dba = dTd.sum(0).float(), dTa.sum(0).float()
+        return None, dwd, dbd, dwa, dba, None
+
+
+def geo_embedding_train_ok(points, m):
+    return (TRAIN_OWN_GEO and points.is_cuda and m.proj_d.weight.shape == (256, 256) and m.angle_k == 3 and points.shape[1] >= 4
+            and m.proj_d.weight.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and int(__import__("math").floor(__import__("math").pi * float(m.factor_a) * _GEO_HINV)) + 7 <= 80 - 6)
