@@ -348,10 +348,9 @@ class UNOPose(nn.Module):
         return ops.gather_rows(pts.float(), idx), ops.gather_rows(pts_lrf, idx), ops.gather_rows(feats, idx), idx
 
     # ---- training (M:25-76 with self.training; F:245-298) ----------------------------------------------------------
-    def _pixel_features_train(self, rgb, choose):
-        """(B,3,S,S), (B,Np) -> (B,Np,256) with the gradient path of the reference: the backbone's taps (under no_grad
-        and on the fused kernels when it is frozen, F:194-198) -> trainable up-projection -> bilinear resize evaluated
-        at the chosen pixels (= F.interpolate + gather, recorded by autograd)."""
+    def _lowres_train(self, rgb):
+        """(B,3,S,S) -> the up-projected low-resolution map (B, 4S/14, 4S/14, 256) with the gradient path of the reference: the backbone's
+        taps (under no_grad and on the fused kernels when it is frozen, F:194-198) -> trainable up-projection."""
         net = self.feature_extraction.rgb_net
         frozen = not any(p.requires_grad for p in net.vit.parameters())
         if frozen:
@@ -363,26 +362,60 @@ class UNOPose(nn.Module):
         side = H // 14
         z = torch.cat([o[:, 5:, :] for o in taps], dim=2).float()
         z = ops.linear(z, net.output_upscaling).reshape(B, side, side, 4, 4, net.out_dim)
-        low = z.permute(0, 1, 3, 2, 4, 5).reshape(B, 4 * side, 4 * side, net.out_dim)
-        return ops.bilinear_sample_pixels(low, choose, H, W)
+        return z.permute(0, 1, 3, 2, 4, 5).reshape(B, 4 * side, 4 * side, net.out_dim)
+
+    def _pixel_features_train(self, rgb, choose):
+        """(B,3,S,S), (B,Np) -> (B,Np,256): `_lowres_train` + the bilinear resize evaluated at the chosen pixels (= F.interpolate + gather,
+        recorded by autograd)."""
+        return ops.bilinear_sample_pixels(self._lowres_train(rgb), choose, rgb.shape[-2], rgb.shape[-1])
 
     def forward_train(self, end_points):
         tem_pts = end_points["tem1_pts"]
         radius = torch.norm(tem_pts - tem_pts.mean(1, keepdim=True), dim=2).max(1)[0]
         scale = radius.reshape(-1, 1, 1) + 1e-6
         dense_pm, tem_n = end_points["pts"] / scale, tem_pts / scale
-        idx_o = ops.furthest_point_sample(tem_n, self.fine_npoint)
-        dense_po = ops.gather_rows(tem_n, idx_o)
-        dense_fm = self._pixel_features_train(end_points["rgb"], end_points["rgb_choose"])
-        # features of the FPS-selected reference pixels only (the reference gathers all 5000 and then selects: same values,
+        # The index-only geometry -- the serial 6144 -> 4096 FPS of the reference cloud (3.7 ms at configs[3]'s shape), both global frames,
+        # both coarse FPS chains -- carries no gradient and needs the points alone: it runs on a side HIP stream underneath the backbone
+        # passes and the up-projections of the main stream (as `_features` does in eval); the main stream joins it before the first use.
+        main = torch.cuda.current_stream() if dense_pm.is_cuda else None
+        side = self._side_stream(dense_pm.device) if main is not None and self.internal_overlap else None
+        geo = {}
+
+        def geometry():
+            with torch.no_grad():
+                geo["idx_o"] = ops.furthest_point_sample(tem_n, self.fine_npoint)
+                geo["dense_po"] = ops.gather_rows(tem_n, geo["idx_o"])
+                geo["sel_choose"] = torch.gather(end_points["tem1_choose"], 1, geo["idx_o"].long())
+                geo["pm_lrf"] = ops.lrf_global(end_points["pts"], self.use_ref_rad)
+                geo["po_lrf"] = ops.lrf_global(tem_pts, self.use_ref_rad)  # NB App-E.1: frames of the FULL cloud, gathered with subset indices
+                geo["fps_m"] = ops.furthest_point_sample(dense_pm, self.coarse_npoint)
+                geo["fps_o"] = ops.furthest_point_sample(geo["dense_po"], self.coarse_npoint)
+
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                geometry()
+                for t in geo.values():
+                    t.record_stream(main)
+            low_m = self._lowres_train(end_points["rgb"])
+            low_o = self._lowres_train(end_points["tem1_rgb"])
+            main.wait_stream(side)
+        else:
+            geometry()
+            low_m = self._lowres_train(end_points["rgb"])
+            low_o = self._lowres_train(end_points["tem1_rgb"])
+        H, W = end_points["rgb"].shape[-2:]
+        dense_po = geo["dense_po"]
+        dense_fm = ops.bilinear_sample_pixels(low_m, end_points["rgb_choose"], H, W)
+        # features of the FPS-selected reference pixels only (the reference gathers all of them and then selects: same values,
         # and only the selected ones receive gradient there too)
-        dense_fo = self._pixel_features_train(end_points["tem1_rgb"], torch.gather(end_points["tem1_choose"], 1, idx_o.long()))
-        pm_lrf = ops.lrf_global(end_points["pts"], self.use_ref_rad)
-        po_lrf = ops.lrf_global(tem_pts, self.use_ref_rad)  # NB App-E.1: frames of the FULL cloud, gathered with subset indices
+        dense_fo = ops.bilinear_sample_pixels(low_o, geo["sel_choose"], H, W)
         B = dense_pm.size(0)
         bg_point = torch.ones(B, 1, 3, device=dense_pm.device)
-        sparse_pm, sparse_pm_lrf, sparse_fm, fps_idx_m = self._sample_wlrf(dense_pm, pm_lrf, dense_fm, self.coarse_npoint)
-        sparse_po, sparse_po_lrf, sparse_fo, fps_idx_o = self._sample_wlrf(dense_po, po_lrf, dense_fo, self.coarse_npoint)
+        fps_idx_m, fps_idx_o = geo["fps_m"], geo["fps_o"]
+        # (`_sample_wlrf`, U:156-177, with its FPS taken from the side stream)
+        sparse_pm, sparse_pm_lrf, sparse_fm = ops.gather_rows(dense_pm.float(), fps_idx_m), ops.gather_rows(geo["pm_lrf"], fps_idx_m), ops.gather_rows(dense_fm, fps_idx_m)
+        sparse_po, sparse_po_lrf, sparse_fo = ops.gather_rows(dense_po.float(), fps_idx_o), ops.gather_rows(geo["po_lrf"], fps_idx_o), ops.gather_rows(dense_fo, fps_idx_o)
         geo_m = self.geo_embedding(torch.cat([bg_point, sparse_pm_lrf], dim=1))
         geo_o = self.geo_embedding(torch.cat([bg_point, sparse_po_lrf], dim=1))
         end_points = self.coarse_point_matching(sparse_pm, sparse_fm, geo_m, sparse_po, sparse_fo, geo_o, radius, end_points)

@@ -593,7 +593,7 @@ TRAIN_OWN_GEMM = True  # A/B attribute: False = nn.Linear through the library
 # The persistent 256 x 256-tile kernels pay off from a few tens of GFLOP per launch (measured at the training shapes: a
 # 32 776 x 256 x 256 linear takes 38 us on csrc/gemm_f32.hip and 17 us on the library, the 4096 x 3072 x 4096 up-projection
 # 0.31 vs 0.86 ms): below this many flops the training step keeps nn.Linear.
-TRAIN_OWN_GEMM_MIN_FLOP = 2e10
+TRAIN_OWN_GEMM_MIN_FLOP = 4e9  # (round 6 same-box A/B of the training step: 2e10 121-124 ms, 1e10 119-121, 4e9 118.2, 1e9 117-120: scripts/ubench/train_ab.py)
 
 
 def _transposed_weights(lin, kind):
