@@ -134,8 +134,11 @@ def test_no_library_convolution_or_batchnorm_in_the_training_step():
     step()  # caches
     lib, names = library_ops()
     assert lib == [], lib
-    for k in ("conv1x1_f32_kernel", "conv1x1_wgrad_kernel", "bn_relu_maxpool_kernel", "bn_relu_maxpool_bwd_apply_kernel", "bn_relu_apply_kernel"):
+    for k in ("conv1x1_f32_kernel", "conv1x1_wgrad_kernel", "bn_relu_maxpool_kernel", "bn_relu_maxpool_bwd_apply_kernel", "bn_relu_apply_kernel",
+              # round 6: the geometric embedding forward + backward (no scatter_ of the composite's max backward, no sin / cos passes)
+              "geo_embed_table_kernel", "geo_embed_table_bwd_kernel"):
         assert any(k in n for n in names), k
+    assert not any(n in ("aten::scatter_", "aten::sin", "aten::cos") for n in names), [n for n in names if n in ("aten::scatter_", "aten::sin", "aten::cos")]
     ops.TRAIN_OWN_CONV, ops.USE_FUSED_BN_RELU = False, False
     try:
         lib, _ = library_ops()

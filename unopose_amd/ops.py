@@ -2059,10 +2059,16 @@ TRAIN_OWN_GEO = True  # A/B attribute: False = the op-by-op composite (geo_embed
 
 def _geo_grid(m, rows, npoint):
     """sinus(x_r) on the table grid x_r = (r - (npoint / 2 - 1)) / 4, (rows, 256) float64: T = S W^T is the table, dW = dT^T S its gradient."""
-    div = m.embedding.div_term.detach().double()
-    x = (torch.arange(rows, device=div.device, dtype=torch.float64) - float(npoint // 2 - 1)) / _GEO_HINV
-    om = x[:, None] * div[None, :]
-    return torch.stack([torch.sin(om), torch.cos(om)], dim=-1).reshape(rows, -1)
+    div = m.embedding.div_term
+    key = (rows, npoint, div._version, div.data_ptr())
+    cache = m.__dict__.setdefault("_geo_grid_cache", {})
+    if key not in cache:  # (depends on the frequencies only: built once, not per training step)
+        d64 = div.detach().double()
+        x = (torch.arange(rows, device=div.device, dtype=torch.float64) - float(npoint // 2 - 1)) / _GEO_HINV
+        om = x[:, None] * d64[None, :]
+        cache.clear() if len(cache) > 8 else None
+        cache[key] = torch.stack([torch.sin(om), torch.cos(om)], dim=-1).reshape(rows, -1)
+    return cache[key]
 
 
 class _GeoEmbedFn(torch.autograd.Function):
