@@ -30,11 +30,14 @@ def logged(name, *a):
     return orig(name, *a)
 import unopose_amd.ops as ops
 _lib.call = logged
-ops.call = logged
+FAMS = (ops.linear, ops.attention, ops.geometry, ops.sampling, ops.pose, ops.train)  # (each family module binds `call` at import)
+for fam in FAMS:
+    fam.call = logged
 with torch.autocast("cuda", dtype=torch.bfloat16):
     model(dict(ep))
 _lib.call = orig
-ops.call = orig
+for fam in FAMS:
+    fam.call = orig
 
 def timeit(f, n=20):
     for _ in range(3): f()

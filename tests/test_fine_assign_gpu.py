@@ -82,7 +82,7 @@ def test_fused_fine_pose_vs_oracle(B, N1, N2):
 def test_fused_assignment_vs_streaming_kernels(B, N1, N2):
     """Labels, row weights and soft correspondences against posehead.hip's passes over the stored fp32 matrix."""
     from unopose_amd import ops
-    from unopose_amd.ops import call, ptr, stream_ptr
+    from unopose_amd._lib import call, ptr, stream_ptr
 
     gen = torch.Generator().manual_seed(7 + N1)
     f1, f2, score, p1, p2, _, _ = constructed_features(B, N1, N2, gen, n_bg=40)
@@ -123,7 +123,7 @@ def test_fused_assignment_vs_streaming_kernels(B, N1, N2):
 
 
 def test_fine_assign_rejects_bad_arguments():
-    from unopose_amd.ops import call, ptr, stream_ptr
+    from unopose_amd._lib import call, ptr, stream_ptr
     x = torch.zeros(64, device="cuda")
     with pytest.raises(RuntimeError, match="feature width"):
         call("unopose_fine_assign", ptr(x), ptr(x), 1, 2, 2, 128, 10.0, ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x),

@@ -110,7 +110,7 @@ def test_model_forward_sparse_equals_dense_upprojection():
 
 
 def test_upproj_plan_rejects_small_capacity():
-    from unopose_amd.ops import call, ptr, stream_ptr
+    from unopose_amd._lib import call, ptr, stream_ptr
     x = torch.zeros(1 << 16, dtype=torch.int32, device="cuda")
     ch = torch.zeros(1, 8, dtype=torch.int64, device="cuda")
     with pytest.raises(RuntimeError, match="cap_rows"):

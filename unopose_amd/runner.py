@@ -201,7 +201,7 @@ def broadcast_module_(module, src=0):
         flat = bcast(torch.cat([t.detach().reshape(-1).to(wire) for t in group]))
         off = 0
         with torch.no_grad():  # in-place copy on the parameter itself: bumps `_version`, which keys every derived-weight
-            for t in group:    # cache in ops.py (a `.data` alias would leave them stale)
+            for t in group:    # caches in ops/ (a `.data` alias would leave them stale)
                 n = t.numel()
                 t.copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
                 off += n
