@@ -15,7 +15,7 @@ batch, _, _ = make_batch(32, 2048, 5000, img, seed=1, device=dev)
 batch["coarse_rand"] = torch.rand(32, 18000, device=dev)
 with torch.autocast("cuda", dtype=torch.bfloat16):
     model(dict(batch))
-sites = collections.defaultdict(lambda: [0, 0])
+sites = collections.defaultdict(lambda: [0, 0, set()])
 VIEW = ("aten.view", "aten.reshape", "aten.expand", "aten.slice", "aten.select", "aten.unsqueeze", "aten.squeeze", "aten.transpose", "aten.permute",
         "aten.t.default", "aten.alias", "aten.detach", "aten._unsafe_view", "aten.as_strided", "aten.unbind", "aten.split", "aten.sym_", "aten.is_",
         "aten.empty", "aten._local_scalar", "aten.record_stream", "aten.unfold", "aten.lift_fresh")
@@ -33,6 +33,7 @@ class Log(TorchDispatchMode):
             s = sites[(where, name)]
             s[0] += 1
             s[1] += nbytes
+            s[2].update(f"{tuple(o.shape)}:{str(o.dtype)[6:]}" for o in outs if torch.is_tensor(o) and o.is_cuda and o.numel() > 1e5)
         return out
 
 
@@ -41,8 +42,8 @@ with torch.autocast("cuda", dtype=torch.bfloat16), Log():
 torch.cuda.synchronize()
 tot = sum(v[0] for v in sites.values())
 print(f"{tot} aten ops that launch work, {sum(v[1] for v in sites.values()) / 1e6:.0f} MB written")
-for (where, name), (n, b) in sorted(sites.items(), key=lambda kv: -kv[1][1])[:70]:
-    print(f"{b / 1e6:9.1f} MB {n:4d} x  {name:42s} {where}")
+for (where, name), (n, b, shp) in sorted(sites.items(), key=lambda kv: -kv[1][1])[:70]:
+    print(f"{b / 1e6:9.1f} MB {n:4d} x  {name:42s} {where}  {' '.join(sorted(shp))}")
 print("---- by call count")
-for (where, name), (n, b) in sorted(sites.items(), key=lambda kv: -kv[1][0])[:40]:
+for (where, name), (n, b, shp) in sorted(sites.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f"{b / 1e6:9.1f} MB {n:4d} x  {name:42s} {where}")

@@ -22,6 +22,7 @@ STACKED_FINE = True  # (module attributes: A/Bs set them from the script) the 2B
 PE_UNDER_COARSE = True
 GEOM_UNDER_VIT = 1  # 1: FPS-196 / gathers, 2: + frames + embedding
 LRF_UNDER_VIT = True  # the two global frames on the side stream as well
+TRAIN_PE_UNDER_COARSE = True  # training: both clouds' PE groups (forward and backward) on the side stream underneath the coarse stage
 
 
 def _scores(scores, n1):
@@ -120,14 +121,22 @@ class FinePointMatchingOneRef(nn.Module):
             [SparseToDenseTransformer(d, 4, cfg.focusing_factor) for _ in range(self.nblock)])
         self.taps = None  # assign a dict to receive (f1, f2, atten, score) of the next forward (tests)
 
-    def forward_train(self, p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points):
+    def forward_train(self, p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points, pe_ahead=None):
         """Fi:58-117, training branch.  The positional encoding is evaluated per cloud, query first (its BatchNorm layers
-        use -- and update -- batch statistics per call, exactly as the reference's two PE calls do)."""
+        use -- and update -- batch statistics per call, exactly as the reference's two PE calls do).  `pe_ahead` = (grouped features of the
+        query cloud in the start pose, of the reference cloud, the stream they were computed on): `UNOPose.forward_train` evaluates
+        them underneath the coarse stage (they depend on the points and the injected start pose alone); only the projection runs here."""
         B, n1 = p1.shape[:2]
-        p1_ = (p1 - end_points["init_t"].unsqueeze(1)) @ end_points["init_R"] if "init_R" in end_points else p1
         bg = self.bg_token.expand(B, -1, -1)
-        f1 = torch.cat([bg, ops.linear(f1, self.in_proj) + self.PE(p1_)], dim=1)
-        f2 = torch.cat([bg, ops.linear(f2, self.in_proj) + self.PE(p2)], dim=1)
+        if pe_ahead is None:
+            p1_ = (p1 - end_points["init_t"].unsqueeze(1)) @ end_points["init_R"] if "init_R" in end_points else p1
+            pe1, pe2 = self.PE(p1_), self.PE(p2)
+        else:
+            g1, g2, side = pe_ahead
+            torch.cuda.current_stream().wait_stream(side)
+            pe1, pe2 = self.PE.project(g1), self.PE.project(g2)
+        f1 = torch.cat([bg, ops.linear(f1, self.in_proj) + pe1], dim=1)
+        f2 = torch.cat([bg, ops.linear(f2, self.in_proj) + pe2], dim=1)
         attens, scores, sals = [], [], []
         for blk, head in zip(self.transformers, self.score_heads):
             f1, f2 = blk(f1, geo1, fps_idx1, f2, geo2, fps_idx2)
@@ -143,7 +152,7 @@ class FinePointMatchingOneRef(nn.Module):
 
     def forward(self, p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points, pe2_groups=None):
         if self.training:
-            return self.forward_train(p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points)
+            return self.forward_train(p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points, pe_ahead=pe2_groups)
         B, n1 = p1.shape[:2]
         if "init_R" in end_points and "init_t" in end_points:
             p1_ = ops.rigid_rows(p1, end_points["init_t"], end_points["init_R"])
@@ -416,11 +425,29 @@ class UNOPose(nn.Module):
         # (`_sample_wlrf`, U:156-177, with its FPS taken from the side stream)
         sparse_pm, sparse_pm_lrf, sparse_fm = ops.gather_rows(dense_pm.float(), fps_idx_m), ops.gather_rows(geo["pm_lrf"], fps_idx_m), ops.gather_rows(dense_fm, fps_idx_m)
         sparse_po, sparse_po_lrf, sparse_fo = ops.gather_rows(dense_po.float(), fps_idx_o), ops.gather_rows(geo["po_lrf"], fps_idx_o), ops.gather_rows(dense_fo, fps_idx_o)
+        # The fine matcher's positional encoding up to its max-pool (grouping + SharedMLP: HBM-bound streams over multi-GB activations, own
+        # kernels only) needs the points and the fine stage's start pose -- which in training is the ground truth plus noise, not the
+        # coarse network's output (C:46-107) -- so both clouds' halves run on the side stream underneath the latency-bound coarse stage,
+        # forward and -- autograd replays every op on the stream of its forward -- backward.  Query cloud first: the BatchNorm layers
+        # use and update batch statistics per call in the reference's order.
+        pe_ahead = None
+        if side is not None and TRAIN_PE_UNDER_COARSE:
+            if "aug_pose" not in end_points:  # (the draw the coarse stage would make after its blocks: nothing else draws in between)
+                end_points["aug_pose"] = aug_pose_noise(end_points["rotation_label"], end_points["translation_label"] / (radius.reshape(-1, 1) + 1e-6))
+            init_R, init_t = end_points["aug_pose"]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                PE = self.fine_point_matching.PE
+                g1 = PE.groups((dense_pm - init_t.unsqueeze(1)) @ init_R)
+                g2 = PE.groups(dense_po)
+            g1.record_stream(main)
+            g2.record_stream(main)
+            pe_ahead = (g1, g2, side)
         geo_m = self.geo_embedding(torch.cat([bg_point, sparse_pm_lrf], dim=1))
         geo_o = self.geo_embedding(torch.cat([bg_point, sparse_po_lrf], dim=1))
         end_points = self.coarse_point_matching(sparse_pm, sparse_fm, geo_m, sparse_po, sparse_fo, geo_o, radius, end_points)
         return self.fine_point_matching(dense_pm, dense_fm, geo_m, fps_idx_m, dense_po, dense_fo, geo_o, fps_idx_o, radius,
-                                        end_points)
+                                        end_points, pe2_groups=pe_ahead)
 
     def forward(self, end_points):
         if self.training:
