@@ -38,3 +38,9 @@ mkdir -p $R/profiles && cp $R/gpurun_out/${TAG}_pmc_summary.json $R/profiles/   
 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench_n1_bf16_s518.json 2> $R/gpurun_out/${TAG}_bench_n1_bf16_s518.log
 python3 $R/bench.py --img 224 > $R/gpurun_out/${TAG}_bench_n1_bf16_s224.json 2>/dev/null
 tail -c 1500 $R/gpurun_out/${TAG}_bench_n1_bf16_s518.json
+# round 6: the training step (kernel statistics + the bench line of `--train`)
+rm -rf /tmp/kt
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python3 $R/bench.py --train --steps 3 --warmup 2 > /dev/null 2>&1
+python3 $R/scripts/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) 80 > $R/gpurun_out/${TAG}_train_kernel_stats.csv
+python3 $R/bench.py --train --steps 10 --warmup 3 > $R/gpurun_out/${TAG}_train_n1_fp32_4096.json 2>/dev/null
+python3 $R/bench.py --train --train-pts 2048 --steps 10 --warmup 3 > $R/gpurun_out/${TAG}_train_n1_fp32_2048.json 2>/dev/null

@@ -275,9 +275,12 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
     __syncthreads();
     ti = __builtin_amdgcn_readfirstlane(mbox[0]);
   }
-  if (EPI == 5 && stagger > 0 && (slot & 1)) {
-    // STAGGER (see gemm.hip): every second workgroup of an XCD starts `stagger` ticks of the 100 MHz clock late -- about half a tile -- so that
-    // the HBM-sized residual epilogues of one half of the chip run beside the K loops of the other half instead of all 256 at once
+  if (EPI == 5 && stagger > 0 && ((slot / tiles_n) & 1)) {
+    // STAGGER (see gemm.hip): every second GROUP of tiles_n workgroups of an XCD -- the workgroups that draw the tiles of one row panel, i.e.
+    // share an A panel through L2, stay together -- starts `stagger` ticks of the 100 MHz clock late (about half a tile), so that the
+    // HBM-sized residual epilogues of one half of the chip run beside the K loops of the other half instead of all 256 at once
+    // (proj at M = 87 936: 208 -> 190 us; fc2 459 -> 443 us).  The longer, contended epilogues let the sharers of a panel drift apart in
+    // K all the same: fc2's fabric reads are 1.5 GB per launch against 0.74 GB with the plain epilogue (profiles/r06_pmc_summary.json).
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     while ((int64_t)(__builtin_amdgcn_s_memrealtime() - t0) < (int64_t)stagger) __builtin_amdgcn_s_sleep(8);
   }
