@@ -24,6 +24,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (the same default unopose_amd/__init__.py sets, here because this process touches the GPU before it imports the package: the runner
+#  uses up to nine streams, the HIP runtime maps them onto 4 hardware queues by default and streams sharing a queue serialise)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def parse(argv=None):

@@ -22,6 +22,7 @@ STACKED_FINE = True  # (module attributes: A/Bs set them from the script) the 2B
 PE_UNDER_COARSE = True
 GEOM_UNDER_VIT = 1  # 1: FPS-196 / gathers, 2: + frames + embedding
 LRF_UNDER_VIT = True  # the two global frames on the side stream as well
+_SIDE_STREAMS = {}  # (device index, launch stream) -> its helper stream, for the life of the process
 TRAIN_PE_UNDER_COARSE = True  # training: both clouds' PE groups (forward and backward) on the side stream underneath the coarse stage
 
 
@@ -343,13 +344,13 @@ class UNOPose(nn.Module):
 
     def _side_stream(self, device):
         """The helper stream paired with the CURRENT stream (one per launch stream, so several forwards in flight on
-        different streams do not funnel their side work through one queue)."""
+        different streams do not funnel their side work through one queue).  Process-wide, not per model: streams map onto a few
+        hardware queues for good, and every model a process builds must reuse them (pipeline._STREAM_POOL)."""
         cur = torch.cuda.current_stream(device)
-        pool = self.__dict__.setdefault("_side_streams", {})
-        key = (device, cur.cuda_stream)
-        if key not in pool:
-            pool[key] = torch.cuda.Stream(device=device)
-        return pool[key]
+        key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), cur.cuda_stream)
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        return _SIDE_STREAMS[key]
 
     def _sample_wlrf(self, pts, pts_lrf, feats, npoint):
         """U:156-177 (gathers done in (B,N,C) layout)."""

@@ -24,6 +24,21 @@ import torch
 from . import ops
 
 
+# HIP streams are a process-wide resource that maps onto a handful of hardware queues (GPU_MAX_HW_QUEUES = 4 by default): every stream
+# a process has EVER created keeps its queue assignment, and two streams that share a queue serialise.  A process that builds one pipeline
+# after another (bench.py's legs, a runner that is re-created per dataset) must therefore not mint new streams each time -- measured in
+# round 6: the bounded training leg at the end of bench.py's default run took 119 ms per step against 108 ms in a process of its own, its
+# side stream sharing a queue with the main one.  All pipelines of a process draw from this pool (they are used one at a time).
+_STREAM_POOL = {}
+
+
+def _pool_streams(dev, kind, n, priority=0):
+    pool = _STREAM_POOL.setdefault((dev.index, kind), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev, priority=priority))
+    return pool[:n]
+
+
 class Ticket:
     """One submitted forward: `result()` hands back the end_points dict, ordered after the forward on the caller's
     current stream (no host synchronisation)."""
@@ -66,7 +81,7 @@ class PipelinedForward:
         if self.depth > 1 and not (ops.HIP_GEMM_ALL and ops.USE_HIP_GEMM):
             raise RuntimeError("more than one forward in flight needs ops.HIP_GEMM_ALL (library stream-K GEMMs spin on partner "
                                "workgroups and can hang when forwards overlap)")
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.depth)] if self.depth > 1 else [None]
+        self.streams = _pool_streams(dev, "pipe", self.depth) if self.depth > 1 else [None]
         self._saved_overlap = getattr(model, "internal_overlap", None)
         if hasattr(model, "internal_overlap"):  # measured: with a second forward in flight the in-forward overlaps cost 1.6 %
             model.internal_overlap = self.depth == 1
@@ -118,7 +133,7 @@ class PipelinedForward:
         self.last_mode = "stages" if use_stages else "whole"  # what this submit chose (bench.py reports it)
         if use_stages:
             if self._stage_streams is None:
-                self._stage_streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device, priority=-1)]
+                self._stage_streams = [_pool_streams(self.device, "features", 1)[0], _pool_streams(self.device, "matching", 1, priority=-1)[0]]
             for ss in self._stage_streams:  # the caches the very first forward built (in EITHER mode) are ordered before this stream's first use
                 if self._warm is not None and ss.cuda_stream not in self._warm_seen:
                     ss.wait_event(self._warm)
