@@ -19,7 +19,7 @@ def timed(name, *a):
     rec.append(((time.perf_counter() - t0) * 1e6, name, [int(x) if isinstance(x, int) else None for x in a]))
     return r
 _lib.call = timed
-for fam in (ops.linear, ops.attention, ops.geometry, ops.sampling, ops.pose, ops.train):  # (each family module binds `call` at import)
+for fam in (ops.dense, ops.attention, ops.geometry, ops.sampling, ops.pose, ops.train):  # (each family module binds `call` at import)
     fam.call = timed
 import unopose_amd.model.modules as mm
 for m in (mm,):

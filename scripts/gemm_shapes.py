@@ -30,7 +30,7 @@ def logged(name, *a):
     return orig(name, *a)
 import unopose_amd.ops as ops
 _lib.call = logged
-FAMS = (ops.linear, ops.attention, ops.geometry, ops.sampling, ops.pose, ops.train)  # (each family module binds `call` at import)
+FAMS = (ops.dense, ops.attention, ops.geometry, ops.sampling, ops.pose, ops.train)  # (each family module binds `call` at import)
 for fam in FAMS:
     fam.call = logged
 with torch.autocast("cuda", dtype=torch.bfloat16):

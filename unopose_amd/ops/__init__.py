@@ -1,5 +1,5 @@
 """Fused operators of the MI355X UNOPose forward (C ABI part 2) on torch tensors, by family:
-    linear     nn.Linear on the hand-written GEMMs, LayerNorm / LayerScale glue, the residual + LayerNorm fold, the trainable form
+    dense      nn.Linear on the hand-written GEMMs, LayerNorm / LayerScale glue, the residual + LayerNorm fold, the trainable form
     attention  ViT attention, RPE / cross token attention, focused linear attention
     geometry   frames, Procrustes, radius normalisation, gathers, geometric embedding, positional encoding
     sampling   pixel sampling and the sparse up-projection
@@ -16,7 +16,7 @@ from .common import (  # noqa: F401
     _c, differentiable, is_differentiable, _fallbacks_seen, note_fallback, _params_key, _SPLIT_MEMO, _MUTATION_EPOCH, note_mutation,
     clear_split_memo, _aligned16, _no_autograd, _f32_path, _own_f32, _own_glue,
 )
-from .linear import (  # noqa: F401
+from .dense import (  # noqa: F401
     linear_backend, _bf16_weights, linear_bf16_hip, own_gemm_ok, bf16_linear_2d, f32x3_ok, split_f32, _f32x3_weights, linear_f32x3,
     linear_f32x3_bf16, linear_f32_raw, _transposed_weights, _LinearFn, _ZERO_BIAS, _zero_bias, linear_train, _lin, mlp, linear,
     ffn_add_layernorm, linear_add_layernorm, patch_embed, vit_prologue_ok, vit_prologue, bmm_nt_f32, score_head, add_layernorm,

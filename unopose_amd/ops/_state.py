@@ -8,7 +8,7 @@ pinned by a test (tests/test_pipeline_gpu.py: no library GEMM on the eval path; 
 # frames), whose outputs carry no gradient in the reference either, keep running on HIP.  UNOPose.forward enters it when `model.training`.
 _DIFF = False
 
-# ---- linear layers (ops/linear.py)
+# ---- linear layers (ops/dense.py)
 USE_HIP_GEMM = True  # own bf16 GEMM (csrc/gemm.hip + gemm_small.hip) for the linears; False: hipBLASLt through torch
 HIP_GEMM_ALL = True  # every shape the tiling admits on the own GEMM: no library stream-K kernel (inter-workgroup waits) on the path, which
                      # is what makes two forwards in flight safe (pipeline.py)
@@ -24,7 +24,7 @@ GEO_TABLE_F32 = True  # fp32 result through the 6-point table kernel; False: the
 USE_SPARSE_UPPROJ = True  # only the map cells the chosen pixels' bilinear taps read are up-projected (csrc/upproj.hip)
 USE_FUSED_FINE = True  # bf16 fine stage without the (B, N1 + 1, N2 + 1) similarity (csrc/fineassign.hip)
 
-# ---- training step (ops/train.py, ops/linear.py `_LinearFn`, ops/geometry.py `_GeoEmbedFn`)
+# ---- training step (ops/train.py, ops/dense.py `_LinearFn`, ops/geometry.py `_GeoEmbedFn`)
 USE_FUSED_INFONCE = True  # False: two F.cross_entropy calls
 USE_FUSED_BN_RELU = True  # False: nn.BatchNorm2d (MIOpen) + F.relu in the PE's SharedMLP under train()
 TRAIN_FUSED_SALIENCY = True  # False: the two softmax + matmul pairs of the reference through torch

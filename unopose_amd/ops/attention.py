@@ -8,7 +8,7 @@ import torch.nn.functional as F
 from .._lib import call, lib, ptr, stream_ptr
 from . import _state as st
 from .common import _c, _own_f32, _own_glue, _params_key, note_fallback
-from .linear import _lin, bf16_linear_2d, bmm_nt_f32, linear, linear_f32_raw
+from .dense import _lin, bf16_linear_2d, bmm_nt_f32, linear, linear_f32_raw
 
 
 def vit_attention(qkv, heads):

@@ -10,7 +10,7 @@ from .._lib import call, check_f32, lib, ptr, stream_ptr
 from ..pointnet2 import _ext
 from . import _state as st
 from .common import _c, _own_glue, _params_key, note_fallback
-from .linear import _lin, mlp
+from .dense import _lin, mlp
 
 
 def lrf_global(pts, use_ref_rad=False):

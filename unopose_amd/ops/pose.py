@@ -7,7 +7,7 @@ from .._lib import call, check_f32, ptr, stream_ptr
 from . import _state as st
 from .common import _c, _own_f32, _own_glue
 from .geometry import pairwise_distance, weighted_procrustes
-from .linear import bmm_nt_f32
+from .dense import bmm_nt_f32
 
 
 def overlap_scores(scores, n1):

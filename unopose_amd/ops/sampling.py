@@ -5,7 +5,7 @@ import torch
 from .._lib import call, ptr, stream_ptr
 from . import _state as st
 from .common import _c, note_mutation
-from .linear import _bf16_weights
+from .dense import _bf16_weights
 
 
 def bilinear_sample_native(z, choose, H, W, out=None, tok_offset=0):
