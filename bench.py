@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # (the same default unopose_amd/__init__.py sets, here because this process touches the GPU before it imports the package: the runner
 #  uses up to nine streams, the HIP runtime maps them onto 4 hardware queues by default and streams sharing a queue serialise)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 def parse(argv=None):
@@ -43,8 +43,7 @@ def parse(argv=None):
     ap.add_argument("--inflight", type=int, default=2,
                     help="forwards in flight per GPU (unopose_amd.pipeline.PipelinedForward): consecutive steps are dealt "
                          "round-robin over this many HIP streams; a step is still one forward over one batch, and the "
-                         "latency-bound matcher of one batch runs underneath the ViT of the next.  1 = one stream.  The "
-                         "fp32 path always runs one at a time")
+                         "latency-bound matcher of one batch runs underneath the ViT of the next.  1 = one stream")
     ap.add_argument("--stages", default="auto", choices=["auto", "0", "1"],
                     help="PipelinedForward(stages=...): 1 = ViT half and matcher half of every forward on two streams, 0 = whole "
                          "forwards side by side, auto = by ViT size")
@@ -441,7 +440,7 @@ def contract_224_leg(dev, sync, steps=20, warm=3):
     batch["coarse_rand"] = torch.rand(B, 18000, device=dev)
     out = {"workload": "UNOPose.forward at the reference's test contract: instance batch 16, 224x224 crops, 2048 query pts, 5000->2048 "
                        "reference pts (configs/main_cfg.py:87-92,130-131)", "batch": B, "steps": steps, "warmup": warm}
-    for name, amp, depth in (("fp32", None, 1), ("bf16", torch.bfloat16, 2)):
+    for name, amp, depth in (("fp32", None, 2), ("bf16", torch.bfloat16, 2)):
         pipe = PipelinedForward(model, depth=depth, autocast_dtype=amp)
         dt, o = _timed_steps(pipe, lambda: dict(batch), steps, warm, sync)
         pipe.close()
@@ -701,7 +700,7 @@ def main():
     if not args.dry_run and graphed is None:
         from unopose_amd.pipeline import PipelinedForward
 
-        pipe = PipelinedForward(model, depth=args.inflight if amp else 1, autocast_dtype=torch.bfloat16 if amp else None, timing=True,
+        pipe = PipelinedForward(model, depth=args.inflight, autocast_dtype=torch.bfloat16 if amp else None, timing=True,
                                 stages="auto" if args.stages == "auto" else bool(int(args.stages)))
         args.inflight = pipe.depth
 
@@ -808,33 +807,24 @@ def main():
     if rank == 0 and world == 1 and not args.dry_run:
         if amp and not args.no_fp32 and graphed is None:
             # the reference's default precision (configs/main_cfg.py:87-89: test.amp.enabled=False) through the same runner object as
-            # `--dtype fp32` (PipelinedForward without autocast: one forward at a time): 3 warm-ups, 20 steps, HIP events around every
-            # step (median / p10 / p90) beside the wall-clock rate
+            # `--dtype fp32` (PipelinedForward without autocast -- pipelined like the bf16 path since round 6: every fp32 GEMM is an own
+            # kernel): 3 warm-ups, 20 steps, the HIP-event step period (median / p10 / p90) beside the wall-clock rate
             k = 20 if args.steps >= 20 else max(3, args.steps)
             if pipe is not None:
                 pipe.close()
             from unopose_amd.pipeline import PipelinedForward
 
-            pipe32 = PipelinedForward(model, depth=1, autocast_dtype=None)
-            step32 = lambda: pipe32.submit(dict(batch)).result  # noqa: E731
-            for _ in range(3):
-                step32()
-            sync()
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
-            t1 = time.perf_counter()
-            for a, b in evs:
-                a.record()
-                o32 = step32()
-                b.record()
-            sync()
-            d32 = time.perf_counter() - t1
-            e32 = (o32()["pred_R"] - R_gt).abs().amax(dim=(1, 2))
-            per = sorted(a.elapsed_time(b) for a, b in evs)
+            pipe32 = PipelinedForward(model, depth=args.inflight, autocast_dtype=None, timing=True)
+            d32, o32 = _timed_steps(pipe32, lambda: dict(batch), k, 3, sync)
+            e32 = (o32["pred_R"] - R_gt).abs().amax(dim=(1, 2))
+            h32, d_ = pipe32.history[-k:], pipe32.depth
+            per = sorted(h32[i][1].elapsed_time(h32[i + d_][1]) / d_ for i in range(len(h32) - d_))  # completion-to-completion period, as for the headline
             q32 = lambda f: per[min(len(per) - 1, int(round(f * (len(per) - 1))))]  # noqa: E731
+            pipe32.close()
             log("fp32 leg done")
             res["fp32"] = {"value": B * k / d32, "unit": "pairs/s", "ms_per_step": d32 / k * 1e3, "steps": k, "warmup": 3,
                            "step_ms_hip_events": {"median": q32(0.5), "p10": q32(0.1), "p90": q32(0.9)},
-                           "median_rot_err_vs_gt": e32.median().item(),
+                           "forwards_in_flight": d_, "median_rot_err_vs_gt": e32.median().item(),
                            "arithmetic": "bf16x3 hi/lo split on the matrix cores with fp32 accumulation (hi.hi + hi.lo + lo.hi: ~2^-17 relative per "
                                          "product, not IEEE fp32's 2^-24) in every linear layer and attention contraction; geometry (FPS, ball query, "
                                          "frames, Procrustes, assignment statistics) and the small contractions of bmm_f32 in exact fp32; the "

@@ -96,6 +96,6 @@ def test_package_import_defaults_the_hardware_queue_count_without_overriding_the
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     env["PYTHONPATH"] = root
-    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "8"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "16"
     env["GPU_MAX_HW_QUEUES"] = "2"
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "2"

@@ -54,15 +54,40 @@ def test_two_in_flight_equals_one_at_a_time(model, stages):
 
 
 @torch.no_grad()
-def test_fp32_runs_one_at_a_time_and_library_gemms_are_refused(model):
+def test_fp32_pipelines_like_bf16_and_library_gemms_are_refused(model):
+    """Round 6: the fp32 path (the reference's default precision) runs two forwards in flight as well -- every fp32 GEMM of the eval path is an
+    own kernel (`ops.USE_F32X3`; test_no_library_gemm_on_the_eval_path[fp32]) -- with results bit-equal to one at a time; with the
+    own fp32 GEMM switched off it falls back to one at a time; a linear the own kernels do not take raises while forwards overlap."""
     from unopose_amd import ops
     from unopose_amd.pipeline import PipelinedForward
 
-    p32 = PipelinedForward(model, depth=2, autocast_dtype=None)
-    assert p32.depth == 1 and p32.streams == [None]
-    ep = batches(1, B=2)[0]
-    out = p32.submit(dict(ep)).result()
-    assert out["pred_R"].dtype == torch.float32 and torch.isfinite(out["pred_R"]).all()
+    eps = batches(4, B=2)
+    seq = PipelinedForward(model, depth=1, autocast_dtype=None)
+    ref = [{k: seq.submit(dict(ep)).wait()[k].clone() for k in KEYS} for ep in eps]
+    assert ref[0]["pred_R"].dtype == torch.float32
+    for stages in (False, True):
+        p32 = PipelinedForward(model, depth=2, autocast_dtype=None, stages=stages)
+        assert p32.depth == 2 and len(p32.streams) == 2
+        tickets = [p32.submit(dict(ep)) for ep in eps]
+        for i in (2, 0, 3, 1):
+            out = tickets[i].result()
+            for k in KEYS:
+                assert torch.equal(out[k], ref[i][k]), (stages, i, k)
+        p32.close()
+    old = ops.USE_F32X3
+    ops.USE_F32X3 = False
+    try:
+        p1 = PipelinedForward(model, depth=2, autocast_dtype=None)
+        assert p1.depth == 1 and p1.streams == [None]
+    finally:
+        ops.USE_F32X3 = old
+    lin = torch.nn.Linear(100, 100).cuda()  # N % 256 != 0: not a shape of csrc/gemm_f32.hip
+    prev, ops.FORBID_LIBRARY_BF16_GEMM = ops.FORBID_LIBRARY_BF16_GEMM, True
+    try:
+        with pytest.raises(RuntimeError, match="library GEMM"):
+            ops.linear(torch.randn(64, 100, device="cuda"), lin)
+    finally:
+        ops.FORBID_LIBRARY_BF16_GEMM = prev
     old = ops.HIP_GEMM_ALL
     ops.HIP_GEMM_ALL = False
     try:

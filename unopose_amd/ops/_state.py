@@ -16,7 +16,7 @@ USE_F32X3 = True  # fp32 linears on csrc/gemm_f32.hip (hi / lo-split bf16 operan
 USE_FUSED_LINEAR_LN = True  # linear + residual + LayerNorm of the matcher's layers in one GEMM epilogue
 USE_LN_FOLD = True  # round 6: the ViT's residual + LayerNorm passes folded into the GEMM epilogues (csrc/gemm_kernel.h EPI 5 / 6 / 7);
                     # False: scale_residual_layernorm_ between the GEMMs (round 5's path).  A/B: profiles/r06_ln_fold_ab.txt
-FORBID_LIBRARY_BF16_GEMM = False  # set by pipeline.PipelinedForward around forwards it overlaps: the bf16 library fall-back of `linear` raises
+FORBID_LIBRARY_BF16_GEMM = False  # set by pipeline.PipelinedForward around forwards it overlaps: the library fall-back of `linear` (bf16 and fp32) raises
 
 # ---- geometry / sampling / pose heads
 GEO_TABLE = True      # bf16 geometric embedding through the 4-point table kernel; False: the matrix-core kernel

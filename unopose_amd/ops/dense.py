@@ -273,6 +273,10 @@ def linear(x, lin, relu=False, gelu=False):
     if st._DIFF and not gelu and torch.is_grad_enabled():
         return linear_train(x, lin, relu)
     if st._DIFF or not (torch.is_autocast_enabled() and x.is_cuda):
+        if st.FORBID_LIBRARY_BF16_GEMM and x.is_cuda and not st._DIFF:
+            raise RuntimeError(f"ops.linear: a {tuple(x.shape)} {x.dtype} -> {lin.weight.shape[0]} linear does not fit csrc/gemm_f32.hip (N % 256, K % 32, fp32 "
+                               "without autograd) and would go to a library GEMM while several forwards are in flight (PipelinedForward, depth > 1).  "
+                               "Use depth=1 for this model configuration")
         y = lin(x)
         return F.relu(y) if relu else (F.gelu(y) if gelu else y)
     cache = _bf16_weights(lin)

@@ -64,8 +64,9 @@ class Ticket:
 
 class PipelinedForward:
     """model: an eval-mode UNOPose on a HIP device.  depth: forwards in flight (1..4 accepted; 2 is the useful value: bench.py
-    --inflight 3 / 4 measure the same rate or less).  autocast_dtype: torch.bfloat16 (the pipelined path) or None (fp32: one batch
-    at a time, whatever `depth` says).  The model's weights must not change while forwards are in flight (the per-module weight
+    --inflight 3 / 4 measure the same rate or less).  autocast_dtype: torch.bfloat16 or None (fp32, the reference's default precision:
+    pipelined as well since round 6 -- every fp32 GEMM of the eval path is the own fp32-class kernel, `ops.USE_F32X3`; with that switch off
+    fp32 runs one batch at a time, whatever `depth` says).  The model's weights must not change while forwards are in flight (the per-module weight
     caches are rebuilt on whichever stream sees the new version first); after an update call `drain()` then `reset()`.
     `close()` restores the model's `internal_overlap` switch."""
 
@@ -77,7 +78,7 @@ class PipelinedForward:
         if dev.type != "cuda":
             raise RuntimeError("PipelinedForward needs the model on a HIP device")
         self.device = dev
-        self.depth = depth if autocast_dtype is not None else 1
+        self.depth = depth if (autocast_dtype is not None or ops.USE_F32X3) else 1
         if self.depth > 1 and not (ops.HIP_GEMM_ALL and ops.USE_HIP_GEMM):
             raise RuntimeError("more than one forward in flight needs ops.HIP_GEMM_ALL (library stream-K GEMMs spin on partner "
                                "workgroups and can hang when forwards overlap)")
@@ -192,7 +193,9 @@ class PipelinedForward:
             if torch.is_tensor(v) and v.is_cuda:
                 v.record_stream(sv)
                 v.record_stream(st)
-        ac = (lambda: torch.autocast("cuda", dtype=self.autocast_dtype))
+        import contextlib
+
+        ac = (lambda: torch.autocast("cuda", dtype=self.autocast_dtype)) if self.autocast_dtype is not None else contextlib.nullcontext
         with torch.no_grad():
             with torch.cuda.stream(sv), ac():
                 start = torch.cuda.Event(enable_timing=True) if self.timing else None
