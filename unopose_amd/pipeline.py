@@ -246,3 +246,4 @@ class PipelinedForward:
         self.drain()
         if self._saved_overlap is not None:
             self.model.internal_overlap = self._saved_overlap
+
