@@ -5,7 +5,7 @@ import ctypes
 import torch
 import torch.nn.functional as F
 
-from .._lib import call, lib, ptr, stream_ptr
+from .._lib import call, lib, on_device, ptr, stream_ptr
 from . import _state as st
 from .common import _c, _own_f32, _own_glue, _params_key, note_fallback
 from .dense import _lin, bf16_linear_2d, bmm_nt_f32, linear, linear_f32_raw
@@ -20,14 +20,14 @@ def vit_attention(qkv, heads):
         B, T, C3 = qkv.shape
         qkv = _c(qkv)
         out = torch.empty(B, T, C3 // 3, dtype=torch.bfloat16, device=qkv.device)
-        with torch.cuda.device(qkv.device):
+        with on_device(qkv.device):
             call("unopose_vit_attention", ptr(qkv), B, T, heads, ptr(out), stream_ptr())
         return out
     if qkv.dtype == torch.float32 and qkv.is_cuda and qkv.shape[-1] == 3 * heads * 64:
         B, T, C3 = qkv.shape
         qkv = _c(qkv)
         out = torch.empty(B, T, C3 // 3, dtype=torch.float32, device=qkv.device)
-        with torch.cuda.device(qkv.device):
+        with on_device(qkv.device):
             call("unopose_vit_attention_f32", ptr(qkv), B, T, heads, ptr(out), stream_ptr())
         return out
     note_fallback("vit_attention", f"head dim {qkv.shape[-1] // (3 * heads)} / dtype {qkv.dtype} (kernels: head dim 64, bf16 or fp32)")
@@ -41,7 +41,7 @@ def vit_attention_f32_split(qkv, heads):
     assert qkv.dtype == torch.float32 and qkv.is_cuda and C3 == 3 * heads * 64
     qkv = _c(qkv)
     out = torch.empty(B * T, 2 * (C3 // 3), dtype=torch.bfloat16, device=qkv.device)
-    with torch.cuda.device(qkv.device):
+    with on_device(qkv.device):
         call("unopose_vit_attention_f32_split", ptr(qkv), B, T, heads, ptr(out), stream_ptr())
     return out
 
@@ -52,7 +52,7 @@ def vit_attention_f32_ss(qkv_split, B, T, heads):
     C3 = qkv_split.shape[-1] // 2
     assert qkv_split.dtype == torch.bfloat16 and qkv_split.is_cuda and qkv_split.is_contiguous() and C3 == 3 * heads * 64
     out = torch.empty(B * T, 2 * (C3 // 3), dtype=torch.bfloat16, device=qkv_split.device)
-    with torch.cuda.device(qkv_split.device):
+    with on_device(qkv_split.device):
         call("unopose_vit_attention_f32_ss", ptr(qkv_split), B, T, heads, ptr(out), stream_ptr())
     return out
 
@@ -120,7 +120,7 @@ def _token_attention_hip_f32(x, mem, att, embed):
     E = _c(embed.float()) if rpe else None
     out = torch.empty(B, n, C, dtype=torch.float32, device=x.device)
     qptr, kptr = yq.data_ptr(), ykv.data_ptr()
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         call("unopose_token_attention_f32", ctypes.c_void_p(qptr), yq.stride(1), ctypes.c_void_p(kptr), ykv.stride(1),
              ptr(vt), ctypes.c_void_p(qptr + C * 4) if rpe else None, yq.stride(1), ptr(E) if rpe else None, B, n, m,
              0.125, ptr(out), stream_ptr())
@@ -172,14 +172,14 @@ def _token_attention_hip(x, mem, att, embed):
             ykv = bf16_linear_2d(mem.to(bf).reshape(B * m, C), w_kv, bkv32, b_kv).reshape(B, m, -1)
     # q | qp and k | v are consumed in place from the projection outputs (row strides passed to the kernel)
     vt = torch.empty(B, C, _KEY_PAD, dtype=bf, device=x.device)
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         call("unopose_transpose_pad_bf16", ctypes.c_void_p(ykv.data_ptr() + C * 2), ykv.stride(1), B, m, C, _KEY_PAD, ptr(vt), stream_ptr())
     E = _c(embed.to(bf)) if rpe else None
     out = torch.empty(B, n, C, dtype=bf, device=x.device)
     esz = 2
     q_ptr = yq.data_ptr()
     k_ptr = ykv.data_ptr()
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         call("unopose_token_attention", ctypes.c_void_p(q_ptr), yq.stride(1), ctypes.c_void_p(k_ptr), ykv.stride(1),
              ptr(vt), ctypes.c_void_p(q_ptr + C * esz) if rpe else None, yq.stride(1),
              ptr(E) if E is not None else None, B, n, m, 0.125, ptr(out), stream_ptr())
@@ -234,7 +234,7 @@ def _focused_linear_attention_hip_f32(xq, xkv, att, focusing):
     v = linear(xkv, att.proj_v)
     kf = torch.empty(B, j, C, dtype=torch.float32, device=xq.device)
     out = torch.empty(B, N, C, dtype=torch.float32, device=xq.device)
-    with torch.cuda.device(xq.device):
+    with on_device(xq.device):
         call("unopose_linear_attention_f32", ptr(kproj), ptr(inv_sp), None, None, B, j, focusing, 1, ptr(kf), stream_ptr())
         ksum = _c(kf.sum(dim=1))
         if _own_f32(v) and v.dtype == torch.float32:
@@ -267,7 +267,7 @@ def _focused_linear_attention_hip(xq, xkv, att, focusing):
     kproj, v = _c(ykv[..., :C]), ykv[..., C:]
     kf = torch.empty(B, j, C, dtype=bf, device=xq.device)
     out = torch.empty(B, N, C, dtype=bf, device=xq.device)
-    with torch.cuda.device(xq.device):
+    with on_device(xq.device):
         call("unopose_linear_attention", ptr(kproj), ptr(inv_sp), None, None, B, j, focusing, 1, ptr(kf),
              stream_ptr())
         kf32 = kf.float()

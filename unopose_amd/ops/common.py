@@ -43,8 +43,19 @@ def note_fallback(site, why):
 
 def _params_key(mod, *extra):
     """Cache key of state derived from a module's tensors: version and address of EVERY parameter and buffer of the module, so that an
-    in-place edit of any of them -- a bias alone included -- rebuilds the derived state."""
-    return tuple((t._version, t.data_ptr()) for t in itertools.chain(mod.parameters(), mod.buffers())) + extra
+    in-place edit of any of them -- a bias alone included -- rebuilds the derived state.  The (owner dict, name)
+    slots are listed once per module (its structure does not change; a REPLACED tensor is seen through the slot) -- walking
+    `mod.parameters()` on every call cost ~7 us x 147 calls per forward (scripts/host_profile.py)."""
+    slots = mod.__dict__.get("_pk_slots")
+    if slots is None:
+        slots = [(m._parameters, k) for m in mod.modules() for k in m._parameters] + [(m._buffers, k) for m in mod.modules() for k in m._buffers]
+        mod.__dict__["_pk_slots"] = slots
+    key = []
+    for d, k in slots:
+        t = d[k]
+        if t is not None:
+            key.append((t._version, t.data_ptr()))
+    return tuple(key) + extra
 
 
 _SPLIT_MEMO = []  # [(key, source tensor, split tensor)], newest first

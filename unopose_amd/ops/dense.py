@@ -4,7 +4,7 @@ LayerNorm fold, and the trainable form under autograd.  Each function cites the 
 import torch
 import torch.nn.functional as F
 
-from .._lib import call, lib, ptr, stream_ptr
+from .._lib import call, lib, on_device, ptr, stream_ptr
 from . import _state as st
 from .common import _MUTATION_EPOCH, _SPLIT_MEMO, _aligned16, _c, _f32_path, _no_autograd, _params_key, note_fallback, note_mutation
 
@@ -35,7 +35,7 @@ def linear_bf16_hip(x2, w, bias_f32, gelu=False, relu=False):
     M, K = x2.shape
     N = w.shape[0]
     out = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
-    with torch.cuda.device(x2.device):
+    with on_device(x2.device):
         call("unopose_linear_bf16", ptr(x2), ptr(w), ptr(bias_f32), ptr(out), M, N, K, 1 if gelu else (2 if relu else 0), stream_ptr())
     return out
 
@@ -83,7 +83,7 @@ def split_f32(x2, memo=False):
             if e[0] == key:
                 return e[2]
     out = torch.empty(M, 2 * K, dtype=torch.bfloat16, device=x2.device)
-    with torch.cuda.device(x2.device):
+    with on_device(x2.device):
         call("unopose_split_bf16x2", ptr(x2), M, K, ptr(out), stream_ptr())
     if memo:
         _SPLIT_MEMO.insert(0, (key, x2, out))
@@ -107,7 +107,7 @@ def linear_f32x3(xs, ws, bias_f32, M, N, K, gelu=False, relu=False, out="f32"):
     """C-ABI unopose_linear_f32x3 on split operands; `out`: "f32" -> (M,N) fp32, "split" -> (M,2N) split layout, "both"."""
     C = torch.empty(M, N, dtype=torch.float32, device=xs.device) if out in ("f32", "both") else None
     Cs = torch.empty(M, 2 * N, dtype=torch.bfloat16, device=xs.device) if out in ("split", "both") else None
-    with torch.cuda.device(xs.device):
+    with on_device(xs.device):
         call("unopose_linear_f32x3", ptr(xs), ptr(ws), ptr(bias_f32), None if C is None else ptr(C), None if Cs is None else ptr(Cs),
              M, N, K, 1 if gelu else (2 if relu else 0), stream_ptr())
     return C if out == "f32" else (Cs if out == "split" else (C, Cs))
@@ -116,7 +116,7 @@ def linear_f32x3(xs, ws, bias_f32, M, N, K, gelu=False, relu=False, out="f32"):
 def linear_f32x3_bf16(xs, ws, bias_f32, M, N, K, resid=None):
     """C-ABI unopose_linear_f32x3_bf16: bf16( resid + bf16(X W^T + b) ) with X, W in the split layout."""
     out = torch.empty(M, N, dtype=torch.bfloat16, device=xs.device)
-    with torch.cuda.device(xs.device):
+    with on_device(xs.device):
         call("unopose_linear_f32x3_bf16", ptr(xs), ptr(ws), ptr(bias_f32), None if resid is None else ptr(resid), ptr(out), M, N, K, stream_ptr())
     return out
 
@@ -205,7 +205,7 @@ class _LinearFn(torch.autograd.Function):
                 splits = lib().unopose_linear_wgrad_f32_splits(rows, N, K)
                 ws = torch.empty(splits * N * K, dtype=torch.float32, device=g.device)
                 gw = torch.empty(N, K, dtype=torch.float32, device=g.device)
-                with torch.cuda.device(g.device):
+                with on_device(g.device):
                     call("unopose_linear_wgrad_f32", ptr(gc), ptr(x2), rows, N, K, ptr(ws), ptr(gw), stream_ptr())
                 gw = gw.to(lin.weight.dtype)
             else:
@@ -329,7 +329,7 @@ def linear_add_layernorm(h, lin, x, norm):
             hb = _c(h if h.dtype == torch.bfloat16 else h.to(torch.bfloat16)).reshape(rows, K)
             xb = _c(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)).reshape(rows, N)
             out = torch.empty(rows, N, dtype=torch.bfloat16, device=h.device)
-            with torch.cuda.device(h.device):
+            with on_device(h.device):
                 call("unopose_linear_add_layernorm_bf16", ptr(hb), ptr(cache[1]), ptr(cache[3]), ptr(xb), ptr(norm.weight.detach()),
                      ptr(norm.bias.detach()), float(norm.eps), ptr(out), rows, K, stream_ptr())
         return out.reshape(*h.shape[:-1], N)
@@ -407,7 +407,7 @@ def vit_prologue(xa, xb, vit, norm1):
     P = (S // 14) ** 2
     npre = prefix.shape[0]
     dev = xa.device
-    with torch.autocast("cuda", enabled=False), torch.cuda.device(dev):
+    with torch.autocast("cuda", enabled=False), on_device(dev):
         a = torch.empty((na + nb) * P, Kp, dtype=torch.bfloat16, device=dev)
         call("unopose_patchify_bf16", ptr(_c(xa)), na, None if xb is None else ptr(_c(xb)), nb, S, Kp, ptr(a), stream_ptr())
         y = linear_bf16_hip(a, wp, b)
@@ -429,7 +429,7 @@ def bmm_nt_f32(a, b, alpha=1.0):
     Bo, Bi, n, K = a4.shape
     m = b4.shape[2]
     out = torch.empty(Bo, Bi, n, m, dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with on_device(a.device):
         call("unopose_bmm_f32", ptr(a4), a4.stride(0), a4.stride(1), a4.stride(2), a4.stride(3), ptr(b4), b4.stride(0), b4.stride(1),
              b4.stride(2), b4.stride(3), ptr(out), Bo, Bi, n, m, K, float(alpha), stream_ptr())
     return out if a.dim() == 4 else out[:, 0]
@@ -447,7 +447,7 @@ def score_head(x, lin):
             lin._rowdot_cache_f32 = cache
         xc = _c(x)
         out = torch.empty(*x.shape[:-1], 1, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             call("unopose_row_dot", ptr(xc), 0, ptr(cache[1]), cache[2], xc.numel() // 256, 256, ptr(out), 0, stream_ptr())
         return out
     if st._DIFF or not (st.HIP_GEMM_ALL and x.is_cuda and torch.is_autocast_enabled()):
@@ -462,7 +462,7 @@ def score_head(x, lin):
         if x.shape[-1] == 256 and x.dtype in (torch.bfloat16, torch.float32):
             xc = _c(x)
             out = torch.empty(*x.shape[:-1], 1, dtype=torch.bfloat16, device=x.device)
-            with torch.cuda.device(x.device):
+            with on_device(x.device):
                 call("unopose_row_dot", ptr(xc), int(x.dtype == torch.bfloat16), ptr(cache[1]), cache[2], xc.numel() // 256, 256, ptr(out), 1,
                      stream_ptr())
             return out
@@ -497,7 +497,7 @@ def add_layernorm(a, b, norm, out_dtype=None, out=None):
             exp *= out.shape[d]
     ok = (torch.float32, torch.bfloat16)
     assert a.dtype in ok and out_dtype in ok and (b is None or b.dtype in ok) and a.is_cuda
-    with torch.cuda.device(a.device):
+    with on_device(a.device):
         call("unopose_add_layernorm_strided", ptr(a), int(a.dtype == torch.bfloat16), ptr(b) if b is not None else None,
              int(b is not None and b.dtype == torch.bfloat16), ptr(norm.weight), ptr(norm.bias), rows, C,
              float(norm.eps), ptr(out), int(out_dtype == torch.bfloat16), int(ld), stream_ptr())
@@ -510,7 +510,7 @@ def scale_residual_(x, y, gamma):
     assert x.dtype == torch.float32 and x.is_contiguous() and y.dtype == torch.bfloat16
     y = _c(y)
     C = x.shape[-1]
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         call("unopose_scale_residual", ptr(x), ptr(y), ptr(gamma), x.numel() // C, C, stream_ptr())
     return x
 
@@ -523,7 +523,7 @@ def scale_residual_layernorm_f32_(x, y, gamma, norm):
     C = x.shape[-1]
     rows = x.numel() // C
     out = None if norm is None else torch.empty(rows, 2 * C, dtype=torch.bfloat16, device=x.device)
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         call("unopose_scale_residual_layernorm_f32", ptr(x), None if y is None else ptr(_c(y)), None if y is None else ptr(gamma),
              None if norm is None else ptr(norm.weight), None if norm is None else ptr(norm.bias), rows, C,
              0.0 if norm is None else float(norm.eps), None if out is None else ptr(out), stream_ptr())
@@ -544,7 +544,7 @@ def scale_residual_layernorm_(x, y, gamma, norm):
     y = _c(y)
     C = x.shape[-1]
     out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         call("unopose_scale_residual_layernorm", ptr(x), ptr(y), ptr(gamma), ptr(norm.weight), ptr(norm.bias),
              x.numel() // C, C, float(norm.eps), ptr(out), stream_ptr())
     return out
@@ -601,7 +601,7 @@ def linear_residual_(x, a, lin, gamma):
     a = _c(a)
     xb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     stats = torch.empty((rows + 255) // 256 * 256, C // 256, 2, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         call("unopose_linear_bf16_residual", ptr(a), ptr(w), ptr(b), ptr(x), ptr(xb), ptr(stats), rows, C, K, stream_ptr())
     return xb, stats
 
@@ -612,6 +612,6 @@ def linear_lnfold(xb, stats, lin, norm, gelu=False):
     N, K = w.shape
     rows = xb.numel() // K
     out = torch.empty(*xb.shape[:-1], N, dtype=torch.bfloat16, device=xb.device)
-    with torch.cuda.device(xb.device):
+    with on_device(xb.device):
         call("unopose_linear_bf16_lnfold", ptr(xb), ptr(w), ptr(d), ptr(c), ptr(stats), K // 256, float(norm.eps), ptr(out), rows, N, K, int(gelu), stream_ptr())
     return out

@@ -6,7 +6,7 @@ import ctypes
 import torch
 import torch.nn.functional as F
 
-from .._lib import call, check_f32, lib, ptr, stream_ptr
+from .._lib import call, check_f32, lib, on_device, ptr, stream_ptr
 from ..pointnet2 import _ext
 from . import _state as st
 from .common import _c, _own_glue, _params_key, note_fallback
@@ -19,7 +19,7 @@ def lrf_global(pts, use_ref_rad=False):
     check_f32(pts, "pts")
     B, N, _ = pts.shape
     out = torch.empty_like(pts)
-    with torch.cuda.device(pts.device):
+    with on_device(pts.device):
         call("unopose_lrf_global", ptr(pts), B, N, int(bool(use_ref_rad)), ptr(out), stream_ptr())
     return out
 
@@ -31,7 +31,7 @@ def query_lrf_group(xyz, radius, nsample):
     check_f32(xyz, "xyz")
     B, N, _ = xyz.shape
     out = torch.empty(B, 6, N, int(nsample), dtype=torch.float32, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with on_device(xyz.device):
         call("unopose_query_lrf_group", ptr(xyz), B, N, float(radius), int(nsample), ptr(out), stream_ptr())
     return out
 
@@ -52,7 +52,7 @@ def lrf_group_idx(xyz, new_xyz, idx, radius):
         raise ValueError(f"idx must be a (B,N,S) device tensor, got {tuple(idx.shape)}")
     S = idx.shape[2]
     out = torch.empty(B, 6, N, S, dtype=torch.float32, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with on_device(xyz.device):
         call("unopose_lrf_group_idx", ptr(xyz), ptr(new_xyz), ptr(idx), B, N, float(radius), S, ptr(out), stream_ptr())
     return out
 
@@ -68,7 +68,7 @@ def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
         check_f32(weights, "weights")
     R = torch.empty(M, 3, 3, dtype=torch.float32, device=src.device)
     t = torch.empty(M, 3, dtype=torch.float32, device=src.device)
-    with torch.cuda.device(src.device):
+    with on_device(src.device):
         call("unopose_weighted_procrustes", ptr(src), ptr(ref), ptr(weights) if weights is not None else None, M, N,
              float(weight_thresh), float(eps), ptr(R), ptr(t), stream_ptr())
     return R, t
@@ -80,7 +80,7 @@ def cloud_radius(pts):
         return torch.norm(pts - pts.mean(1, keepdim=True), dim=2).max(1)[0]
     p = _c(pts.float())
     out = torch.empty(p.shape[0], dtype=torch.float32, device=p.device)
-    with torch.cuda.device(p.device):
+    with on_device(p.device):
         call("unopose_cloud_radius", ptr(p), p.shape[0], p.shape[1], ptr(out), stream_ptr())
     return out
 
@@ -100,7 +100,7 @@ def scale_by_radius(x, radius, multiply=False, eps=1e-6):
         if r.numel() != 1:
             raise ValueError(f"scale_by_radius: {r.numel()} radii for a batch of {B}")
         r = r.expand(B)
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         call("unopose_scale_by_radius", ptr(xc), B, xc.numel() // B, ptr(_c(r)), float(eps), int(multiply), ptr(out), stream_ptr())
     return out
 
@@ -117,7 +117,7 @@ def gather_rows(feats, idx, off=0, alt=None, prepend=False):
         if alt is not None:
             alt = _c(alt.reshape(B, C).to(feats.dtype))
         out = torch.empty(B, J + int(prepend), C, dtype=feats.dtype, device=feats.device)
-        with torch.cuda.device(feats.device):
+        with on_device(feats.device):
             call("unopose_gather_rows", ptr(feats), B, N, C * feats.element_size(), ptr(idx), int(idx.dtype == torch.int64), J, int(off),
                  None if alt is None else ptr(alt), int(prepend), ptr(out), stream_ptr())
         return out
@@ -227,7 +227,7 @@ def geo_embedding(points, m, out_dtype=None):
         tab = _geo_tables(m, key, npoint)
         if tab is not None and not _GEO_TABLE_UNAVAILABLE.get(points.device, False):
             try:
-                with torch.cuda.device(points.device):
+                with on_device(points.device):
                     call("unopose_geo_embedding_table", ptr(points), B, n, ptr(tab[0]), tab[0].shape[0], ptr(tab[1]), tab[1].shape[0],
                          ptr(bias), ptr(tab[2]), ptr(div), _GEO_HINV, npoint, float(m.sigma_d), float(m.factor_a),
                          int(m.reduction_a == "mean"), int(bf16_out), ptr(knn), ptr(out), stream_ptr())
@@ -238,7 +238,7 @@ def geo_embedding(points, m, out_dtype=None):
                 # a device that cannot give the table kernel its ~145 KiB of LDS: the matrix-core kernel below takes over, loudly, for good
                 _GEO_TABLE_UNAVAILABLE[points.device] = True
                 note_fallback("geo_embedding", f"table kernel unavailable on {points.device} ({e}): matrix-core kernel")
-    with torch.cuda.device(points.device):
+    with on_device(points.device):
         call("unopose_geo_embedding", ptr(points), B, n, ptr(wdh), ptr(wdl), ptr(wah), ptr(wal), ptr(bias), ptr(div),
              float(m.sigma_d), float(m.factor_a), int(m.reduction_a == "mean"), int(not bf16_out), int(bf16_out),
              ptr(knn), ptr(out), stream_ptr())
@@ -302,7 +302,7 @@ def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None, cand_in=None, want_
         assert [tuple(t.shape) for t in flat[::2]] == [(32, 6), (64, 32), (128, 64)], "kernel is built for [6,32,64,128]"
         from .._lib import lib
         image = torch.empty(lib().unopose_pe_image_bytes(), dtype=torch.uint8, device=pts.device)
-        with torch.cuda.device(pts.device):
+        with on_device(pts.device):
             call("unopose_pe_pack_weights", *(ptr(t) for t in flat), ptr(image), stream_ptr())
         cache = (key, flat, image)
         mlp._hip_cache = cache
@@ -312,7 +312,7 @@ def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None, cand_in=None, want_
         buf, b0, c0 = out_split
         assert bf16x3 and buf.dtype == torch.bfloat16 and buf.is_contiguous() and buf.shape[1] == N and c0 % 32 == 0 and b0 + B <= buf.shape[0]
         ld = buf.shape[2] // 2  # row width in 4-byte units
-        with torch.cuda.device(pts.device):
+        with on_device(pts.device):
             if want_cand:
                 cand_out = (torch.empty(B, N, int(nsample), dtype=torch.int32, device=pts.device),
                             torch.empty(B, N, dtype=torch.int32, device=pts.device))
@@ -324,7 +324,7 @@ def pe_group_mlp_max(pts, radius, nsample, mlp, bf16x3=None, cand_in=None, want_
                  None if cand_out is None else ptr(cand_out[1]), dst, ld, 1, stream_ptr())
         return (buf, cand_out) if want_cand else buf
     out = torch.empty(B, N, 128, dtype=torch.float32, device=pts.device)
-    with torch.cuda.device(pts.device):
+    with on_device(pts.device):
         if bf16x3:
             if want_cand:
                 cand_out = (torch.empty(B, N, int(nsample), dtype=torch.int32, device=pts.device),
@@ -398,7 +398,7 @@ class _GeoEmbedFn(torch.autograd.Function):
         amax = torch.empty(B, n, n, 64, dtype=torch.int32, device=points.device)
         knn = torch.empty(B, n, 3, dtype=torch.int32, device=points.device)
         mean = int(m.reduction_a == "mean")
-        with torch.cuda.device(points.device):
+        with on_device(points.device):
             call("unopose_geo_embedding_train_forward", ptr(points), B, n, ptr(td), rows_d, ptr(ta), rows_a, ptr(bias), ptr(wdf), ptr(div), _GEO_HINV,
                  float(m.sigma_d), float(m.factor_a), mean, ptr(knn), ptr(out), ptr(amax), stream_ptr())
         ctx.save_for_backward(points, knn, amax, sd, sa)
@@ -416,7 +416,7 @@ class _GeoEmbedFn(torch.autograd.Function):
         ws = torch.empty(G, rd_l + rows_a, 256, dtype=torch.float32, device=dE.device)
         full = torch.zeros(rows_d, 256, dtype=torch.float32, device=dE.device)
         past = torch.zeros(1, dtype=torch.int32, device=dE.device)
-        with torch.cuda.device(dE.device):
+        with on_device(dE.device):
             call("unopose_geo_embedding_train_backward", ptr(points), ptr(knn), B, n, rows_d, rows_a, _GEO_HINV, sigma_d, factor_a, mean, ptr(dE), ptr(amax),
                  ptr(ws), ptr(full), ptr(past), stream_ptr())
         torch._assert_async(past == 0, "geo embedding backward: a distance index past the table (the clouds are not radius-normalised)")

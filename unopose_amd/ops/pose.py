@@ -3,7 +3,7 @@ torch composites."""
 import torch
 import torch.nn.functional as F
 
-from .._lib import call, check_f32, ptr, stream_ptr
+from .._lib import call, check_f32, on_device, ptr, stream_ptr
 from . import _state as st
 from .common import _c, _own_f32, _own_glue
 from .geometry import pairwise_distance, weighted_procrustes
@@ -18,7 +18,7 @@ def overlap_scores(scores, n1):
     sc = _c(scores)
     B, n_tot = sc.shape[0], sc.shape[1]
     out = torch.empty(B, n_tot - 2, dtype=torch.float32, device=sc.device)
-    with torch.cuda.device(sc.device):
+    with on_device(sc.device):
         call("unopose_overlap_scores", ptr(sc), int(sc.dtype == torch.bfloat16), B, n_tot, n1, ptr(out), stream_ptr())
     return out
 
@@ -29,7 +29,7 @@ def pose_score(dis, w, thr):
         return ((dis < thr).float() * w).sum(1) / (w.sum(1) + 1e-8) * w.mean(1)
     d, ww = _c(dis.float()), _c(w.float())
     out = torch.empty(d.shape[0], dtype=torch.float32, device=d.device)
-    with torch.cuda.device(d.device):
+    with on_device(d.device):
         call("unopose_pose_score", ptr(d), ptr(ww), d.shape[0], d.shape[1], float(thr), ptr(out), stream_ptr())
     return out
 
@@ -40,7 +40,7 @@ def rigid_rows(p, t, R):
     multiply-adds, so that no library bf16 GEMM kernel is on the path (`own_gemm_ok`)."""
     if st.HIP_GEMM_ALL and torch.is_autocast_enabled() and _own_glue(p) and p.dtype == torch.float32 and p.dim() == 3:
         pc, out = _c(p), torch.empty(p.shape, dtype=torch.bfloat16, device=p.device)
-        with torch.cuda.device(p.device):
+        with on_device(p.device):
             call("unopose_rigid_rows_bf16", ptr(pc), pc.shape[0], pc.shape[1], ptr(_c(t.float())), ptr(_c(R.float())), ptr(out), stream_ptr())
         return out
     x = p - t.unsqueeze(1)
@@ -162,7 +162,7 @@ def coarse_pose(atten, score, pts1, pts2, rand, n1p=6000, n2p=300):
     score1, score2 = _c(score[:, :N1].float()), _c(score[:, N2:].float())  # NB `N2:` (model_utils.py:440)
     rand = _c(rand.float())
     dev = atten.device
-    with torch.cuda.device(dev):
+    with on_device(dev):
         stats, w1, w2 = _assign_labels(atten, score1, score2)
         cdf = torch.empty(B, N1 * N2, dtype=torch.float32, device=dev)
         rs = torch.empty(B, n1p, 3, 3, dtype=torch.float32, device=dev)
@@ -192,7 +192,7 @@ def fine_pose(atten, score, pts1, pts2, dis_thres=0.15):
     check_f32(atten, "atten")
     score1, score2 = _c(score[:, :N1].float()), _c(score[:, N1:].float())
     dev = atten.device
-    with torch.cuda.device(dev):
+    with on_device(dev):
         stats, w1, w2 = _assign_labels(atten, score1, score2)
         weight = torch.empty(B, N1, dtype=torch.float32, device=dev)
         pred = torch.empty(B, N1, 3, dtype=torch.float32, device=dev)
@@ -217,7 +217,7 @@ def normalize_rows_bf16(f, temp):
         return _c((F.normalize(f.float(), p=2, dim=-1) / temp).to(torch.bfloat16))
     fc = _c(f)
     out = torch.empty(f.shape, dtype=torch.bfloat16, device=f.device)
-    with torch.cuda.device(f.device):
+    with on_device(f.device):
         call("unopose_normalize_rows_bf16", ptr(fc), int(f.dtype == torch.bfloat16), fc.numel() // 256, 256, float(temp), ptr(out), stream_ptr())
     return out
 
@@ -235,7 +235,7 @@ def fine_pose_from_features(f1, f2, temp, score, pts1, pts2, dis_thres=0.15):
     score1, score2 = _c(score[:, :N1].float()), _c(score[:, N1:].float())
     dev = pts1.device
     R, C = N1 + 1, N2 + 1
-    with torch.cuda.device(dev):
+    with on_device(dev):
         ws = torch.empty(B * (R + C) + B * (-(-N1 // 256) - (-N2 // 256)), dtype=torch.float32, device=dev)
         w1 = torch.empty(B, N1, dtype=torch.float32, device=dev)
         w2 = torch.empty(B, N2, dtype=torch.float32, device=dev)

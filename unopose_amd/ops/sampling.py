@@ -2,7 +2,7 @@
 those pixels read (csrc/upproj.hip, fused.hip)."""
 import torch
 
-from .._lib import call, ptr, stream_ptr
+from .._lib import call, on_device, ptr, stream_ptr
 from . import _state as st
 from .common import _c, note_mutation
 from .dense import _bf16_weights
@@ -32,7 +32,7 @@ def bilinear_sample_native(z, choose, H, W, out=None, tok_offset=0):
     if out is None:
         out = torch.empty(B, Np, 256, dtype=torch.float32, device=z.device)
     assert out.shape == (B, Np, 256) and out.dtype == torch.float32 and out.is_contiguous()
-    with torch.cuda.device(z.device):
+    with on_device(z.device):
         call("unopose_bilinear_sample_tokens", ptr(z), int(z.dtype == torch.bfloat16), ptr(choose), B, side, Np, int(H),
              int(W), int(tok_offset), int(tok_stride), ptr(out), stream_ptr())
     return out
@@ -56,7 +56,7 @@ def upproj_plan(choose, H, W, side, tok_offset, tok_stride):
     plan = dict(choose=choose, H=int(H), W=int(W), side=int(side), tok_offset=int(tok_offset), tok_stride=int(tok_stride),
                 cap_rows=cap_rows, ws=torch.empty(B2 * (cells + 32), **i32), row_list=torch.empty(cap_rows, **i32),
                 cellmap=torch.empty(B2 * cells, **i32), tile_info=torch.empty(18, **i32))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         call("unopose_upproj_plan", ptr(choose), B2, Np, int(H), int(W), int(side), int(tok_offset), int(tok_stride), cap_rows,
              ptr(plan["ws"]), ptr(plan["row_list"]), ptr(plan["cellmap"]), ptr(plan["tile_info"]), stream_ptr())
     return plan
@@ -81,7 +81,7 @@ def sparse_pixel_features(acts, lin, plan, out=None):
     if out is None:
         out = torch.empty(B2, Np, 256, dtype=torch.float32, device=dev)
     assert out.shape == (B2, Np, 256) and out.dtype == torch.float32 and out.is_contiguous()
-    with torch.cuda.device(dev):
+    with on_device(dev):
         cells = torch.empty(plan["cap_rows"], 256, dtype=torch.bfloat16, device=dev)
         call("unopose_linear_bf16_gather", ptr(acts), B2 * ts, K, ptr(w), N, ptr(bias), ptr(plan["row_list"]),
              ptr(plan["tile_info"]), plan["cap_rows"] // 256, ptr(cells), stream_ptr())

@@ -3,7 +3,7 @@ convolutions (csrc/bn_train.hip, conv_train.hip, saliency_train.hip)."""
 import torch
 import torch.nn.functional as F
 
-from .._lib import call, lib, ptr, stream_ptr
+from .._lib import call, lib, on_device, ptr, stream_ptr
 from . import _state as st
 from .common import _aligned16, _c
 
@@ -20,7 +20,7 @@ class _InfoNCEFn(torch.autograd.Function):
         B, R, C = atten.shape
         x = _c(atten.float())
         ws = torch.empty(2 * B * (R + C), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             call("unopose_softmax_stats", ptr(x), B, R, C, ptr(ws), stream_ptr())
         rmax, rinv = ws[:B * R].reshape(B, R), ws[B * R:2 * B * R].reshape(B, R)
         cmax, cinv = ws[2 * B * R:2 * B * R + B * C].reshape(B, C), ws[2 * B * R + B * C:].reshape(B, C)
@@ -36,7 +36,7 @@ class _InfoNCEFn(torch.autograd.Function):
         x, ws, label1, label2 = ctx.saved_tensors
         B, R, C = x.shape
         grad = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             call("unopose_infonce_grad", ptr(x), B, R, C, ptr(ws), ptr(_c(label1)), ptr(_c(label2)), ptr(_c(g.float())), ptr(grad), stream_ptr())
         return grad, None, None
 
@@ -73,7 +73,7 @@ class _BNReLUTrain(torch.autograd.Function):
         else:
             momentum = 0.0
         w, b_ = _c(weight.detach().float()), _c(bias.detach().float())
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             call("unopose_bn_relu_train_forward", ptr(x), B, C, L, ptr(w), ptr(b_), float(bn.eps), float(momentum),
                  ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None, ptr(ws), ptr(mean), ptr(rstd), ptr(y), stream_ptr())
         ctx.save_for_backward(x, w, b_, mean, rstd)
@@ -88,7 +88,7 @@ class _BNReLUTrain(torch.autograd.Function):
         chunk = lib().unopose_bn_train_chunk()
         ws = torch.empty(2 * B * C * ((L + chunk - 1) // chunk), dtype=torch.float32, device=x.device)
         dgamma, dbeta, dx = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             call("unopose_bn_relu_train_backward", ptr(x), ptr(dy), B, C, L, ptr(w), ptr(b_), ptr(mean), ptr(rstd), ptr(ws), ptr(dgamma), ptr(dbeta),
                  ptr(dx), stream_ptr())
         return dx, dgamma, dbeta, None
@@ -126,7 +126,7 @@ class _BNReLUMaxPoolTrain(torch.autograd.Function):
         else:
             momentum = 0.0
         w, b_ = _c(weight.detach().float()), _c(bias.detach().float())
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             call("unopose_bn_relu_maxpool_train_forward", ptr(x), B, C, N, S, ptr(w), ptr(b_), float(bn.eps), float(momentum),
                  ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None, ptr(ws), ptr(mean), ptr(rstd), ptr(out), ptr(idx),
                  stream_ptr())
@@ -141,7 +141,7 @@ class _BNReLUMaxPoolTrain(torch.autograd.Function):
         g = _c(g.float())
         ws = torch.empty(2 * B * C, dtype=torch.float32, device=x.device)
         dgamma, dbeta, dx = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             call("unopose_bn_relu_maxpool_train_backward", ptr(x), ptr(g), ptr(idx), B, C, N, S, ptr(w), ptr(b_), ptr(mean), ptr(rstd), ptr(ws),
                  ptr(dgamma), ptr(dbeta), ptr(dx), stream_ptr())
         return dx, dgamma, dbeta, None
@@ -169,7 +169,7 @@ class _SaliencyFn(torch.autograd.Function):
         dev = a.device
         m1, rmax, rsum = (torch.empty(B, n1, dtype=torch.float32, device=dev) for _ in range(3))
         m2, cmax, csum = (torch.empty(B, n2, dtype=torch.float32, device=dev) for _ in range(3))
-        with torch.cuda.device(dev):
+        with on_device(dev):
             call("unopose_saliency_train_forward", ptr(a), ptr(v1), ptr(v2), B, n1, n2, ptr(m1), ptr(m2), ptr(rmax), ptr(rsum), ptr(cmax), ptr(csum),
                  stream_ptr())
         ctx.save_for_backward(a, v1, v2, m1, m2, rmax, rsum, cmax, csum)
@@ -183,7 +183,7 @@ class _SaliencyFn(torch.autograd.Function):
         g1, g2 = _c(g1.float().reshape(B, n1)), _c(g2.float().reshape(B, n2))
         da = torch.empty_like(a)
         ds1, ds2 = torch.empty_like(v1), torch.empty_like(v2)
-        with torch.cuda.device(a.device):
+        with on_device(a.device):
             call("unopose_saliency_train_backward", ptr(a), ptr(v1), ptr(v2), ptr(m1), ptr(m2), ptr(rmax), ptr(rsum), ptr(cmax), ptr(csum), ptr(g1),
                  ptr(g2), B, n1, n2, ptr(da), ptr(ds1), ptr(ds2), stream_ptr())
         ad, d1, d2, sh1, sh2 = ctx.meta
@@ -209,7 +209,7 @@ def nearest_partner(a, b, thr, over_b=True):
     d = torch.empty(B, nout, dtype=torch.float32, device=a.device)
     idx = torch.empty(B, nout, dtype=torch.int32, device=a.device)
     anyc = torch.empty(B, nout, dtype=torch.uint8, device=a.device)
-    with torch.cuda.device(a.device):
+    with on_device(a.device):
         call("unopose_nearest_partner", ptr(a), ptr(b), B, n, m, int(over_b), float(thr), ptr(d), ptr(idx), ptr(anyc), stream_ptr())
     return d, idx.long(), anyc.bool()
 
@@ -242,7 +242,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         x = _c(x)
         w2 = _c(weight.detach().reshape(M, C).float())
         y = torch.empty((B, M) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             call("unopose_conv1x1_train_forward", ptr(x), B, C, L, ptr(w2), M, ptr(y), stream_ptr())
         ctx.save_for_backward(x, w2)
         ctx.wshape = tuple(weight.shape)
@@ -256,7 +256,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         L = x.numel() // (B * C)
         dy = _c(dy.float())
         dx = dw = None
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 call("unopose_conv1x1_train_forward", ptr(dy), B, M, L, ptr(w2.t().contiguous()), C, ptr(dx), stream_ptr())

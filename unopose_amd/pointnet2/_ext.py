@@ -11,7 +11,7 @@ of ``libunopose_hip.so``.
 """
 import torch
 
-from .._lib import call, check_f32, check_i32, ptr, stream_ptr
+from .._lib import call, check_f32, check_i32, on_device, ptr, stream_ptr
 
 
 def furthest_point_sampling(points, nsamples):
@@ -20,7 +20,7 @@ def furthest_point_sampling(points, nsamples):
     out = torch.zeros(B, nsamples, dtype=torch.int32, device=points.device)
     if out.numel() == 0:  # empty batch: nothing to launch
         return out
-    with torch.cuda.device(points.device):
+    with on_device(points.device):
         call("unopose_furthest_point_sampling", ptr(points), B, N, int(nsamples), ptr(out), stream_ptr())
     return out
 
@@ -33,7 +33,7 @@ def gather_points(points, idx):
     out = torch.empty(B, C, M, dtype=torch.float32, device=points.device)
     if out.numel() == 0:  # empty batch: nothing to launch
         return out
-    with torch.cuda.device(points.device):
+    with on_device(points.device):
         call("unopose_gather_points", ptr(points), ptr(idx), B, C, N, M, ptr(out), stream_ptr())
     return out
 
@@ -45,7 +45,7 @@ def gather_points_grad(grad_out, idx, n):
     out = torch.zeros(B, C, int(n), dtype=torch.float32, device=grad_out.device)
     if out.numel() == 0:  # empty batch: nothing to launch
         return out
-    with torch.cuda.device(grad_out.device):
+    with on_device(grad_out.device):
         call("unopose_gather_points_grad", ptr(grad_out), ptr(idx), B, C, int(n), M, ptr(out), stream_ptr())
     return out
 
@@ -58,7 +58,7 @@ def ball_query(new_xyz, xyz, radius, nsample):
     idx = torch.empty(B, M, int(nsample), dtype=torch.int32, device=new_xyz.device)
     if idx.numel() == 0:  # empty batch: nothing to launch
         return idx
-    with torch.cuda.device(new_xyz.device):
+    with on_device(new_xyz.device):
         call("unopose_ball_query", ptr(new_xyz), ptr(xyz), B, N, M, float(radius), int(nsample), ptr(idx),
              stream_ptr())
     return idx
@@ -72,7 +72,7 @@ def group_points(points, idx):
     out = torch.empty(B, C, M, S, dtype=torch.float32, device=points.device)
     if out.numel() == 0:  # empty batch: nothing to launch
         return out
-    with torch.cuda.device(points.device):
+    with on_device(points.device):
         call("unopose_group_points", ptr(points), ptr(idx), B, C, N, M, S, ptr(out), stream_ptr())
     return out
 
@@ -84,7 +84,7 @@ def group_points_grad(grad_out, idx, n):
     out = torch.zeros(B, C, int(n), dtype=torch.float32, device=grad_out.device)
     if out.numel() == 0:  # empty batch: nothing to launch
         return out
-    with torch.cuda.device(grad_out.device):
+    with on_device(grad_out.device):
         call("unopose_group_points_grad", ptr(grad_out), ptr(idx), B, C, int(n), M, S, ptr(out), stream_ptr())
     return out
 
@@ -98,7 +98,7 @@ def three_nn(unknowns, knows):
     idx = torch.zeros(B, n, 3, dtype=torch.int32, device=unknowns.device)
     if dist2.numel() == 0:  # empty batch / no query points: nothing to launch
         return [dist2, idx]
-    with torch.cuda.device(unknowns.device):
+    with on_device(unknowns.device):
         call("unopose_three_nn", ptr(unknowns), ptr(knows), B, n, m, ptr(dist2), ptr(idx), stream_ptr())
     return [dist2, idx]
 
@@ -112,7 +112,7 @@ def three_interpolate(points, idx, weight):
     out = torch.empty(B, c, n, dtype=torch.float32, device=points.device)
     if out.numel() == 0:  # empty batch: nothing to launch
         return out
-    with torch.cuda.device(points.device):
+    with on_device(points.device):
         call("unopose_three_interpolate", ptr(points), ptr(idx), ptr(weight), B, c, m, n, ptr(out), stream_ptr())
     return out
 
@@ -125,7 +125,7 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     out = torch.zeros(B, c, int(m), dtype=torch.float32, device=grad_out.device)
     if out.numel() == 0:  # empty batch: nothing to launch
         return out
-    with torch.cuda.device(grad_out.device):
+    with on_device(grad_out.device):
         call("unopose_three_interpolate_grad", ptr(grad_out), ptr(idx), ptr(weight), B, c, n, int(m), ptr(out),
              stream_ptr())
     return out

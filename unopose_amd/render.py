@@ -6,7 +6,7 @@ call (so it can also be passed to the toolkit itself) plus a batched form for ma
 import numpy as np
 import torch
 
-from ._lib import call, ptr, stream_ptr
+from ._lib import call, on_device, ptr, stream_ptr
 
 
 class HipDepthRenderer:
@@ -31,7 +31,7 @@ class HipDepthRenderer:
         K4 = torch.as_tensor(np.asarray(K4, np.float32)).reshape(-1, 4)
         K4 = (K4.expand(P, 4) if K4.shape[0] == 1 else K4).contiguous().to(self.device)
         depth = torch.empty(P, self.H, self.W, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with on_device(self.device):
             call("unopose_render_depth", ptr(v), v.shape[0], ptr(f), f.shape[0], ptr(Rt), ptr(K4), P, self.H, self.W, ptr(depth),
                  stream_ptr(self.device))
         return depth
