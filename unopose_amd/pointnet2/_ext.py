@@ -17,9 +17,10 @@ from .._lib import call, check_f32, check_i32, on_device, ptr, stream_ptr
 def furthest_point_sampling(points, nsamples):
     check_f32(points, "points")
     B, N, _ = points.shape
-    out = torch.zeros(B, nsamples, dtype=torch.int32, device=points.device)
-    if out.numel() == 0:  # empty batch: nothing to launch
-        return out
+    if B == 0 or nsamples == 0 or N == 0:  # nothing to launch (the reference returns zeros)
+        return torch.zeros(B, nsamples, dtype=torch.int32, device=points.device)
+    # (the kernel writes every index, out[0] = 0 included: no zero fill -- a 67-us launch in front of each FPS chain when the GPU is busy)
+    out = torch.empty(B, nsamples, dtype=torch.int32, device=points.device)
     with on_device(points.device):
         call("unopose_furthest_point_sampling", ptr(points), B, N, int(nsamples), ptr(out), stream_ptr())
     return out
