@@ -29,6 +29,9 @@ namespace unopose {
 #ifndef GEMM_LNF_ABL
 #define GEMM_LNF_ABL 0  // EPI 6 / 7 timing ablations (wrong results): 1 = no LayerNorm math in the epilogue, 2 = no c / row-partial DMA, 3 = both
 #endif
+#ifndef GEMM_XPOL
+#define GEMM_XPOL 2  // cache policy of EPI 5's accesses to the fp32 residual stream (aux bits; 2 = nt): a stream of 540 MB per launch that is next read a whole block later -- default policy: proj 209 us at M = 87 936, nt 178, nt + sc0 183, nt + sc1 184, sc1 195-207; fc2 439-442 with every policy (round 6)
+#endif
 #define GEMM_BK 64
 constexpr bool kMfma = GEMM_ABL != 2, kFrag = GEMM_ABL != 3, kDma = GEMM_ABL != 1;
 
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
       auto load_round = [&](int r, f32x4(&dst)[4]) {  // round r = rows r * 16 .. + 15 of the wave's 128
 #pragma unroll
         for (int it = 0; it < 4; ++it)
-          dst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, x_v0 + (uint32_t)(r * 16 + it * 4) * x_rowb, 0, 0));
+          dst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, x_v0 + (uint32_t)(r * 16 + it * 4) * x_rowb, 0, GEMM_XPOL));
       };
 #pragma unroll
       for (int r = 0; r < PF; ++r) load_round(r, rv[r]);
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = a[e] + o[e];
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), x_rs, x_v0 + (uint32_t)(r * 16 + it * 4) * x_rowb, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), x_rs, x_v0 + (uint32_t)(r * 16 + it * 4) * x_rowb, 0, GEMM_XPOL);
           typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
           const u32x2 pk = {cvt_pk_bf16_f32(v[0], v[1]), cvt_pk_bf16_f32(v[2], v[3])};
           if (nt_store)
