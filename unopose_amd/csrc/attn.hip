@@ -224,6 +224,9 @@ __global__ __launch_bounds__(256, 2) void token_attn_kernel(const u16 *__restric
 // reads them): no barriers, only its own counted vmcnt -- the tile after next is issued as soon as the current one has been read, so
 // one to two tiles (8 - 16 KiB per wave, 64 - 128 KiB per CU) are in flight all the time.  Same MFMA order as token_attn_kernel<true>:
 // bit-identical results.
+#ifndef TA_EPOL
+#define TA_EPOL 1  // cache policy of the embedding stream's LDS-DMA loads (gemm_dma16<POL>: 0 default, 1 nt, 2 sc1, 3 sc0 sc1 nt).  The stream (1.27 GB per launch, read once) no longer pushes K / V^T -- re-read by every wave of a cloud -- out of L2: 291.5 -> 272.5 us at 64 x 197 x 197 x 256 (nt), 291 (sc1), 272 (sc0 sc1 nt); round 6
+#endif
 constexpr int TA_RING = 2 * 8192;  // per wave
 constexpr int TA_ROWS = 4;         // query rows per wave, processed in MFMA tiles of 4.  Measured at 64 x 197 x 197: 4 rows 290 us, 7 rows (4 + 3:
                                    // every wave task in ONE round of the 2048 wave slots) 305 us -- the kernel is bound by bytes in flight x latency, and
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void token_attn_rpe_dma_kernel(const u16 *_
     const uint32_t so = row0 + (uint32_t)r * (uint32_t)m * 512u + (uint32_t)t * 8192u;
     const uint32_t dst = lds0 + (uint32_t)(s & 1) * 8192u;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) gemm_dma16(dst + j * 1024, voff[j], e_rs, (int)so);
+    for (int j = 0; j < 8; ++j) gemm_dma16<TA_EPOL>(dst + j * 1024, voff[j], e_rs, (int)so);
   };
   issue_tile(0);
   if (total > 1) issue_tile(1);
