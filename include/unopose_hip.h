@@ -322,6 +322,13 @@ int unopose_linear_bf16_ld(const void *A, int lda, const void *W, int ldw, const
 int unopose_linear_add_layernorm_bf16(const void *A, const void *W, const float *bias, const void *resid, const float *ln_w,
                                       const float *ln_b, float eps, void *C, long M, int K, unopose_stream_t stream);
 
+/* linear_bf16 (bias only) for the token attention's fused projections (q | q W_p | k | v or k | v; model/transformer.py:130-148, 386-405): the
+ * LAST 256 output columns -- V -- are not written to C but TRANSPOSED and key-padded into vt (M / tokens clouds, 256, key_pad) bf16, keys
+ * tokens .. key_pad - 1 zero: the V^T operand of unopose_token_attention, without a transpose launch.  M = whole clouds of `tokens` rows;
+ * N % 128 == 0, K % 64 == 0; C (M, N) keeps its other columns. */
+int unopose_linear_bf16_kv_vt(const void *A, const void *W, const float *bias, void *C, void *vt, long M, int N, int K, int tokens, int key_pad,
+                              unopose_stream_t stream);
+
 /* Row-gathered grouped form of linear_bf16: C[r] = A[row_list[r]] . W[g(r)*256 .. +255]^T + bias, g(r) = the group of r's tile
  * (tile_info as written by upproj_plan; N / 256 groups).  A (M,K), W (N,K), C (max_tiles * 256, 256) bf16; bias fp32 (N).
  * The tile count is read on the device. */

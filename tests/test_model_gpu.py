@@ -390,6 +390,20 @@ def test_token_attention_kernel_bf16(model):
     for o, r in ((out_self, ref_self), (out_cross, ref_cross)):
         e = (o.float() - r).abs()
         assert e.max().item() < 3e-2 and e.mean().item() < 4e-3, (e.max().item(), e.mean().item())
+    # round 6: V^T written by the k | v projection's epilogue (csrc/gemm_small.hip EPI 4: transposed, key-padded with zeros) must equal the
+    # transpose launch it replaces bit for bit -- also for a cloud count whose rows end inside a tile and for 1 and 5 clouds
+    for Bc in (1, B, 5):
+        xs, ys = x[:1].repeat(Bc, 1, 1) + 0.01 * torch.arange(Bc, device="cuda").reshape(Bc, 1, 1), y[:1].repeat(Bc, 1, 1)
+        Es = E[:1].repeat(Bc, 1, 1, 1)
+        got = {}
+        for fused in (True, False):
+            ops.USE_KV_VT = fused
+            try:
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    got[fused] = (ops.token_attention(xs, xs, layer0, 4, Es), ops.token_attention(xs, ys, layer1, 4, None))
+            finally:
+                ops.USE_KV_VT = True
+        assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][1], got[False][1]), Bc
 
 
 @torch.no_grad()

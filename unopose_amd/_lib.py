@@ -44,6 +44,7 @@ SIGNATURES = {
     "unopose_fine_correspondences": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "unopose_upproj_plan": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "unopose_linear_add_layernorm_bf16": [_P, _P, _P, _P, _P, _P, _F, _P, ctypes.c_long, _I, _P],
+    "unopose_linear_bf16_kv_vt": [_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _I, _P],
     "unopose_linear_bf16_gather": [_P, ctypes.c_long, _I, _P, _I, _P, _P, _P, _I, _P, _P],
     "unopose_bilinear_sample_compact": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "unopose_fine_assign": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -201,6 +201,16 @@ int unopose_linear_add_layernorm_bf16(const void *A, const void *W, const float 
   return check_launch("linear_add_layernorm_bf16");
 }
 
+int unopose_linear_bf16_kv_vt(const void *A, const void *W, const float *bias, void *C, void *vt, long M, int N, int K, int tokens, int key_pad,
+                               unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(A && W && bias && C && vt, "linear_bf16_kv_vt: null pointer");
+  UNOPOSE_REQUIRE(M >= 1 && M < (1L << 31) && N >= 256 && N % 128 == 0 && K >= GEMM_BK && K % GEMM_BK == 0,
+                  "linear_bf16_kv_vt: needs N %% 128 == 0 (>= 256) and K %% 64 == 0 (got M=%ld N=%d K=%d)", M, N, K);
+  UNOPOSE_REQUIRE(tokens >= 1 && key_pad >= tokens && M % tokens == 0 && key_pad - tokens <= 64, "linear_bf16_kv_vt: M must be whole clouds of `tokens` rows, key_pad in [tokens, tokens + 64] (got %ld, %d, %d)", M, tokens, key_pad);
+  UNOPOSE_REQUIRE((size_t)M * K * 2 < (1UL << 32) && (size_t)N * K * 2 < (1UL << 32) && (size_t)M * N * 2 < (1UL << 32), "linear_bf16_kv_vt: operand larger than 4 GiB");
+  return gemm_small_linear_vt(A, W, bias, C, vt, M, N, K, tokens, key_pad, (hipStream_t)stream);
+}
+
 int unopose_linear_bf16_gather(const void *A, long M, int K, const void *W, int N, const float *bias, const int *row_list,
                                const int *tile_info, int max_tiles, void *C, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(A && W && bias && C && row_list && tile_info, "linear_bf16_gather: null pointer");

@@ -76,6 +76,7 @@ __device__ __forceinline__ void gemm_dma16(uint32_t lds_byte, uint32_t vo, __amd
 // Small-tile kernels (gemm_small.hip): 128 x 128 tiles for epilogue 0 / 1 / 2, 64 x 256 tiles for the residual + LayerNorm epilogue.
 int gemm_small_linear(const void *A, const void *W, const float *bias, void *C, long M, int N, int K, int lda, int ldw, int ldc, int epilogue,
                       hipStream_t s);
+int gemm_small_linear_vt(const void *A, const void *W, const float *bias, void *C, void *vt, long M, int N, int K, int tokens, int key_pad, hipStream_t s);
 int gemm_small_linear_ln(const void *A, const void *W, const float *bias, const void *resid, const float *ln_w, const float *ln_b, float eps,
                          void *C, long M, int K, hipStream_t s);
 

@@ -26,7 +26,11 @@ __global__ __launch_bounds__(256, (BM == 128 && NST == 2) ? 2 : 1) void gemm_sma
                                                                            const float *__restrict__ bias, u16 *__restrict__ C, int M, int N,
                                                                            int K, int tiles_m, int tiles_n, int lda, int ldw, int ldc,
                                                                            const u16 *__restrict__ resid, const float *__restrict__ ln_w,
-                                                                           const float *__restrict__ ln_b, float ln_eps) {
+                                                                           const float *__restrict__ ln_b, float ln_eps, u16 *__restrict__ vt = nullptr,
+                                                                           int vt_m = 0, int vt_pad = 0) {
+  // EPI 4 (round 6): bias only, and the LAST 256 columns -- the V half of the token attention's k | v projection (transformer.py:130-148,
+  // 386-405) -- leave TRANSPOSED and key-padded, vt[cloud][channel][key] with `vt_pad` keys per row of which the first `vt_m` are tokens and the rest
+  // zeros: the operand layout of unopose_token_attention, written by the projection itself instead of by a transpose launch per attention call.
   constexpr int WN = BN / 64, WM = 4 / WN;  // wave grid
   static_assert(WM * 64 == BM, "4 waves of 64 x 64");
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
@@ -234,6 +238,37 @@ __global__ __launch_bounds__(256, (BM == 128 && NST == 2) ? 2 : 1) void gemm_sma
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (EPI == 4 && n0 + wn * 64 >= N - 256) {
+    // this wave's 64 x 64 block belongs to V: lane = one token row (its 128 staged bytes come back as 8 x 16 B), then one 2-byte store per
+    // channel -- consecutive lanes are consecutive keys of a channel row of vt: whole contiguous runs, split only where a cloud ends
+    const int grow = m0 + wm * 64 + lane;
+    const int cb = grow / vt_m, key = grow - cb * vt_m;
+    const int ch0 = n0 + wn * 64 - (N - 256);
+    u16 *dst = vt + ((size_t)cb * 256 + ch0) * vt_pad + key;
+    u32x4 rowv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) rowv[q] = *reinterpret_cast<const u32x4 *>(cw + lane * 128 + ((q ^ (lane & 7)) << 4));
+    if (grow < M) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dst[(size_t)(q * 8 + 2 * e) * vt_pad] = (u16)(rowv[q][e] & 0xFFFFu);
+          dst[(size_t)(q * 8 + 2 * e + 1) * vt_pad] = (u16)(rowv[q][e] >> 16);
+        }
+    }
+    // the padding keys vt_m .. vt_pad - 1 of every cloud that ENDS inside this wave's rows: lanes 0 .. vt_pad - vt_m - 1 write the zeros
+    const int g0 = m0 + wm * 64, g1 = min(g0 + 64, M);  // rows [g0, g1)
+    for (int cbz = g0 / vt_m; cbz * vt_m + vt_m <= g1; ++cbz) {  // (wave-uniform: clouds whose last token lies in [g0, g1))
+      if (cbz * vt_m + vt_m - 1 < g0) continue;
+      if (lane < vt_pad - vt_m) {
+        u16 *z = vt + ((size_t)cbz * 256 + ch0) * vt_pad + vt_m + lane;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) z[(size_t)c * vt_pad] = 0;
+      }
+    }
+    return;
+  }
   const uint32_t c_v0 = (uint32_t)((((size_t)m0 + wm * 64 + (lane >> 3)) * ldc + n0 + wn * 64 + (lane & 7) * 8) * 2);
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
@@ -265,6 +300,15 @@ int gemm_small_linear(const void *A, const void *W, const float *bias, void *C, 
   return launch_small<128, 128, 0, 2>(A, W, bias, C, M, N, K, lda, ldw, ldc, nullptr, nullptr, nullptr, 0.f, s);
 }
 // N == 256: LayerNorm(A W^T + bias + resid) * ln_w + ln_b, 64-row tiles
+// bias only; the last 256 columns written transposed + key-padded into vt (EPI 4 above); C keeps the other columns (its last 256 are not written)
+int gemm_small_linear_vt(const void *A, const void *W, const float *bias, void *C, void *vt, long M, int N, int K, int tokens, int key_pad, hipStream_t s) {
+  const int tiles_m = cdiv(M, 128), tiles_n = N / 128;
+  const int tiles = tiles_m * tiles_n;
+  const int grid = ((tiles + 7) >> 3) << 3;
+  hipLaunchKernelGGL((gemm_small_kernel<128, 128, 4, 2>), dim3(grid), dim3(256), 0, s, (const u16 *)A, (const u16 *)W, bias, (u16 *)C, (int)M, N, K, tiles_m,
+                     tiles_n, K, K, N, (const u16 *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f, (u16 *)vt, tokens, key_pad);
+  return check_launch("linear_bf16_kv_vt");
+}
 int gemm_small_linear_ln(const void *A, const void *W, const float *bias, const void *resid, const float *ln_w, const float *ln_b, float eps,
                          void *C, long M, int K, hipStream_t s) {
   return launch_small<64, 256, 3, 2>(A, W, bias, C, M, 256, K, K, K, 256, resid, ln_w, ln_b, eps, s);

@@ -163,17 +163,33 @@ def _token_attention_hip(x, mem, att, embed):
     w_q, b_q, w_kv, b_kv, w_all, b_all, bq32, bkv32, ball32 = _attn_weights(att, rpe)
     nq = w_q.shape[0]
     xb = x.to(bf)
+    vt = torch.empty(B, C, _KEY_PAD, dtype=bf, device=x.device)
+
+    def project_kv(a2, w, b32, rows):
+        """a2 @ w^T + b with the V columns (the last 256) written straight into `vt` (csrc/gemm_small.hip EPI 4): no transpose launch"""
+        y = torch.empty(rows, w.shape[0], dtype=bf, device=x.device)
+        with on_device(x.device):
+            call("unopose_linear_bf16_kv_vt", ptr(a2), ptr(w), ptr(b32), ptr(y), ptr(vt), rows, w.shape[0], C, m, _KEY_PAD, stream_ptr())
+        return y
+
+    fused_vt = st.USE_KV_VT and C == 256 and _KEY_PAD - m <= 64 and st.USE_HIP_GEMM and st.HIP_GEMM_ALL
     with torch.autocast("cuda", enabled=False):
         if mem is x:  # self-attention: one GEMM for q | qp | k | v
-            y = bf16_linear_2d(xb.reshape(B * n, C), w_all, ball32, b_all).reshape(B, n, -1)
+            if fused_vt:
+                y = project_kv(_c(xb).reshape(B * n, C), w_all, ball32, B * n).reshape(B, n, -1)
+            else:
+                y = bf16_linear_2d(xb.reshape(B * n, C), w_all, ball32, b_all).reshape(B, n, -1)
             yq, ykv = y[..., :nq], y[..., nq:]
         else:
             yq = bf16_linear_2d(xb.reshape(B * n, C), w_q, bq32, b_q).reshape(B, n, -1)
-            ykv = bf16_linear_2d(mem.to(bf).reshape(B * m, C), w_kv, bkv32, b_kv).reshape(B, m, -1)
+            if fused_vt:
+                ykv = project_kv(_c(mem.to(bf)).reshape(B * m, C), w_kv, bkv32, B * m).reshape(B, m, -1)
+            else:
+                ykv = bf16_linear_2d(mem.to(bf).reshape(B * m, C), w_kv, bkv32, b_kv).reshape(B, m, -1)
     # q | qp and k | v are consumed in place from the projection outputs (row strides passed to the kernel)
-    vt = torch.empty(B, C, _KEY_PAD, dtype=bf, device=x.device)
-    with on_device(x.device):
-        call("unopose_transpose_pad_bf16", ctypes.c_void_p(ykv.data_ptr() + C * 2), ykv.stride(1), B, m, C, _KEY_PAD, ptr(vt), stream_ptr())
+    if not fused_vt:
+        with on_device(x.device):
+            call("unopose_transpose_pad_bf16", ctypes.c_void_p(ykv.data_ptr() + C * 2), ykv.stride(1), B, m, C, _KEY_PAD, ptr(vt), stream_ptr())
     E = _c(embed.to(bf)) if rpe else None
     out = torch.empty(B, n, C, dtype=bf, device=x.device)
     esz = 2
