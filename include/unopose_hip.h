@@ -454,6 +454,12 @@ int unopose_scale_residual(float *x, const void *y_bf16, const float *gamma, lon
 int unopose_linear_attention(const void *x, const float *inv_softplus_scale, const void *kvt,
                              const float *ksum, int B, int N, int focus, int mode, void *out,
                              unopose_stream_t stream);
+/* The key / value state of one layer in one launch (transformer.py:545-562: k's focusing, k.sum(dim=1) and the "bjhc,bjhd->bhcd"
+ * einsum): ykv (B,J,512) bf16 = [k projection | v] rows as the fused k | v projection writes them; kvt (B,4,64 d,64 c) bf16 and
+ * ksum (B,256) float32 come out in the layouts unopose_linear_attention(mode 0) reads.  The focused keys are rounded to bf16 before
+ * both sums (the values mode 1 writes). */
+int unopose_linear_attention_kv_state(const void *ykv, const float *inv_softplus_scale, int B, int J, int focus, void *kvt,
+                                      float *ksum, unopose_stream_t stream);
 /* Same function on float32 data (the reference's default precision, configs/main_cfg.py:87-89): x, kvt
  * and out are float32; the per-head contraction runs as hi/lo-split bf16 MFMAs (fp32-class accuracy). */
 int unopose_linear_attention_f32(const float *x, const float *inv_softplus_scale, const float *kvt,

@@ -519,6 +519,38 @@ def test_fused_linear_attention_kernel(model):
     e = (out.float() - ref).abs()
     scale = ref.abs().mean().item()
     assert e.mean().item() / scale < 2e-2 and e.max().item() / scale < 0.5, (e.mean().item(), e.max().item(), scale)
+    # the one-launch key / value state (round 6) against the 7-launch form it replaced: same bf16 focused keys, same fp32 sums up to order
+    ops.USE_LA_KV_STATE = False
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            old = ops.focused_linear_attention(xq, xkv, att, 4, 3)
+    finally:
+        ops.USE_LA_KV_STATE = True
+    d = (out.float() - old.float()).abs()
+    assert d.mean().item() / scale < 2e-3 and d.max().item() / scale < 0.1, (d.mean().item(), d.max().item(), scale)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("B,J", [(3, 196), (2, 128), (2, 129), (1, 7), (2, 300)])
+def test_linear_attention_kv_state_kernel(B, J):
+    """unopose_linear_attention_kv_state vs mode 1 + plain sums: ksum and kvt from the [k | v] rows, ragged token counts (rounds of 128)."""
+    import torch.nn.functional as F
+    from unopose_amd._lib import call, ptr, stream_ptr
+
+    g = torch.Generator().manual_seed(B * 1000 + J)
+    ykv = torch.randn(B, J, 512, generator=g).cuda().bfloat16()
+    inv_sp = (1.0 / F.softplus(torch.randn(256, generator=g))).cuda()
+    kf = torch.empty(B, J, 256, dtype=torch.bfloat16, device="cuda")
+    call("unopose_linear_attention", ptr(ykv[..., :256].contiguous()), ptr(inv_sp), None, None, B, J, 3, 1, ptr(kf), stream_ptr())
+    kvt = torch.full((B, 4, 64, 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ksum = torch.full((B, 256), float("nan"), device="cuda")
+    call("unopose_linear_attention_kv_state", ptr(ykv), ptr(inv_sp), B, J, 3, ptr(kvt), ptr(ksum), stream_ptr())
+    ks_ref = kf.double().sum(1)
+    kv_ref = torch.einsum("bjhd,bjhc->bhdc", ykv[..., 256:].double().reshape(B, J, 4, 64), kf.double().reshape(B, J, 4, 64))
+    assert torch.isfinite(ksum).all() and torch.isfinite(kvt.float()).all()
+    assert (ksum.double() - ks_ref).abs().max().item() <= 1e-5 * ks_ref.abs().max().item() + 1e-6
+    # bf16 output: half an ulp of the value (2^-9 relative) plus the fp32 summation's slack
+    assert ((kvt.double() - kv_ref).abs() <= 2.0 ** -8 * kv_ref.abs() + 1e-4 * kv_ref.abs().max()).all()
 
 
 

@@ -79,6 +79,7 @@ SIGNATURES = {
     "unopose_scale_residual": [_P, _P, _P, ctypes.c_long, _I, _P],
     "unopose_linear_attention": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "unopose_linear_attention_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "unopose_linear_attention_kv_state": [_P, _P, _I, _I, _I, _P, _P, _P],
     "unopose_linear_bf16": [_P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P],
     "unopose_gemm_bf16_tile": [],
     "unopose_gemm_fold_stagger": [_I],

@@ -22,6 +22,39 @@ __device__ __forceinline__ u16 la_f2bf(float f) {
 }
 __device__ __forceinline__ float la_bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
 
+// The focusing of one token row held in MFMA A-operand layout: the lane pair (lane, lane ^ 32) owns the row, lane half `hb` the 8-channel
+// runs [16 ks + 8 hb, +8).  q <- ((relu(x) + 1e-6) / softplus(scale))^3, returns |q_before| / |q_after| (the row's rescale factor).
+__device__ __forceinline__ float la_focus(const u16 *xr, const float *__restrict__ inv_sp, int hb, float (&q)[16][8]) {
+  float n1 = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    union { bf16x8 v; u16 u[8]; } f;
+    f.v = *reinterpret_cast<const bf16x8 *>(xr + ks * 16);
+    const float4 s0 = *reinterpret_cast<const float4 *>(inv_sp + ks * 16 + hb * 8);
+    const float4 s1 = *reinterpret_cast<const float4 *>(inv_sp + ks * 16 + hb * 8 + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = (fmaxf(la_bf2f(f.u[e]), 0.f) + 1e-6f) * sc[e];
+      q[ks][e] = v;
+      n1 += v * v;
+    }
+  }
+  n1 += __shfl_xor(n1, 32);
+  float n3 = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float p = q[ks][e];
+      p = p * p * p;  // focusing_factor = 3 (the only value the kernel is built for; checked by the host)
+      q[ks][e] = p;
+      n3 += p * p;
+    }
+  n3 += __shfl_xor(n3, 32);
+  return sqrtf(n1) / sqrtf(n3);
+}
+
 // x: (B,N,256) bf16 projected q (or k); inv_sp: (256) 1/softplus(scale); kvt: (B,4,64 d,64 c) bf16;
 // ksum: (B,256) fp32; out (B,N,256) bf16.
 template <int MODE>
@@ -52,34 +85,7 @@ __global__ __launch_bounds__(256) void linear_attn_kernel(const u16 *__restrict_
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const u16 *xr = &tile[wave][col][hb * 8];
   float q[16][8];
-  float n1 = 0.f;
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    union { bf16x8 v; u16 u[8]; } f;
-    f.v = *reinterpret_cast<const bf16x8 *>(xr + ks * 16);
-    const float4 s0 = *reinterpret_cast<const float4 *>(inv_sp + ks * 16 + hb * 8);
-    const float4 s1 = *reinterpret_cast<const float4 *>(inv_sp + ks * 16 + hb * 8 + 4);
-    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float v = (fmaxf(la_bf2f(f.u[e]), 0.f) + 1e-6f) * sc[e];
-      q[ks][e] = v;
-      n1 += v * v;
-    }
-  }
-  n1 += __shfl_xor(n1, 32);
-  float n3 = 0.f;
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float p = q[ks][e];
-      p = p * p * p;  // focusing_factor = 3 (the only value the kernel is built for; checked by the host)
-      q[ks][e] = p;
-      n3 += p * p;
-    }
-  n3 += __shfl_xor(n3, 32);
-  const float fac = sqrtf(n1) / sqrtf(n3);
+  const float fac = la_focus(xr, inv_sp, hb, q);
   bf16x8 qa[16];
   float zp[4] = {0.f, 0.f, 0.f, 0.f};
   const float *ks_b = ksum + (size_t)b * 256 + hb * 8;
@@ -143,6 +149,95 @@ __global__ __launch_bounds__(256) void linear_attn_kernel(const u16 *__restrict_
     }
   }
   store_tile();
+}
+
+// The key / value state of one layer in ONE launch: ykv (B,J,512) bf16 = [k projection | v] as the fused projection GEMM leaves it ->
+// kvt (B,4,64 d,64 c) bf16 = sum_j v[j,h,d] kf[j,h,c] and ksum (B,256) fp32 = sum_j kf[j], kf = the focused keys rounded to bf16 (the
+// values the MODE 1 kernel writes; here they never leave LDS).  One workgroup per pair; rounds of 128 tokens: wave w focuses rows
+// [32 w, +32) of the round in place in LDS, then wave h contracts head h over the round's tokens on the matrix cores (k = tokens: the
+// operands are gathered down LDS columns, 8 two-byte reads per fragment -- 100 KB per pair, latency does not matter here).
+__global__ __launch_bounds__(256) void linear_attn_kv_state_kernel(const u16 *__restrict__ ykv, const float *__restrict__ inv_sp, int J,
+                                                                   u16 *__restrict__ kvt, float *__restrict__ ksum) {
+  __shared__ __attribute__((aligned(16))) u16 kf_s[128][256 + 8];
+  __shared__ __attribute__((aligned(16))) u16 v_s[128][256 + 8];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, hb = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  float csum = 0.f;  // this thread's channel (= tid) of ksum
+  for (int r0 = 0; r0 < J; r0 += 128) {
+    {  // phase A: wave's 32 rows of the round
+      const int t0 = r0 + wave * 32;
+      const int nrows = max(0, min(32, J - t0));
+      const u16 *src = ykv + ((size_t)b * J + t0) * 512;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int e = i * 64 + lane, r = e >> 5, c8 = e & 31;  // row, 16-byte column
+        uint4 kq = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
+        if (r < nrows) {
+          kq = *reinterpret_cast<const uint4 *>(src + (size_t)r * 512 + c8 * 8);
+          vq = *reinterpret_cast<const uint4 *>(src + (size_t)r * 512 + 256 + c8 * 8);
+        }
+        *reinterpret_cast<uint4 *>(&kf_s[wave * 32 + r][c8 * 8]) = kq;
+        *reinterpret_cast<uint4 *>(&v_s[wave * 32 + r][c8 * 8]) = vq;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      u16 *xr = &kf_s[wave * 32 + col][hb * 8];
+      float q[16][8];
+      const float fac = la_focus(xr, inv_sp, hb, q);
+      const bool live = col < nrows;  // rows past the cloud contribute nothing (their focusing is 0 / 0)
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        union { bf16x8 v; u16 u[8]; } f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f.u[e] = live ? la_f2bf(q[ks][e] * fac) : (u16)0;
+        *reinterpret_cast<bf16x8 *>(xr + ks * 16) = f.v;  // the positions this lane read: no other lane touches them
+      }
+    }
+    __syncthreads();
+    const int valid = min(128, J - r0);
+#pragma unroll 8
+    for (int t = 0; t < valid; ++t) csum += la_bf2f(kf_s[t][tid]);
+    const int nk = (valid + 15) >> 4;
+#pragma unroll 2
+    for (int kk = 0; kk < nk; ++kk) {
+      bf16x8 av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        union { bf16x8 v; u16 u[8]; } fa, fb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          fa.u[e] = v_s[kk * 16 + hb * 8 + e][wave * 64 + i * 32 + col];
+          fb.u[e] = kf_s[kk * 16 + hb * 8 + e][wave * 64 + i * 32 + col];
+        }
+        av[i] = fa.v;
+        bv[i] = fb.v;
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  ksum[(size_t)b * 256 + tid] = csum;
+  u16 *dst = kvt + ((size_t)b * 4 + wave) * 64 * 64;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+        dst[d * 64 + nt * 32 + col] = la_f2bf(acc[mt][nt][r]);
+      }
 }
 
 // ---- fp32-class variant (the reference's default precision: no autocast) ------------------------------------
@@ -285,6 +380,17 @@ int unopose_linear_attention(const void *x, const float *inv_softplus_scale, con
     hipLaunchKernelGGL(linear_attn_kernel<0>, grid, dim3(256), 0, s, (const u16 *)x, inv_softplus_scale,
                        (const u16 *)kvt, ksum, N, focus, (u16 *)out);
   return check_launch("linear_attention");
+}
+
+int unopose_linear_attention_kv_state(const void *ykv, const float *inv_softplus_scale, int B, int J, int focus, void *kvt, float *ksum,
+                                      unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(ykv && inv_softplus_scale && kvt && ksum, "linear_attention_kv_state: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && J >= 1, "linear_attention_kv_state: bad sizes");
+  UNOPOSE_REQUIRE(focus == 3, "linear_attention_kv_state: built for focusing_factor = 3 (got %d)", focus);
+  if (B == 0) return UNOPOSE_OK;
+  hipLaunchKernelGGL(linear_attn_kv_state_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const u16 *)ykv, inv_softplus_scale, J,
+                     (u16 *)kvt, ksum);
+  return check_launch("linear_attention_kv_state");
 }
 
 int unopose_linear_attention_f32(const float *x, const float *inv_softplus_scale, const float *kvt, const float *ksum, int B,

@@ -280,9 +280,17 @@ def _focused_linear_attention_hip(xq, xkv, att, focusing):
     q = _c(linear(xq, att.proj_q))
     with torch.autocast("cuda", enabled=False):
         ykv = bf16_linear_2d(xkv.to(bf).reshape(B * j, C), w_kv, bkv32, b_kv).reshape(B, j, -1)
+    out = torch.empty(B, N, C, dtype=bf, device=xq.device)
+    if st.USE_LA_KV_STATE and C == 256:
+        # focused keys, their sum and k^T v in one launch, read from the projection's rows in place (csrc/linattn.hip)
+        kvt = torch.empty(B, 4, 64, 64, dtype=bf, device=xq.device)
+        ksum = torch.empty(B, C, dtype=torch.float32, device=xq.device)
+        with on_device(xq.device):
+            call("unopose_linear_attention_kv_state", ptr(ykv), ptr(inv_sp), B, j, focusing, ptr(kvt), ptr(ksum), stream_ptr())
+            call("unopose_linear_attention", ptr(q), ptr(inv_sp), ptr(kvt), ptr(ksum), B, N, focusing, 0, ptr(out), stream_ptr())
+        return out
     kproj, v = _c(ykv[..., :C]), ykv[..., C:]
     kf = torch.empty(B, j, C, dtype=bf, device=xq.device)
-    out = torch.empty(B, N, C, dtype=bf, device=xq.device)
     with on_device(xq.device):
         call("unopose_linear_attention", ptr(kproj), ptr(inv_sp), None, None, B, j, focusing, 1, ptr(kf),
              stream_ptr())
