@@ -455,11 +455,12 @@ int unopose_linear_attention(const void *x, const float *inv_softplus_scale, con
                              const float *ksum, int B, int N, int focus, int mode, void *out,
                              unopose_stream_t stream);
 /* The key / value state of one layer in one launch (transformer.py:545-562: k's focusing, k.sum(dim=1) and the "bjhc,bjhd->bhcd"
- * einsum): ykv (B,J,512) bf16 = [k projection | v] rows as the fused k | v projection writes them; kvt (B,4,64 d,64 c) bf16 and
- * ksum (B,256) float32 come out in the layouts unopose_linear_attention(mode 0) reads.  The focused keys are rounded to bf16 before
- * both sums (the values mode 1 writes). */
-int unopose_linear_attention_kv_state(const void *ykv, const float *inv_softplus_scale, int B, int J, int focus, void *kvt,
-                                      float *ksum, unopose_stream_t stream);
+ * einsum): ykv (B,rows_per_pair,512) bf16 = [k projection | v] rows as the fused k | v projection writes them, of which rows
+ * [first_row, first_row + J) of every pair are the tokens (the sparse-to-dense block's tokens sit behind their background-token row,
+ * transformer.py:655-668: first_row = 1); kvt (B,4,64 d,64 c) bf16 and ksum (B,256) float32 come out in the layouts
+ * unopose_linear_attention(mode 0) reads.  The focused keys are rounded to bf16 before both sums (the values mode 1 writes). */
+int unopose_linear_attention_kv_state(const void *ykv, const float *inv_softplus_scale, int B, int J, int rows_per_pair,
+                                      int first_row, int focus, void *kvt, float *ksum, unopose_stream_t stream);
 /* Same function on float32 data (the reference's default precision, configs/main_cfg.py:87-89): x, kvt
  * and out are float32; the per-head contraction runs as hi/lo-split bf16 MFMAs (fp32-class accuracy). */
 int unopose_linear_attention_f32(const float *x, const float *inv_softplus_scale, const float *kvt,
@@ -492,12 +493,13 @@ int unopose_row_dot(const void *x, int x_bf16, const float *w, float b, long row
 int unopose_normalize_rows_bf16(const void *x, int x_bf16, long rows, int C, float temp, void *out, unopose_stream_t stream);
 /* vt (B, C, pad) bf16: vt[b,c,j] = v[b,j,c] (rows of v `ld` elements apart), zero for m <= j < pad: the value image of
  * unopose_token_attention. */
-/* out (B, prepend + J, row) = rows of feats (B, N, row) picked by idx (B, J; int32 or int64): row idx - off, or alt (B, row) where
- * idx - off < 0; with prepend = 1 row 0 of every batch is alt as well.  Rows are row_bytes long (a multiple of 4, any element
+/* out (B, prepend + J, row) = rows of feats (B, N, row) picked by idx (B, J; int32 or int64): row idx - off, or alt (B rows,
+ * alt_stride_bytes apart: the background tokens may be row 0 of a (B, 1 + n, row) tensor) where idx - off < 0; with prepend = 1 row 0
+ * of every batch is alt as well.  Rows are row_bytes long (a multiple of 4, any element
  * type).  The (B,N,C)-layout gather the model uses instead of gather_operation's transposes (model_utils.py:146-149) and the
  * background-token sampling of the sparse-to-dense block (transformer.py:655-662: index 0 = the background token). */
 int unopose_gather_rows(const void *feats, int B, int N, int row_bytes, const void *idx, int idx_is_i64, int J, int off,
-                        const void *alt, int prepend, void *out, unopose_stream_t stream);
+                        const void *alt, long alt_stride_bytes, int prepend, void *out, unopose_stream_t stream);
 int unopose_transpose_pad_bf16(const void *v, long ld, int B, int m, int C, int pad, void *vt, unopose_stream_t stream);
 
 /* Small fp32 glue of the forward (round 5: the last torch reductions / elementwise kernels of the eval path).

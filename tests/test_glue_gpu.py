@@ -159,6 +159,10 @@ def test_gather_rows_kernel_matches_torch_composite():
             base = torch.where((idx == 0).unsqueeze(-1), bg.to(dtype), torch.gather(feats, 1, (idx.long() - 1).clamp(min=0).unsqueeze(2).expand(-1, -1, C)))
             assert torch.equal(ops.gather_rows(feats, idx, off=1, alt=bg), base)
             assert torch.equal(ops.gather_rows(feats, idx, off=1, alt=bg, prepend=True), torch.cat([bg.to(dtype), base], 1))
+            if (C * feats.element_size()) % 4 == 0:  # the alternative rows read in place as row 0 of a (B, 1 + n, C) tensor (no copy)
+                holder = torch.randn(5, 9, C, generator=g).cuda().to(dtype)
+                holder[:, 0:1] = bg.to(dtype)
+                assert torch.equal(ops.gather_rows(feats, idx, off=1, alt=holder[:, 0:1], prepend=True), torch.cat([bg.to(dtype), base], 1))
     # differentiable mode / tensors that carry gradients keep the autograd-recorded composite
     f = torch.randn(2, 10, 4, device="cuda", requires_grad=True)
     out = ops.gather_rows(f, torch.randint(0, 10, (2, 3), device="cuda"))

@@ -544,7 +544,13 @@ def test_linear_attention_kv_state_kernel(B, J):
     call("unopose_linear_attention", ptr(ykv[..., :256].contiguous()), ptr(inv_sp), None, None, B, J, 3, 1, ptr(kf), stream_ptr())
     kvt = torch.full((B, 4, 64, 64), float("nan"), dtype=torch.bfloat16, device="cuda")
     ksum = torch.full((B, 256), float("nan"), device="cuda")
-    call("unopose_linear_attention_kv_state", ptr(ykv), ptr(inv_sp), B, J, 3, ptr(kvt), ptr(ksum), stream_ptr())
+    call("unopose_linear_attention_kv_state", ptr(ykv), ptr(inv_sp), B, J, J, 0, 3, ptr(kvt), ptr(ksum), stream_ptr())
+    # the same tokens as rows [2, 2 + J) of J + 3 rows per pair (the sparse-to-dense block's window behind its background row): bit-equal
+    wide = torch.randn(B, J + 3, 512, generator=g).cuda().bfloat16()
+    wide[:, 2:2 + J] = ykv
+    kvt2, ksum2 = torch.empty_like(kvt), torch.empty_like(ksum)
+    call("unopose_linear_attention_kv_state", ptr(wide), ptr(inv_sp), B, J, J + 3, 2, 3, ptr(kvt2), ptr(ksum2), stream_ptr())
+    assert torch.equal(kvt, kvt2) and torch.equal(ksum, ksum2)
     ks_ref = kf.double().sum(1)
     kv_ref = torch.einsum("bjhd,bjhc->bhdc", ykv[..., 256:].double().reshape(B, J, 4, 64), kf.double().reshape(B, J, 4, 64))
     assert torch.isfinite(ksum).all() and torch.isfinite(kvt.float()).all()

@@ -18,6 +18,7 @@ _lib = None
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
+_L = ctypes.c_long
 
 # name -> argtypes (return type is always int).  Must list every symbol that
 # include/unopose_hip.h declares; tests/test_abi.py checks the two agree.
@@ -38,7 +39,7 @@ SIGNATURES = {
     "unopose_assign_labels": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "unopose_linear_bf16_ld": [_P, _I, _P, _I, _P, _P, _I, ctypes.c_long, _I, _I, _I, _P],
     "unopose_scale_residual_layernorm_f32": [_P, _P, _P, _P, _P, ctypes.c_long, _I, _F, _P, _P],
-    "unopose_gather_rows": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P],
+    "unopose_gather_rows": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _L, _I, _P, _P],
     "unopose_softmax_stats": [_P, _I, _I, _I, _P, _P],
     "unopose_infonce_grad": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "unopose_fine_correspondences": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -79,7 +80,7 @@ SIGNATURES = {
     "unopose_scale_residual": [_P, _P, _P, ctypes.c_long, _I, _P],
     "unopose_linear_attention": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "unopose_linear_attention_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
-    "unopose_linear_attention_kv_state": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "unopose_linear_attention_kv_state": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "unopose_linear_bf16": [_P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P],
     "unopose_gemm_bf16_tile": [],
     "unopose_gemm_fold_stagger": [_I],

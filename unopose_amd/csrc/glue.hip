@@ -160,8 +160,8 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const u16 *__restric
 //      One launch instead of index cast + clamp + gather + compare + where + cat.
 template <typename IDX>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t *__restrict__ feats, const IDX *__restrict__ idx,
-                                                          const uint32_t *__restrict__ alt, int N, int J, int words, int off, int prepend,
-                                                          uint32_t *__restrict__ out) {
+                                                          const uint32_t *__restrict__ alt, int alt_words, int N, int J, int words, int off,
+                                                          int prepend, uint32_t *__restrict__ out) {
   const int b = blockIdx.y, rows = J + prepend;
   const long total = (long)rows * words;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t *__rest
     if (r >= prepend) src = (long)idx[(size_t)b * J + (r - prepend)] - off;
     uint32_t v;
     if (src < 0)
-      v = alt ? alt[(size_t)b * words + w] : 0u;
+      v = alt ? alt[(size_t)b * alt_words + w] : 0u;
     else
       v = feats[((size_t)b * N + (size_t)min(src, (long)N - 1)) * words + w];
     out[((size_t)b * rows + r) * words + w] = v;
@@ -357,19 +357,21 @@ using namespace unopose;
 extern "C" {
 
 int unopose_gather_rows(const void *feats, int B, int N, int row_bytes, const void *idx, int idx_is_i64, int J, int off, const void *alt,
-                        int prepend, void *out, unopose_stream_t stream) {
+                        long alt_stride_bytes, int prepend, void *out, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(feats && idx && out, "gather_rows: null pointer");
   UNOPOSE_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && J >= 1 && row_bytes >= 4 && row_bytes % 4 == 0 && (off == 0 || off == 1) && (prepend == 0 || prepend == 1),
                   "gather_rows: bad sizes (B=%d N=%d J=%d row_bytes=%d)", B, N, J, row_bytes);
   UNOPOSE_REQUIRE(alt || (off == 0 && prepend == 0), "gather_rows: off / prepend need the alternative row");
-  const int words = row_bytes / 4;
+  UNOPOSE_REQUIRE(!alt || (alt_stride_bytes >= row_bytes && alt_stride_bytes % 4 == 0 && alt_stride_bytes / 4 <= 0x7FFFFFFF),
+                  "gather_rows: alt rows must be >= row_bytes apart, a multiple of 4 (got %ld)", alt_stride_bytes);
+  const int words = row_bytes / 4, alt_words = (int)(alt_stride_bytes / 4);
   const dim3 grid((unsigned)std::min<long>(((long)(J + prepend) * words + 255) / 256, 4096), B);
   if (idx_is_i64)
     hipLaunchKernelGGL(gather_rows_kernel<long long>, grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t *)feats, (const long long *)idx,
-                       (const uint32_t *)alt, N, J, words, off, prepend, (uint32_t *)out);
+                       (const uint32_t *)alt, alt_words, N, J, words, off, prepend, (uint32_t *)out);
   else
-    hipLaunchKernelGGL(gather_rows_kernel<int>, grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t *)feats, (const int *)idx, (const uint32_t *)alt, N,
-                       J, words, off, prepend, (uint32_t *)out);
+    hipLaunchKernelGGL(gather_rows_kernel<int>, grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t *)feats, (const int *)idx, (const uint32_t *)alt,
+                       alt_words, N, J, words, off, prepend, (uint32_t *)out);
   return check_launch("gather_rows");
 }
 

@@ -156,8 +156,10 @@ __global__ __launch_bounds__(256) void linear_attn_kernel(const u16 *__restrict_
 // values the MODE 1 kernel writes; here they never leave LDS).  One workgroup per pair; rounds of 128 tokens: wave w focuses rows
 // [32 w, +32) of the round in place in LDS, then wave h contracts head h over the round's tokens on the matrix cores (k = tokens: the
 // operands are gathered down LDS columns, 8 two-byte reads per fragment -- 100 KB per pair, latency does not matter here).
+// A pair's rows are [j0, j0 + J) of its Jrows rows in memory (the sparse-to-dense block projects the background-token row along
+// with the 196 tokens rather than copying them out: j0 = 1).
 __global__ __launch_bounds__(256) void linear_attn_kv_state_kernel(const u16 *__restrict__ ykv, const float *__restrict__ inv_sp, int J,
-                                                                   u16 *__restrict__ kvt, float *__restrict__ ksum) {
+                                                                   int Jrows, int j0, u16 *__restrict__ kvt, float *__restrict__ ksum) {
   __shared__ __attribute__((aligned(16))) u16 kf_s[128][256 + 8];
   __shared__ __attribute__((aligned(16))) u16 v_s[128][256 + 8];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void linear_attn_kv_state_kernel(const u16 *__
     {  // phase A: wave's 32 rows of the round
       const int t0 = r0 + wave * 32;
       const int nrows = max(0, min(32, J - t0));
-      const u16 *src = ykv + ((size_t)b * J + t0) * 512;
+      const u16 *src = ykv + ((size_t)b * Jrows + j0 + t0) * 512;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int e = i * 64 + lane, r = e >> 5, c8 = e & 31;  // row, 16-byte column
@@ -382,14 +384,14 @@ int unopose_linear_attention(const void *x, const float *inv_softplus_scale, con
   return check_launch("linear_attention");
 }
 
-int unopose_linear_attention_kv_state(const void *ykv, const float *inv_softplus_scale, int B, int J, int focus, void *kvt, float *ksum,
-                                      unopose_stream_t stream) {
+int unopose_linear_attention_kv_state(const void *ykv, const float *inv_softplus_scale, int B, int J, int rows_per_pair, int first_row,
+                                      int focus, void *kvt, float *ksum, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(ykv && inv_softplus_scale && kvt && ksum, "linear_attention_kv_state: null pointer");
-  UNOPOSE_REQUIRE(B >= 0 && J >= 1, "linear_attention_kv_state: bad sizes");
+  UNOPOSE_REQUIRE(B >= 0 && J >= 1 && first_row >= 0 && rows_per_pair >= first_row + J, "linear_attention_kv_state: bad sizes");
   UNOPOSE_REQUIRE(focus == 3, "linear_attention_kv_state: built for focusing_factor = 3 (got %d)", focus);
   if (B == 0) return UNOPOSE_OK;
   hipLaunchKernelGGL(linear_attn_kv_state_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const u16 *)ykv, inv_softplus_scale, J,
-                     (u16 *)kvt, ksum);
+                     rows_per_pair, first_row, (u16 *)kvt, ksum);
   return check_launch("linear_attention_kv_state");
 }
 

@@ -344,9 +344,10 @@ class _AttentionOutput(nn.Module):
         self.squeeze = nn.Linear(2 * d, d)
         self.norm = nn.LayerNorm(d)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         if x.is_cuda and not ops.is_differentiable():  # squeeze + residual + LayerNorm: one launch under autocast
-            return ops.ffn_add_layernorm(x, self.expand, self.squeeze, self.norm)
+            return ops.ffn_add_layernorm(x, self.expand, self.squeeze, self.norm, out=out)
+        assert out is None
         return self.norm(x + ops.linear(ops.linear(x, self.expand, relu=True), self.squeeze))
 
 
@@ -359,7 +360,8 @@ class TransformerLayer(nn.Module):
         self.attention = _AttentionLayer(d, rpe)
         self.output = _AttentionOutput(d)
 
-    def forward(self, x, mem, embed=None):
+    def forward(self, x, mem, embed=None, out=None):
+        """`out` (inference on the GPU only): a contiguous tensor of x's shape the layer's result is written into."""
         a = self.attention
         if mem is None:  # self-attention
             mem = x
@@ -368,7 +370,7 @@ class TransformerLayer(nn.Module):
             x = ops.linear_add_layernorm(h, a.linear, x, a.norm)
         else:
             x = a.norm(ops.linear(h, a.linear) + x)
-        return self.output(x)
+        return self.output(x, out=out)
 
 
 class GeometricTransformer(nn.Module):
@@ -382,26 +384,31 @@ class GeometricTransformer(nn.Module):
         e_all = _adjacent(e0, e1)
         if e_all is not None and f0.shape == f1.shape:
             # the self layer shares its weights between the clouds (T:498-499): run both as ONE batch of 2B
-            # (the embeddings of the two clouds were produced back to back in one buffer)
+            # (the embeddings of the two clouds were produced back to back in one buffer -- and so were the features when the
+            # previous block's cross layers wrote them, see forward_stacked)
+            f = _adjacent(f0, f1)
+            f = self.forward_stacked(torch.cat([f0, f1], 0) if f is None else f, e_all)
             B = f0.shape[0]
-            f = self.layers[0](torch.cat([f0, f1], 0), None, e_all)
-            f0, f1 = f[:B], f[B:]
-        else:
-            f0 = self.layers[0](f0, f0, e0)
-            f1 = self.layers[0](f1, f1, e1)
+            return f[:B], f[B:]
+        f0 = self.layers[0](f0, f0, e0)
+        f1 = self.layers[0](f1, f1, e1)
         f0 = self.layers[1](f0, f1)
         f1 = self.layers[1](f1, f0)
         return f0, f1
 
     def forward_stacked(self, f, e_all):
-        """Both clouds as one (2B, n, C) batch (cloud 0 = first half) with their embeddings stacked the
-        same way; returns (f0, f1)."""
+        """Both clouds as one (2B, n, C) batch (cloud 0 = first half) with their embeddings stacked the same way; returns the
+        block's output stacked the same way: on the GPU the two cross layers write the halves of ONE tensor (no concatenation
+        before the next block's 2B self layer or the sparse-to-dense block's dense layer)."""
         B = f.shape[0] // 2
         f = self.layers[0](f, None, e_all)
-        f0, f1 = f[:B], f[B:]
-        f0 = self.layers[1](f0, f1)
-        f1 = self.layers[1](f1, f0)
-        return f0, f1
+        if ops.USE_STACKED_OUT and f.is_cuda and not ops.is_differentiable():
+            out = torch.empty_like(f, memory_format=torch.contiguous_format)
+            f0 = self.layers[1](f[:B], f[B:], out=out[:B])
+            self.layers[1](f[B:], f0, out=out[B:])
+            return out
+        f0 = self.layers[1](f[:B], f[B:])
+        return torch.cat([f0, self.layers[1](f[B:], f0)], 0)
 
 
 def _adjacent(e0, e1):
@@ -439,9 +446,11 @@ class LinearTransformerLayer(nn.Module):
         self.attention = _LinearAttentionLayer(d)
         self.output = _AttentionOutput(d)
 
-    def forward(self, x, mem):
+    def forward(self, x, mem, kv_skip=0):
+        """`kv_skip`: the first rows of every batch of `mem` that are NOT keys / values (the background-token row of a stacked
+        (2B, 1 + n, C) block output, read in place instead of sliced into a copy)."""
         a = self.attention
-        h = ops.focused_linear_attention(x, mem, a.attention, self.heads, self.focusing_factor)
+        h = ops.focused_linear_attention(x, mem, a.attention, self.heads, self.focusing_factor, kv_skip=kv_skip)
         if x.is_cuda and not ops.is_differentiable():
             x = ops.linear_add_layernorm(h, a.linear, x, a.norm)
         else:
@@ -480,9 +489,10 @@ class SparseToDenseTransformer(nn.Module):
         re-assembled per block (the reference's layout costs two 134 MB concatenations per block at B=32).
         Returns the new (dense, bg)."""
         # T:655-662 with App-E.2's off-by-one: index i addresses row i of [bg | dense], i.e. bg for i == 0
-        f0, f1 = self.sparse_layer.forward_stacked(ops.gather_rows(dense, idx_all, off=1, alt=bg, prepend=True), e_all)
-        new = self.dense_layer(dense, torch.cat([f0[:, 1:], f1[:, 1:]], 0))
-        return new, torch.cat([f0[:, 0:1], f1[:, 0:1]], 0)
+        f = self.sparse_layer.forward_stacked(ops.gather_rows(dense, idx_all, off=1, alt=bg, prepend=True), e_all)
+        if not ops.USE_STACKED_OUT:  # round 5's form (A/B): keys / values and background rows copied out of the block output
+            return self.dense_layer(dense, f[:, 1:].contiguous()), f[:, 0:1].contiguous()
+        return self.dense_layer(dense, f, kv_skip=1), f[:, 0:1]  # (the background rows stay where they are: a strided view)
 
 
 # -------------------------------------------------------------- PE ----------

@@ -21,7 +21,7 @@ from .dense import (  # noqa: F401
     linear_f32x3_bf16, linear_f32_raw, _transposed_weights, _LinearFn, _ZERO_BIAS, _zero_bias, linear_train, _lin, mlp, linear,
     ffn_add_layernorm, linear_add_layernorm, patch_embed, vit_prologue_ok, vit_prologue, bmm_nt_f32, score_head, add_layernorm,
     scale_residual_, scale_residual_layernorm_f32_, vit_f32_fused_ok, scale_residual_layernorm_, ln_fold_ok, _fold_producer_weights,
-    _fold_consumer_weights, linear_residual_, linear_lnfold,
+    _fold_consumer_weights, linear_residual_, linear_lnfold, _into,
 )
 from .attention import (  # noqa: F401
     vit_attention, vit_attention_f32_split, vit_attention_f32_ss, vit_attention_torch, _KEY_PAD, token_attention,
@@ -45,7 +45,7 @@ from .train import (  # noqa: F401
     nearest_partner, _CONV_FWD_PAIRS, _CONV_WGRAD_PAIRS, _conv1x1_pair_ok, _conv1x1_wgrad_ok, _Conv1x1Fn, conv1x1,
 )
 
-_SWITCHES = frozenset(['FORBID_LIBRARY_BF16_GEMM', 'GEO_TABLE', 'GEO_TABLE_F32', 'HIP_GEMM_ALL', 'TRAIN_FUSED_SALIENCY', 'TRAIN_OWN_CONV', 'TRAIN_OWN_GEMM', 'TRAIN_OWN_GEMM_MIN_FLOP', 'TRAIN_OWN_GEO', 'TRAIN_OWN_WGRAD', 'TRAIN_OWN_WGRAD_MIN_ROWS', 'USE_F32X3', 'USE_FUSED_BN_RELU', 'USE_FUSED_FINE', 'USE_FUSED_INFONCE', 'USE_FUSED_LINEAR_LN', 'USE_HIP_GEMM', 'USE_KV_VT', 'USE_LA_KV_STATE', 'USE_LN_FOLD', 'USE_SPARSE_UPPROJ', '_DIFF'])
+_SWITCHES = frozenset(['FORBID_LIBRARY_BF16_GEMM', 'GEO_TABLE', 'GEO_TABLE_F32', 'HIP_GEMM_ALL', 'TRAIN_FUSED_SALIENCY', 'TRAIN_OWN_CONV', 'TRAIN_OWN_GEMM', 'TRAIN_OWN_GEMM_MIN_FLOP', 'TRAIN_OWN_GEO', 'TRAIN_OWN_WGRAD', 'TRAIN_OWN_WGRAD_MIN_ROWS', 'USE_F32X3', 'USE_FUSED_BN_RELU', 'USE_FUSED_FINE', 'USE_FUSED_INFONCE', 'USE_FUSED_LINEAR_LN', 'USE_HIP_GEMM', 'USE_KV_VT', 'USE_LA_KV_STATE', 'USE_LN_FOLD', 'USE_SPARSE_UPPROJ', 'USE_STACKED_OUT', '_DIFF'])
 
 
 class _OpsModule(types.ModuleType):

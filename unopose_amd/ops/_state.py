@@ -24,6 +24,8 @@ GEO_TABLE_F32 = True  # fp32 result through the 6-point table kernel; False: the
 USE_SPARSE_UPPROJ = True  # only the map cells the chosen pixels' bilinear taps read are up-projected (csrc/upproj.hip)
 USE_KV_VT = True  # round 6: the token attention's V^T operand written by the k | v projection's epilogue (csrc/gemm_small.hip EPI 4); False: a transpose launch
 USE_LA_KV_STATE = True  # round 6: the linear attention's key / value state (focused keys, their sum, k^T v) in one launch (csrc/linattn.hip); False: 7 launches
+USE_STACKED_OUT = True  # round 6: a matcher block's two cross layers write the halves of ONE stacked tensor, the dense layer reads its keys / values
+                        # behind the background row in place; False: concatenations / slices copied out (4 more launches per block)
 USE_FUSED_FINE = True  # bf16 fine stage without the (B, N1 + 1, N2 + 1) similarity (csrc/fineassign.hip)
 
 # ---- training step (ops/train.py, ops/dense.py `_LinearFn`, ops/geometry.py `_GeoEmbedFn`)

@@ -219,13 +219,20 @@ def token_attention_torch(x, mem, att, heads, embed=None):
     return torch.einsum("bhnm,bmhc->bnhc", p, v).reshape(B, n, C)
 
 
-def focused_linear_attention(xq, xkv, att, heads, focusing):
+def focused_linear_attention(xq, xkv, att, heads, focusing, kv_skip=0):
     """LinearAttention.forward (transformer.py:533-568).  With 4 heads x 64 the focusing + per-head
     contraction + z scaling run in ONE HIP kernel per side (csrc/linattn.hip): bf16 MFMAs under autocast,
-    hi/lo-split (fp32-class) MFMAs on fp32 data; other shapes take the op-by-op composite."""
+    hi/lo-split (fp32-class) MFMAs on fp32 data; other shapes take the op-by-op composite.
+    `kv_skip`: leading rows of every batch of xkv that are not keys / values (xkv[:, kv_skip:] is meant; the bf16 kernels read the
+    window in place, the other paths slice)."""
     if not st._DIFF and heads == 4 and xq.shape[-1] == 256 and xq.is_cuda and float(focusing) == 3.0:
         if torch.is_autocast_enabled():
-            return _focused_linear_attention_hip(xq, xkv, att, int(focusing))
+            if kv_skip and not (st.USE_LA_KV_STATE and xkv.is_contiguous()):
+                xkv, kv_skip = xkv[:, kv_skip:], 0
+            return _focused_linear_attention_hip(xq, xkv, att, int(focusing), kv_skip)
+    if kv_skip:
+        xkv = xkv[:, kv_skip:]
+    if not st._DIFF and heads == 4 and xq.shape[-1] == 256 and xq.is_cuda and float(focusing) == 3.0:
         if xq.dtype == torch.float32 and xkv.dtype == torch.float32:
             return _focused_linear_attention_hip_f32(xq, xkv, att, int(focusing))
     if not st._DIFF and xq.is_cuda:
@@ -263,10 +270,11 @@ def _focused_linear_attention_hip_f32(xq, xkv, att, focusing):
     return out
 
 
-def _focused_linear_attention_hip(xq, xkv, att, focusing):
+def _focused_linear_attention_hip(xq, xkv, att, focusing, kv_skip=0):
     bf = torch.bfloat16
     B, N, C = xq.shape
-    j = xkv.shape[1]
+    jr = xkv.shape[1]  # rows per pair in memory: the projection runs over all of them, the state over [kv_skip, jr)
+    j = jr - kv_skip
     key = _params_key(att)
     cache = getattr(att, "_hip_cache", None)
     if cache is None or cache[0] != key:
@@ -279,16 +287,17 @@ def _focused_linear_attention_hip(xq, xkv, att, focusing):
     _, w_kv, b_kv, inv_sp, bkv32 = cache
     q = _c(linear(xq, att.proj_q))
     with torch.autocast("cuda", enabled=False):
-        ykv = bf16_linear_2d(xkv.to(bf).reshape(B * j, C), w_kv, bkv32, b_kv).reshape(B, j, -1)
+        ykv = bf16_linear_2d(xkv.to(bf).reshape(B * jr, C), w_kv, bkv32, b_kv).reshape(B, jr, -1)
     out = torch.empty(B, N, C, dtype=bf, device=xq.device)
     if st.USE_LA_KV_STATE and C == 256:
         # focused keys, their sum and k^T v in one launch, read from the projection's rows in place (csrc/linattn.hip)
         kvt = torch.empty(B, 4, 64, 64, dtype=bf, device=xq.device)
         ksum = torch.empty(B, C, dtype=torch.float32, device=xq.device)
         with on_device(xq.device):
-            call("unopose_linear_attention_kv_state", ptr(ykv), ptr(inv_sp), B, j, focusing, ptr(kvt), ptr(ksum), stream_ptr())
+            call("unopose_linear_attention_kv_state", ptr(ykv), ptr(inv_sp), B, j, jr, kv_skip, focusing, ptr(kvt), ptr(ksum), stream_ptr())
             call("unopose_linear_attention", ptr(q), ptr(inv_sp), ptr(kvt), ptr(ksum), B, N, focusing, 0, ptr(out), stream_ptr())
         return out
+    assert kv_skip == 0
     kproj, v = _c(ykv[..., :C]), ykv[..., C:]
     kf = torch.empty(B, j, C, dtype=bf, device=xq.device)
     with on_device(xq.device):

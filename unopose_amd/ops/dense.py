@@ -301,7 +301,7 @@ def linear(x, lin, relu=False, gelu=False):
         return F.relu(y) if relu else (F.gelu(y) if gelu else y)
 
 
-def ffn_add_layernorm(x, expand, squeeze, norm):
+def ffn_add_layernorm(x, expand, squeeze, norm, out=None):
     """LayerNorm(x + squeeze(relu(expand(x)))): the transformer layers' output block (transformer.py:151-193 `AttentionOutput`).
     fp32: the hidden activation goes from one fp32-class GEMM to the next in the split layout (never materialised in fp32, no split
     pass); autocast: expand + ReLU, then squeeze + residual + LayerNorm in one GEMM epilogue."""
@@ -312,14 +312,25 @@ def ffn_add_layernorm(x, expand, squeeze, norm):
         c1, c2 = _f32x3_weights(expand), _f32x3_weights(squeeze)
         hs = linear_f32x3(split_f32(_c(x).reshape(rows, K1)), c1[1], c1[2], rows, N1, K1, relu=True, out="split")
         y = linear_f32x3(hs, c2[1], c2[2], rows, N2, K2).reshape(*x.shape[:-1], N2)
-        return add_layernorm(y, x, norm)
-    return linear_add_layernorm(linear(x, expand, relu=True), squeeze, x, norm)
+        return _into(out, add_layernorm(y, x, norm))
+    return linear_add_layernorm(linear(x, expand, relu=True), squeeze, x, norm, out=out)
 
 
-def linear_add_layernorm(h, lin, x, norm):
+def _into(out, y):
+    """y, or `out` filled with y when the caller named a destination the producing kernel could not write itself."""
+    if out is None:
+        return y
+    note_mutation()
+    out.copy_(y)
+    return out
+
+
+def linear_add_layernorm(h, lin, x, norm, out=None):
     """LayerNorm(lin(h) + x): the post-LN glue after an attention output projection / FFN squeeze (transformer.py:151-193).
     256-wide layers under autocast run as ONE launch -- residual add and LayerNorm in the epilogue of csrc/gemm.hip, on the
-    fp32 accumulators (the unfused form rounds lin(h) to bf16 first); everything else: add_layernorm(linear(h), x)."""
+    fp32 accumulators (the unfused form rounds lin(h) to bf16 first); everything else: add_layernorm(linear(h), x).
+    `out`: a contiguous tensor of the result's shape the result is written INTO (the kernel's own output buffer when it is bf16: the
+    cross layers of a matcher block fill the two halves of one stacked tensor instead of being concatenated afterwards)."""
     N, K = lin.weight.shape
     rows = h.numel() // K
     if (st.USE_FUSED_LINEAR_LN and not st._DIFF and h.is_cuda and torch.is_autocast_enabled() and st.HIP_GEMM_ALL and N == 256
@@ -328,12 +339,15 @@ def linear_add_layernorm(h, lin, x, norm):
         with torch.autocast("cuda", enabled=False):
             hb = _c(h if h.dtype == torch.bfloat16 else h.to(torch.bfloat16)).reshape(rows, K)
             xb = _c(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)).reshape(rows, N)
-            out = torch.empty(rows, N, dtype=torch.bfloat16, device=h.device)
+            direct = out is not None and out.dtype == torch.bfloat16 and out.is_contiguous() and out.numel() == rows * N and out.device == h.device
+            if direct:
+                note_mutation()
+            y = out if direct else torch.empty(rows, N, dtype=torch.bfloat16, device=h.device)
             with on_device(h.device):
                 call("unopose_linear_add_layernorm_bf16", ptr(hb), ptr(cache[1]), ptr(cache[3]), ptr(xb), ptr(norm.weight.detach()),
-                     ptr(norm.bias.detach()), float(norm.eps), ptr(out), rows, K, stream_ptr())
-        return out.reshape(*h.shape[:-1], N)
-    return add_layernorm(linear(h, lin), x, norm)
+                     ptr(norm.bias.detach()), float(norm.eps), ptr(y), rows, K, stream_ptr())
+        return out if direct else _into(out, y.reshape(*h.shape[:-1], N))
+    return _into(out, add_layernorm(linear(h, lin), x, norm))
 
 
 def patch_embed(patches, conv):

@@ -114,12 +114,18 @@ def gather_rows(feats, idx, off=0, alt=None, prepend=False):
     J = idx.shape[1]
     if (feats.is_cuda and not st._DIFF and not feats.requires_grad and feats.is_contiguous() and idx.is_contiguous() and idx.dtype in (torch.int32, torch.int64)
             and (C * feats.element_size()) % 4 == 0 and B <= 65535):
+        alt_stride = 0
         if alt is not None:
-            alt = _c(alt.reshape(B, C).to(feats.dtype))
+            alt = alt.reshape(B, C)
+            if alt.dtype != feats.dtype or alt.stride(1) != 1 or alt.stride(0) < C:  # (rows any distance apart are read in place: the
+                alt = _c(alt.to(feats.dtype))                                        #  background tokens as row 0 of a (B, 1 + n, C) tensor)
+            alt_stride = (alt.stride(0) if B > 1 else C) * feats.element_size()
+            if alt_stride % 4:
+                alt, alt_stride = alt.contiguous(), C * feats.element_size()
         out = torch.empty(B, J + int(prepend), C, dtype=feats.dtype, device=feats.device)
         with on_device(feats.device):
             call("unopose_gather_rows", ptr(feats), B, N, C * feats.element_size(), ptr(idx), int(idx.dtype == torch.int64), J, int(off),
-                 None if alt is None else ptr(alt), int(prepend), ptr(out), stream_ptr())
+                 None if alt is None else ptr(alt), alt_stride, int(prepend), ptr(out), stream_ptr())
         return out
     if off == 0 and alt is None:
         return torch.gather(feats, 1, idx.long().unsqueeze(2).expand(-1, -1, C))
