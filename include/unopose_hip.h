@@ -335,10 +335,11 @@ int unopose_linear_bf16_kv_vt(const void *A, const void *W, const float *bias, v
 int unopose_linear_bf16_gather(const void *A, long M, int K, const void *W, int N, const float *bias, const int *row_list,
                                const int *tile_info, int max_tiles, void *C, unopose_stream_t stream);
 
-/* out (B2,Np,256) fp32 = bilinear blend of the 4 compact rows of each chosen pixel (torch upsample_bilinear2d,
- * align_corners=False, then the pixel gather). */
+/* out (B2,Np,256) = bilinear blend (fp32 arithmetic) of the 4 compact rows of each chosen pixel (torch upsample_bilinear2d,
+ * align_corners=False, then the pixel gather); float32, or with out_bf16 rounded to bf16 (under autocast the reference's features are
+ * half precision from the up-projection on, and the next consumer is an autocast Linear). */
 int unopose_bilinear_sample_compact(const void *Cc, const int *cellmap, const long long *choose, int B2, int side, int Np,
-                                    int H, int W, float *out, unopose_stream_t stream);
+                                    int H, int W, void *out, int out_bf16, unopose_stream_t stream);
 
 /* fine stage without the similarity matrix (bf16 / autocast path; replaces compute_feature_similarity :260-282 followed by
  * assign_labels + fine_correspondences): f1 (B,R,D) and f2 (B,C,D) are the L2-normalised out_proj features as bf16, f1
@@ -489,8 +490,10 @@ int unopose_vit_tokens_layernorm(const void *patch, const float *pos, const floa
 int unopose_row_dot(const void *x, int x_bf16, const float *w, float b, long rows, int C, void *out, int out_bf16,
                     unopose_stream_t stream);
 /* out[r,:] = bf16( x[r,:] / max(||x[r,:]||_2, 1e-12) / temp ) for 256-wide rows: the operands of compute_feature_similarity
- * (core/unopose/utils/model_utils.py:260-282) as the fine assignment reads them. */
-int unopose_normalize_rows_bf16(const void *x, int x_bf16, long rows, int C, float temp, void *out, unopose_stream_t stream);
+ * (core/unopose/utils/model_utils.py:260-282) as the fine assignment reads them; with out_f32 the same bf16-rounded values stored as
+ * float32 (the operand type of unopose_bmm_nt_f32, which forms the coarse similarity from them). */
+int unopose_normalize_rows_bf16(const void *x, int x_bf16, long rows, int C, float temp, void *out, int out_f32,
+                                unopose_stream_t stream);
 /* vt (B, C, pad) bf16: vt[b,c,j] = v[b,j,c] (rows of v `ld` elements apart), zero for m <= j < pad: the value image of
  * unopose_token_attention. */
 /* out (B, prepend + J, row) = rows of feats (B, N, row) picked by idx (B, J; int32 or int64): row idx - off, or alt (B rows,

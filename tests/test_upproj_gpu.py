@@ -62,6 +62,13 @@ def test_sparse_pixel_features_vs_dense(B2, side, Np, K, clustered):
         plan = ops.upproj_plan(choose, S, S, side, 5, 5 + side * side)
         ntiles, nrows = plan_invariants(plan, B2, side, 5)
         out = ops.sparse_pixel_features(acts, lin, plan)
+        ops.PIXEL_FEATS_BF16 = False  # the fp32 result; the default is exactly its bf16 rounding (what the consuming autocast Linear would cast it to)
+        try:
+            out32 = ops.sparse_pixel_features(acts, lin, plan)
+        finally:
+            ops.PIXEL_FEATS_BF16 = True
+        assert out.dtype == BF and out32.dtype == torch.float32 and torch.equal(out, out32.to(BF))
+        out = out32
         z = ops.linear(acts, lin).reshape(B2, 5 + side * side, 4, 4, 256)
         ref = ops.bilinear_sample_native(z, choose, S, S, tok_offset=5)
     e = (out - ref).abs().max().item()

@@ -47,7 +47,7 @@ SIGNATURES = {
     "unopose_linear_add_layernorm_bf16": [_P, _P, _P, _P, _P, _P, _F, _P, ctypes.c_long, _I, _P],
     "unopose_linear_bf16_kv_vt": [_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _I, _P],
     "unopose_linear_bf16_gather": [_P, ctypes.c_long, _I, _P, _I, _P, _P, _P, _I, _P, _P],
-    "unopose_bilinear_sample_compact": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "unopose_bilinear_sample_compact": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     "unopose_fine_assign": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "unopose_min_dist": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P],
     "unopose_coarse_hypotheses": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
@@ -89,7 +89,7 @@ SIGNATURES = {
     "unopose_patchify_bf16": [_P, _I, _P, _I, _I, _I, _P, _P],
     "unopose_vit_tokens_layernorm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P],
     "unopose_row_dot": [_P, _I, _P, _F, ctypes.c_long, _I, _P, _I, _P],
-    "unopose_normalize_rows_bf16": [_P, _I, ctypes.c_long, _I, _F, _P, _P],
+    "unopose_normalize_rows_bf16": [_P, _I, ctypes.c_long, _I, _F, _P, _I, _P],
     "unopose_transpose_pad_bf16": [_P, ctypes.c_long, _I, _I, _I, _I, _P, _P],
     "unopose_cloud_radius": [_P, _I, _I, _P, _P],
     "unopose_scale_by_radius": [_P, _I, _I, _P, _F, _I, _P, _P],

@@ -120,8 +120,9 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const void *__restrict__ x
 
 // ---- out[r, :] = bf16( x[r, :] / max(||x[r, :]||, 1e-12) / temp )   (F.normalize(f, p=2, dim=-1) / temp of
 //      compute_feature_similarity, model_utils.py:260-282), 256-wide rows, one wavefront per row
-template <bool X_BF16>
-__global__ __launch_bounds__(256) void normalize_rows_kernel(const void *__restrict__ x, long rows, float temp, u16 *__restrict__ out) {
+//      OUT_F32: the same bf16-rounded values stored as fp32 (the operand type of csrc/bmm_f32.hip: no cast launch in between)
+template <bool X_BF16, bool OUT_F32>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const void *__restrict__ x, long rows, float temp, void *__restrict__ outv) {
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -134,7 +135,12 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const void *__restr
   }
   const float nrm = fmaxf(sqrtf(wave_sum_f32((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w))), 1e-12f);
   const float y0 = v.x / nrm / temp, y1 = v.y / nrm / temp, y2 = v.z / nrm / temp, y3 = v.w / nrm / temp;
-  *reinterpret_cast<uint2 *>(out + (size_t)r * 256 + lane * 4) = make_uint2(cvt_pk_bf16_f32(y0, y1), cvt_pk_bf16_f32(y2, y3));
+  const uint2 pk = make_uint2(cvt_pk_bf16_f32(y0, y1), cvt_pk_bf16_f32(y2, y3));
+  if (OUT_F32)
+    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(outv) + (size_t)r * 256 + lane * 4) =
+        make_float4(__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u));
+  else
+    *reinterpret_cast<uint2 *>(reinterpret_cast<u16 *>(outv) + (size_t)r * 256 + lane * 4) = pk;
 }
 
 // ---- vt[b, c, j] = v[b, j, c] for j < m, 0 for m <= j < pad   (the channel-major, zero-padded V image of csrc/attn.hip;
@@ -404,12 +410,15 @@ int unopose_row_dot(const void *x, int x_bf16, const float *w, float b, long row
   return check_launch("row_dot");
 }
 
-int unopose_normalize_rows_bf16(const void *x, int x_bf16, long rows, int C, float temp, void *out, unopose_stream_t stream) {
+int unopose_normalize_rows_bf16(const void *x, int x_bf16, long rows, int C, float temp, void *out, int out_f32, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(x && out, "normalize_rows_bf16: null pointer");
   UNOPOSE_REQUIRE(C == 256 && rows >= 1 && temp > 0.f, "normalize_rows_bf16: built for C = 256 (got %d)", C);
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (x_bf16) hipLaunchKernelGGL(normalize_rows_kernel<true>, grid, block, 0, (hipStream_t)stream, x, rows, temp, (u16 *)out);
-  else hipLaunchKernelGGL(normalize_rows_kernel<false>, grid, block, 0, (hipStream_t)stream, x, rows, temp, (u16 *)out);
+  hipStream_t s = (hipStream_t)stream;
+  if (x_bf16 && out_f32) hipLaunchKernelGGL((normalize_rows_kernel<true, true>), grid, block, 0, s, x, rows, temp, out);
+  else if (x_bf16) hipLaunchKernelGGL((normalize_rows_kernel<true, false>), grid, block, 0, s, x, rows, temp, out);
+  else if (out_f32) hipLaunchKernelGGL((normalize_rows_kernel<false, true>), grid, block, 0, s, x, rows, temp, out);
+  else hipLaunchKernelGGL((normalize_rows_kernel<false, false>), grid, block, 0, s, x, rows, temp, out);
   return check_launch("normalize_rows_bf16");
 }
 

@@ -119,9 +119,10 @@ __global__ __launch_bounds__(512) void upproj_fill_kernel(const int *__restrict_
 }
 
 // One wavefront per output pixel, 4 channels per lane: the arithmetic of bilinear_sample_kernel<true> on compact rows.
+template <bool OUT_BF16>  // (the result rounded to bf16: what an autocast Linear makes of it next -- the fine matcher's in_proj reads it directly)
 __global__ __launch_bounds__(256) void bilinear_sample_compact_kernel(const u16 *__restrict__ Cc, const int *__restrict__ cellmap,
                                                                       const long long *__restrict__ choose, int side, int Np, int H,
-                                                                      int W, float *__restrict__ out) {
+                                                                      int W, void *__restrict__ outv) {
   const int b = blockIdx.y, lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= Np) return;
@@ -147,7 +148,11 @@ __global__ __launch_bounds__(256) void bilinear_sample_compact_kernel(const u16 
     const float bot = (1.f - lx) * v[2][c] + lx * v[3][c];
     rp[c] = (1.f - ly) * top + ly * bot;
   }
-  *reinterpret_cast<float4 *>(out + ((size_t)b * Np + p) * 256 + lane * 4) = res;
+  if (OUT_BF16)
+    *reinterpret_cast<uint2 *>(reinterpret_cast<u16 *>(outv) + ((size_t)b * Np + p) * 256 + lane * 4) =
+        make_uint2(cvt_pk_bf16_f32(res.x, res.y), cvt_pk_bf16_f32(res.z, res.w));
+  else
+    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(outv) + ((size_t)b * Np + p) * 256 + lane * 4) = res;
 }
 
 }  // namespace unopose
@@ -184,12 +189,16 @@ int unopose_upproj_plan(const long long *choose, int B2, int Np, int H, int W, i
 }
 
 int unopose_bilinear_sample_compact(const void *Cc, const int *cellmap, const long long *choose, int B2, int side, int Np, int H, int W,
-                                    float *out, unopose_stream_t stream) {
+                                    void *out, int out_bf16, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(Cc && cellmap && choose && out, "bilinear_sample_compact: null pointer");
   UNOPOSE_REQUIRE(B2 >= 0 && B2 <= 65535 && side >= 1 && Np >= 0 && H >= 1 && W >= 1, "bilinear_sample_compact: bad sizes");
   if (B2 == 0 || Np == 0) return UNOPOSE_OK;
-  hipLaunchKernelGGL(bilinear_sample_compact_kernel, dim3(cdiv(Np, 4), B2), dim3(256), 0, (hipStream_t)stream, (const u16 *)Cc, cellmap,
-                     choose, side, Np, H, W, out);
+  if (out_bf16)
+    hipLaunchKernelGGL(bilinear_sample_compact_kernel<true>, dim3(cdiv(Np, 4), B2), dim3(256), 0, (hipStream_t)stream, (const u16 *)Cc, cellmap,
+                       choose, side, Np, H, W, out);
+  else
+    hipLaunchKernelGGL(bilinear_sample_compact_kernel<false>, dim3(cdiv(Np, 4), B2), dim3(256), 0, (hipStream_t)stream, (const u16 *)Cc, cellmap,
+                       choose, side, Np, H, W, out);
   return check_launch("bilinear_sample_compact");
 }
 

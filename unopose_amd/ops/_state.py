@@ -22,6 +22,7 @@ FORBID_LIBRARY_BF16_GEMM = False  # set by pipeline.PipelinedForward around forw
 GEO_TABLE = True      # bf16 geometric embedding through the 4-point table kernel; False: the matrix-core kernel
 GEO_TABLE_F32 = True  # fp32 result through the 6-point table kernel; False: the split-operand matrix-core kernel
 USE_SPARSE_UPPROJ = True  # only the map cells the chosen pixels' bilinear taps read are up-projected (csrc/upproj.hip)
+PIXEL_FEATS_BF16 = True  # round 6: the sparse up-projection's pixel features leave the sampling kernel in bf16 (their consumers are autocast Linears); False: fp32 + a cast each
 USE_KV_VT = True  # round 6: the token attention's V^T operand written by the k | v projection's epilogue (csrc/gemm_small.hip EPI 4); False: a transpose launch
 USE_LA_KV_STATE = True  # round 6: the linear attention's key / value state (focused keys, their sum, k^T v) in one launch (csrc/linattn.hip); False: 7 launches
 USE_STACKED_OUT = True  # round 6: a matcher block's two cross layers write the halves of ONE stacked tensor, the dense layer reads its keys / values

@@ -66,7 +66,7 @@ def feature_similarity(f1, f2, temp):
         # no library bf16 GEMM on the path (own_gemm_ok): the bf16-rounded normalised operands, multiplied by the exact-fp32 MFMA
         # kernel (exact products, fp32 sums -- what the bf16 bmm with fp32 output computes up to summation order)
         with torch.autocast("cuda", enabled=False):
-            return bmm_nt_f32(normalize_rows_bf16(f1, temp).float(), normalize_rows_bf16(f2, 1.0).float())
+            return bmm_nt_f32(normalize_rows_bf16(f1, temp, as_f32=True), normalize_rows_bf16(f2, 1.0, as_f32=True))
     a, b = F.normalize(f1.float(), p=2, dim=2), F.normalize(f2.float(), p=2, dim=2)
     if f1.is_cuda and torch.is_autocast_enabled() and not st.HIP_GEMM_ALL:
         with torch.autocast("cuda", enabled=False):
@@ -211,14 +211,17 @@ def fine_pose_fused_ok(f1, f2):
             and f2.shape[-1] == 256)
 
 
-def normalize_rows_bf16(f, temp):
-    """bf16(F.normalize(f.float(), dim=-1) / temp) in one pass (csrc/glue.hip); f (...,256) bf16 or fp32."""
+def normalize_rows_bf16(f, temp, as_f32=False):
+    """bf16(F.normalize(f.float(), dim=-1) / temp) in one pass (csrc/glue.hip); f (...,256) bf16 or fp32.  `as_f32`: the same
+    bf16-rounded values in an fp32 tensor (the operand type of `bmm_nt_f32`)."""
     if f.shape[-1] != 256 or f.dtype not in (torch.bfloat16, torch.float32):
-        return _c((F.normalize(f.float(), p=2, dim=-1) / temp).to(torch.bfloat16))
+        y = _c((F.normalize(f.float(), p=2, dim=-1) / temp).to(torch.bfloat16))
+        return y.float() if as_f32 else y
     fc = _c(f)
-    out = torch.empty(f.shape, dtype=torch.bfloat16, device=f.device)
+    out = torch.empty(f.shape, dtype=torch.float32 if as_f32 else torch.bfloat16, device=f.device)
     with on_device(f.device):
-        call("unopose_normalize_rows_bf16", ptr(fc), int(f.dtype == torch.bfloat16), fc.numel() // 256, 256, float(temp), ptr(out), stream_ptr())
+        call("unopose_normalize_rows_bf16", ptr(fc), int(f.dtype == torch.bfloat16), fc.numel() // 256, 256, float(temp), ptr(out), int(as_f32),
+             stream_ptr())
     return out
 
 

@@ -65,8 +65,9 @@ def upproj_plan(choose, H, W, side, tok_offset, tok_stride):
 def sparse_pixel_features(acts, lin, plan, out=None):
     """ViT_AE's Linear 3072->4096 + pixel shuffle + bilinear upsampling + pixel gather (oneref_feature_extraction.py:
     200-236, model_utils.py:215-227) evaluated only where the chosen pixels look: acts (B2, tok_stride, K) bf16 token
-    activations (prefix tokens in place), lin the up-projection -> (B2, Np, 256) fp32.  Same bf16 operands, fp32
-    accumulation and bf16 rounding of the cell values as the dense path (`linear` + `bilinear_sample_native`)."""
+    activations (prefix tokens in place), lin the up-projection -> (B2, Np, 256) fp32, or (`PIXEL_FEATS_BF16`, the default) the same
+    values rounded to bf16 -- what the autocast Linears that consume them (coarse / fine in_proj) would make of them first.  Same bf16
+    operands, fp32 accumulation and bf16 rounding of the cell values as the dense path (`linear` + `bilinear_sample_native`)."""
     acts = _c(acts)
     if out is not None:
         note_mutation()
@@ -78,15 +79,15 @@ def sparse_pixel_features(acts, lin, plan, out=None):
     assert N == 16 * 256 and w.shape[1] == K
     Np = plan["choose"].shape[1]
     dev = acts.device
-    if out is None:
-        out = torch.empty(B2, Np, 256, dtype=torch.float32, device=dev)
-    assert out.shape == (B2, Np, 256) and out.dtype == torch.float32 and out.is_contiguous()
+    if out is None:  # bf16 under the switch: the consumers are autocast Linears (coarse / fine in_proj), which would cast it first
+        out = torch.empty(B2, Np, 256, dtype=torch.bfloat16 if st.PIXEL_FEATS_BF16 else torch.float32, device=dev)
+    assert out.shape == (B2, Np, 256) and out.dtype in (torch.float32, torch.bfloat16) and out.is_contiguous()
     with on_device(dev):
         cells = torch.empty(plan["cap_rows"], 256, dtype=torch.bfloat16, device=dev)
         call("unopose_linear_bf16_gather", ptr(acts), B2 * ts, K, ptr(w), N, ptr(bias), ptr(plan["row_list"]),
              ptr(plan["tile_info"]), plan["cap_rows"] // 256, ptr(cells), stream_ptr())
         call("unopose_bilinear_sample_compact", ptr(cells), ptr(plan["cellmap"]), ptr(plan["choose"]), B2, plan["side"], Np,
-             plan["H"], plan["W"], ptr(out), stream_ptr())
+             plan["H"], plan["W"], ptr(out), int(out.dtype == torch.bfloat16), stream_ptr())
     return out
 
 
