@@ -372,6 +372,14 @@ int unopose_coarse_scores(const float *pts1, const float *pts2, int B, int n1, i
                           const float *Rall, const float *tall, int nprop, const int64_t *top,
                           int ncand, const float *w1, float *score, unopose_stream_t stream);
 
+/* idx (B,k) int64 = the k smallest of x (B,n) float32 per row in ascending order, ties by index, NaN as the largest value:
+ * torch.topk(dis, n_proposal2, dim=1, largest=False)[1] of compute_coarse_Rt_overlap (model_utils.py:476).  n <= 16384. */
+int unopose_topk_smallest(const float *x, int B, int n, int k, int64_t *idx, unopose_stream_t stream);
+/* The winning hypothesis of every pair (model_utils.py:486-490): best = first maximum of score (B,ncand) (a NaN wins, as in torch.max),
+ * R (B,3,3) / t (B,3) = Rall / tall (B,nprop,...) at hypothesis top[b,best], best_score (B) = score[b,best]. */
+int unopose_coarse_pick(const float *score, const int64_t *top, int B, int ncand, const float *Rall, const float *tall, int nprop,
+                        float *R, float *t, float *best_score, unopose_stream_t stream);
+
 /* Attention core of the 4-head x 64 token transformers (core/unopose/model/transformer.py:130-148
  * cross, :386-405 RPE self): out (B,n,256) = softmax((q k^T [+ qp . E]) * scale) v, all tensors
  * bfloat16 bit patterns.  q (B,n,256) with row stride ldq elements, k (B,m,256) with row stride ldk

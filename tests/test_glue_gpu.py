@@ -311,3 +311,50 @@ def test_nearest_partner_labels_vs_distance_matrix(B, n, m):
         close = (dist <= thr).any(dim)
         border = ((dr.double() ** 2 - thr ** 2).abs() < 1e-6)
         assert torch.equal(anyc[~border], close[~border])
+
+
+@torch.no_grad()
+def test_topk_smallest_and_coarse_pick_kernels():
+    """unopose_topk_smallest (rank by counting) vs torch.topk(largest=False): same values in ascending order, indices equal where the values are
+    distinct, ties in index order, NaN last; unopose_coarse_pick vs max + gathers (first maximum); coarse_pose with and without them."""
+    import os
+    import numpy as np
+    from unopose_amd import ops
+    from unopose_amd._lib import call, ptr, stream_ptr
+
+    def load(name):
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+        return {k: torch.from_numpy(z[k]).cuda() if z[k].ndim else z[k].item() for k in z.files}
+
+    g = torch.Generator().manual_seed(5)
+    for B, n, k in ((3, 6000, 300), (2, 257, 257), (1, 5, 1), (4, 1000, 37)):
+        x = torch.randn(B, n, generator=g).cuda()
+        idx = torch.full((B, k), -1, dtype=torch.int64, device="cuda")
+        call("unopose_topk_smallest", ptr(x), B, n, k, ptr(idx), stream_ptr())
+        want = torch.topk(x, k, dim=1, largest=False)
+        assert torch.equal(torch.gather(x, 1, idx), want[0]) and torch.equal(idx, want[1])  # (distinct values: one answer)
+    x = torch.tensor([[3.0, 1.0, float("nan"), 1.0, -0.0, 0.0, float("inf"), 1.0, -5.0, float("-inf")]]).cuda()
+    idx = torch.empty(1, 10, dtype=torch.int64, device="cuda")
+    call("unopose_topk_smallest", ptr(x), 1, 10, 10, ptr(idx), stream_ptr())
+    assert idx.tolist() == [[9, 8, 4, 5, 1, 3, 7, 0, 6, 2]]  # ties by index (-0.0 sorts below 0.0: distinct bit patterns), +inf before NaN
+    B, ncand, nprop = 5, 300, 6000
+    sc = torch.randn(B, ncand, generator=g).cuda()
+    sc[1, 7] = sc[1, 200] = sc[1].max() + 1  # a tie: the first wins
+    sc[2, 50] = float("nan")                 # a NaN wins (torch.max)
+    top = torch.stack([torch.randperm(nprop, generator=g)[:ncand] for _ in range(B)]).cuda()
+    rs, ts = torch.randn(B, nprop, 3, 3, generator=g).cuda(), torch.randn(B, nprop, 3, generator=g).cuda()
+    R, t, best = torch.empty(B, 3, 3, device="cuda"), torch.empty(B, 3, device="cuda"), torch.empty(B, device="cuda")
+    call("unopose_coarse_pick", ptr(sc), ptr(top), B, ncand, ptr(rs), ptr(ts), nprop, ptr(R), ptr(t), ptr(best), stream_ptr())
+    ps, bi = sc.max(1)
+    assert bi[1].item() == 7 and bi[2].item() == 50
+    hyp = torch.gather(top, 1, bi.unsqueeze(1)).squeeze(1)
+    ar = torch.arange(B, device="cuda")
+    assert torch.equal(R, rs[ar, hyp]) and torch.equal(t, ts[ar, hyp]) and torch.equal(best.nan_to_num(7.0), ps.nan_to_num(7.0))
+    z = load("coarse_rt")
+    a = ops.coarse_pose(z["atten"], z["score"], z["p1"], z["p2"], z["rand"], 6000, 300)
+    ops.USE_OWN_TOPK = False
+    try:
+        b = ops.coarse_pose(z["atten"], z["score"], z["p1"], z["p2"], z["rand"], 6000, 300)
+    finally:
+        ops.USE_OWN_TOPK = True
+    assert all(torch.equal(u, v) for u, v in zip(a, b))

@@ -52,6 +52,8 @@ SIGNATURES = {
     "unopose_min_dist": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P],
     "unopose_coarse_hypotheses": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "unopose_coarse_scores": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P],
+    "unopose_topk_smallest": [_P, _I, _I, _I, _P, _P],
+    "unopose_coarse_pick": [_P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P],
     "unopose_token_attention": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _F, _P, _P],
     "unopose_token_attention_key_pad": [],
     "unopose_token_attention_f32": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _F, _P, _P],

@@ -430,6 +430,57 @@ __global__ __launch_bounds__(256) void infonce_grad_kernel(const float *__restri
   }
 }
 
+// ---- the k smallest of n values per row, ascending, ties by index (torch.topk(dis, k, largest=False, sorted=True) of model_utils.py:476;
+//      NaN counts as the largest value, as in torch): rank by counting.  One thread per element compares its key with the row's n keys
+//      in LDS (broadcast reads): 6000 x 6000 comparisons per pair are 6 us spread over the chip -- no sort, no library launch.
+__device__ __forceinline__ uint32_t topk_key(float v) {
+  if (v != v) return 0xFFFFFFFFu;
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> uint (below the NaN key: +inf maps to 0xFF800000)
+}
+
+__global__ __launch_bounds__(256) void topk_smallest_kernel(const float *__restrict__ x, int n, int k, int64_t *__restrict__ idx) {
+  extern __shared__ uint32_t tk_keys[];
+  const int b = blockIdx.y;
+  const float *row = x + (size_t)b * n;
+  for (int j = threadIdx.x; j < n; j += 256) tk_keys[j] = topk_key(row[j]);
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t ki = tk_keys[i];
+  int rank = 0;
+  for (int j = 0; j < n; ++j) {
+    const uint32_t kj = tk_keys[j];
+    rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
+  }
+  if (rank < k) idx[(size_t)b * k + rank] = i;
+}
+
+// ---- the winning hypothesis of a pair (model_utils.py:486-490: pose_score.max(1), then the gathers of R and t): the first maximum of
+//      score[b, :] (a NaN wins, the first one, as in torch.max), its hypothesis top[b, best], that hypothesis's R and t.
+__global__ __launch_bounds__(64) void coarse_pick_kernel(const float *__restrict__ score, const int64_t *__restrict__ top, int ncand,
+                                                         const float *__restrict__ Rall, const float *__restrict__ tall, int nprop,
+                                                         float *__restrict__ R, float *__restrict__ t, float *__restrict__ best_score) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float *sc = score + (size_t)b * ncand;
+  uint32_t bk = 0u;
+  int bi = 0x7FFFFFFF;
+  for (int c = lane; c < ncand; c += 64) {
+    const uint32_t kc = topk_key(sc[c]);
+    if (kc > bk || (kc == bk && c < bi)) bk = kc, bi = c;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t ok = __shfl_xor(bk, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ok > bk || (ok == bk && oi < bi)) bk = ok, bi = oi;
+  }
+  const long h = (long)top[(size_t)b * ncand + bi];
+  if (lane < 9) R[(size_t)b * 9 + lane] = Rall[((size_t)b * nprop + h) * 9 + lane];
+  if (lane < 3) t[(size_t)b * 3 + lane] = tall[((size_t)b * nprop + h) * 3 + lane];
+  if (lane == 0) best_score[b] = sc[bi];
+}
+
 }  // namespace unopose
 
 using namespace unopose;
@@ -530,6 +581,23 @@ int unopose_coarse_scores(const float *pts1, const float *pts2, int B, int n1, i
   hipLaunchKernelGGL(coarse_score_kernel, dim3(ncand, B), dim3(256), (size_t)n2 * 12, (hipStream_t)stream, pts1, pts2,
                      n1, n2, Rall, tall, nprop, top, ncand, w1, score);
   return check_launch("coarse_scores");
+}
+
+int unopose_topk_smallest(const float *x, int B, int n, int k, int64_t *idx, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(x && idx, "topk_smallest: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && B <= 65535 && n >= 1 && k >= 1 && k <= n && (size_t)n * 4 <= 64 * 1024, "topk_smallest: bad sizes (n=%d k=%d; n <= 16384)", n, k);
+  if (B == 0) return UNOPOSE_OK;
+  hipLaunchKernelGGL(topk_smallest_kernel, dim3(cdiv(n, 256), B), dim3(256), (size_t)n * 4, (hipStream_t)stream, x, n, k, idx);
+  return check_launch("topk_smallest");
+}
+
+int unopose_coarse_pick(const float *score, const int64_t *top, int B, int ncand, const float *Rall, const float *tall, int nprop, float *R,
+                        float *t, float *best_score, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(score && top && Rall && tall && R && t && best_score, "coarse_pick: null pointer");
+  UNOPOSE_REQUIRE(B >= 0 && ncand >= 1 && nprop >= 1, "coarse_pick: bad sizes");
+  if (B == 0) return UNOPOSE_OK;
+  hipLaunchKernelGGL(coarse_pick_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, score, top, ncand, Rall, tall, nprop, R, t, best_score);
+  return check_launch("coarse_pick");
 }
 
 }  // extern "C"

@@ -45,7 +45,7 @@ from .train import (  # noqa: F401
     nearest_partner, _CONV_FWD_PAIRS, _CONV_WGRAD_PAIRS, _conv1x1_pair_ok, _conv1x1_wgrad_ok, _Conv1x1Fn, conv1x1,
 )
 
-_SWITCHES = frozenset(['FORBID_LIBRARY_BF16_GEMM', 'GEO_TABLE', 'GEO_TABLE_F32', 'HIP_GEMM_ALL', 'PIXEL_FEATS_BF16', 'TRAIN_FUSED_SALIENCY', 'TRAIN_OWN_CONV', 'TRAIN_OWN_GEMM', 'TRAIN_OWN_GEMM_MIN_FLOP', 'TRAIN_OWN_GEO', 'TRAIN_OWN_WGRAD', 'TRAIN_OWN_WGRAD_MIN_ROWS', 'USE_F32X3', 'USE_FUSED_BN_RELU', 'USE_FUSED_FINE', 'USE_FUSED_INFONCE', 'USE_FUSED_LINEAR_LN', 'USE_HIP_GEMM', 'USE_KV_VT', 'USE_LA_KV_STATE', 'USE_LN_FOLD', 'USE_SPARSE_UPPROJ', 'USE_STACKED_OUT', '_DIFF'])
+_SWITCHES = frozenset(['FORBID_LIBRARY_BF16_GEMM', 'GEO_TABLE', 'GEO_TABLE_F32', 'HIP_GEMM_ALL', 'PIXEL_FEATS_BF16', 'TRAIN_FUSED_SALIENCY', 'TRAIN_OWN_CONV', 'TRAIN_OWN_GEMM', 'TRAIN_OWN_GEMM_MIN_FLOP', 'TRAIN_OWN_GEO', 'TRAIN_OWN_WGRAD', 'TRAIN_OWN_WGRAD_MIN_ROWS', 'USE_F32X3', 'USE_FUSED_BN_RELU', 'USE_FUSED_FINE', 'USE_FUSED_INFONCE', 'USE_FUSED_LINEAR_LN', 'USE_HIP_GEMM', 'USE_KV_VT', 'USE_LA_KV_STATE', 'USE_LN_FOLD', 'USE_OWN_TOPK', 'USE_SPARSE_UPPROJ', 'USE_STACKED_OUT', '_DIFF'])
 
 
 class _OpsModule(types.ModuleType):

@@ -27,6 +27,7 @@ USE_KV_VT = True  # round 6: the token attention's V^T operand written by the k 
 USE_LA_KV_STATE = True  # round 6: the linear attention's key / value state (focused keys, their sum, k^T v) in one launch (csrc/linattn.hip); False: 7 launches
 USE_STACKED_OUT = True  # round 6: a matcher block's two cross layers write the halves of ONE stacked tensor, the dense layer reads its keys / values
                         # behind the background row in place; False: concatenations / slices copied out (4 more launches per block)
+USE_OWN_TOPK = True  # round 6: the coarse head's top-k of the hypothesis residuals and the pick of the winner on csrc/posehead.hip; False: torch.topk + max + 3 gathers
 USE_FUSED_FINE = True  # bf16 fine stage without the (B, N1 + 1, N2 + 1) similarity (csrc/fineassign.hip)
 
 # ---- training step (ops/train.py, ops/dense.py `_LinearFn`, ops/geometry.py `_GeoEmbedFn`)

@@ -153,8 +153,8 @@ def _assign_labels(atten, score1, score2):
 
 def coarse_pose(atten, score, pts1, pts2, rand, n1p=6000, n2p=300):
     """compute_coarse_Rt_overlap (model_utils.py:411-490) on HIP kernels (csrc/posehead.hip): streaming
-    assignment statistics, CDF + searchsorted + 3-point Procrustes + residual per hypothesis, candidate
-    scoring; torch only picks the top-k / argmax of tiny (B,6000) / (B,300) arrays."""
+    assignment statistics, CDF + searchsorted + 3-point Procrustes + residual per hypothesis, top-k of the residuals (rank by
+    counting), candidate scoring, pick of the best candidate (`USE_OWN_TOPK`; off: torch.topk / max / gather)."""
     B, N1, _ = pts1.shape
     N2 = pts2.shape[1]
     atten, pts1, pts2 = _c(atten.float()), _c(pts1.float()), _c(pts2.float())
@@ -171,10 +171,21 @@ def coarse_pose(atten, score, pts1, pts2, rand, n1p=6000, n2p=300):
         call("unopose_coarse_hypotheses", ptr(atten), B, N1 + 1, N2 + 1, ptr(score1), ptr(score2), ptr(stats),
              ptr(w1), ptr(w2), ptr(rand), n1p, ptr(pts1), ptr(pts2), ptr(cdf), ptr(rs), ptr(ts), ptr(dis),
              stream_ptr())
-        top = torch.topk(dis, n2p, dim=1, largest=False)[1].contiguous()
+        own = st.USE_OWN_TOPK and n1p <= 16384 and n2p <= n1p
+        if own:  # the n2p smallest residuals, ascending, ties by index (csrc/posehead.hip: rank by counting)
+            top = torch.empty(B, n2p, dtype=torch.int64, device=dev)
+            call("unopose_topk_smallest", ptr(dis), B, n1p, n2p, ptr(top), stream_ptr())
+        else:
+            top = torch.topk(dis, n2p, dim=1, largest=False)[1].contiguous()
         sc = torch.empty(B, n2p, dtype=torch.float32, device=dev)
         call("unopose_coarse_scores", ptr(pts1), ptr(pts2), B, N1, N2, ptr(rs), ptr(ts), n1p, ptr(top), n2p, ptr(w1),
              ptr(sc), stream_ptr())
+        if own:  # first maximum of the scores, its hypothesis, that hypothesis's R and t: one launch
+            R = torch.empty(B, 3, 3, dtype=torch.float32, device=dev)
+            t = torch.empty(B, 3, dtype=torch.float32, device=dev)
+            pose_score = torch.empty(B, dtype=torch.float32, device=dev)
+            call("unopose_coarse_pick", ptr(sc), ptr(top), B, n2p, ptr(rs), ptr(ts), n1p, ptr(R), ptr(t), ptr(pose_score), stream_ptr())
+            return R, t, pose_score
     pose_score, best = sc.max(1)
     hyp = torch.gather(top, 1, best.unsqueeze(1))  # (B,1)
     R = torch.gather(rs, 1, hyp.reshape(B, 1, 1, 1).expand(-1, -1, 3, 3)).squeeze(1)
