@@ -499,13 +499,13 @@ int unopose_row_dot(const void *x, int x_bf16, const float *w, float b, long row
                     unopose_stream_t stream);
 /* out[r,:] = bf16( x[r,:] / max(||x[r,:]||_2, 1e-12) / temp ) for 256-wide rows: the operands of compute_feature_similarity
  * (core/unopose/utils/model_utils.py:260-282) as the fine assignment reads them; with out_f32 the same bf16-rounded values stored as
- * float32 (the operand type of unopose_bmm_nt_f32, which forms the coarse similarity from them). */
+ * float32 (the operand type of unopose_bmm_f32, which forms the coarse similarity from them). */
 int unopose_normalize_rows_bf16(const void *x, int x_bf16, long rows, int C, float temp, void *out, int out_f32,
                                 unopose_stream_t stream);
 /* vt (B, C, pad) bf16: vt[b,c,j] = v[b,j,c] (rows of v `ld` elements apart), zero for m <= j < pad: the value image of
  * unopose_token_attention. */
 /* out (B, prepend + J, row) = rows of feats (B, N, row) picked by idx (B, J; int32 or int64): row idx - off, or alt (B rows,
- * alt_stride_bytes apart: the background tokens may be row 0 of a (B, 1 + n, row) tensor) where idx - off < 0; with prepend = 1 row 0
+ * alt_stride_bytes apart, 0 = one row for all: the background tokens may be row 0 of a (B, 1 + n, row) tensor) where idx - off < 0; with prepend = 1 row 0
  * of every batch is alt as well.  Rows are row_bytes long (a multiple of 4, any element
  * type).  The (B,N,C)-layout gather the model uses instead of gather_operation's transposes (model_utils.py:146-149) and the
  * background-token sampling of the sparse-to-dense block (transformer.py:655-662: index 0 = the background token). */
@@ -517,14 +517,20 @@ int unopose_transpose_pad_bf16(const void *v, long ld, int B, int m, int C, int 
  * cloud_radius: radius[b] = max_i |p_i - mean(p)| of pts (B,N,3) (oneref_grf_predator_pose_estimation_model.py: the normalisation radius).
  * scale_by_radius: out (B,n) = x / (radius[b] + eps) (multiply = 0) or x * (radius[b] + eps) (1).
  * overlap_scores: clamp(sigmoid(.), 0, 1) of the score-head outputs (B, n_tot) of the two stacked clouds without their background tokens
- *   (positions 0 and n1 + 1) -> out (B, n_tot - 2) fp32 (oneref_predator_coarse_point_matching.py:68-76, fine: :91-99).
+ *   (positions 0 and n1 + 1) -> out (B, n_tot - 2) fp32 (oneref_predator_coarse_point_matching.py:68-76, fine: :91-99); with `halves` the
+ *   head ran over the clouds as one batch of 2B: scores is (2B, n1 + 1), cloud 2 of pair b in batch B + b (n_tot = 2 (n1 + 1)).
+ * copy_rows: dst row r = src row r for `rows` rows of row_bytes, the rows src_stride_bytes / dst_stride_bytes apart (src stride 0: one
+ *   row for all) -- the background token written in front of every pair (`torch.cat([bg_token.expand(B, -1, -1), f], dim=1)`,
+ *   oneref_predator_coarse_point_matching.py:52-54) into a tensor that already has the slot.
  * rigid_rows_bf16: bf16((p - t) @ R) with bf16-rounded operands and fp32 accumulation, p (B,N,3) fp32 (autocast's bmm of
  *   oneref_predator_fine_point_matching.py:69).
  * token_sum_bf16: out (B,C) fp32 = sum over the J tokens of x (B,J,C) bf16 (the k-sum of the focused linear attention, transformer.py:560-566).
  * pose_score: sum_i [dis_i < thr] w_i / (sum_i w_i + 1e-8) * mean_i w_i, dis / w (B,N) (model_utils.py:559-566). */
 int unopose_cloud_radius(const float *pts, int B, int N, float *radius, unopose_stream_t stream);
 int unopose_scale_by_radius(const float *x, int B, int n, const float *radius, float eps, int multiply, float *out, unopose_stream_t stream);
-int unopose_overlap_scores(const void *scores, int x_bf16, int B, int n_tot, int n1, float *out, unopose_stream_t stream);
+int unopose_overlap_scores(const void *scores, int x_bf16, int B, int n_tot, int n1, int halves, float *out, unopose_stream_t stream);
+int unopose_copy_rows(const void *src, long src_stride_bytes, void *dst, long dst_stride_bytes, int rows, int row_bytes,
+                      unopose_stream_t stream);
 int unopose_rigid_rows_bf16(const float *p, int B, int N, const float *t, const float *R, void *out, unopose_stream_t stream);
 int unopose_token_sum_bf16(const void *x, int B, int J, int C, float *out, unopose_stream_t stream);
 int unopose_pose_score(const float *dis, const float *w, int B, int N, float thr, float *out, unopose_stream_t stream);

@@ -165,6 +165,13 @@ def test_gather_rows_kernel_matches_torch_composite():
                 holder = torch.randn(5, 9, C, generator=g).cuda().to(dtype)
                 holder[:, 0:1] = bg.to(dtype)
                 assert torch.equal(ops.gather_rows(feats, idx, off=1, alt=holder[:, 0:1], prepend=True), torch.cat([bg.to(dtype), base], 1))
+    # int64 pixel indices as 8-byte rows, written into one half of a stacked tensor (the FPS subset's `choose`, model/unopose.py)
+    ch = torch.randint(0, 50000, (5, 301), generator=g).cuda()
+    for idt in (torch.int32, torch.int64):
+        idx = torch.randint(0, 301, (5, 77), generator=g).cuda().to(idt)
+        dst = torch.full((10, 77), -1, dtype=torch.int64, device="cuda")
+        got = ops.gather_rows(ch.unsqueeze(-1), idx, out=dst[5:].unsqueeze(-1)).squeeze(-1)
+        assert torch.equal(got, torch.gather(ch, 1, idx.long())) and got.data_ptr() == dst[5:].data_ptr() and bool((dst[:5] == -1).all())
     # differentiable mode / tensors that carry gradients keep the autograd-recorded composite
     f = torch.randn(2, 10, 4, device="cuda", requires_grad=True)
     out = ops.gather_rows(f, torch.randint(0, 10, (2, 3), device="cuda"))
@@ -358,3 +365,44 @@ def test_topk_smallest_and_coarse_pick_kernels():
     finally:
         ops.USE_OWN_TOPK = True
     assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+@torch.no_grad()
+def test_copy_rows_and_overlap_scores_halves():
+    """unopose_copy_rows through ops.set_first_rows_ (one row into row 0 of every batch, nothing else touched) and the two-halves form of
+    unopose_overlap_scores (score head run over both clouds as one batch of 2B) against the concatenated form."""
+    from unopose_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    for dtype in (torch.bfloat16, torch.float32):
+        x = torch.randn(6, 197, 256, generator=g).cuda().to(dtype)
+        keep = x.clone()
+        row = torch.randn(256, generator=g).cuda().to(dtype)
+        y = ops.set_first_rows_(x, row)
+        assert y.data_ptr() == x.data_ptr() and torch.equal(x[:, 0], row.expand(6, -1)) and torch.equal(x[:, 1:], keep[:, 1:])
+        sc = torch.randn(10, 197, 1, generator=g).cuda().to(dtype)
+        want = ops.overlap_scores(torch.cat((sc[:5], sc[5:]), dim=1), 196)
+        assert torch.equal(ops.overlap_scores(sc, 196, halves=True), want) and want.shape == (5, 392)
+
+
+@torch.no_grad()
+def test_coarse_slot_path_equals_concatenated_path():
+    """UNOPose.forward with the coarse matcher's stacked input (one gather target with a slot row, one in_proj GEMM, background token copied
+    in, scores read from the two halves) against round 5's concatenations: same poses, bit for bit (row-wise kernels, same rows)."""
+    import unopose_amd.model.unopose as mu
+    from unopose_amd.model import UNOPose, default_model_cfg
+    from unopose_amd.synthetic import make_batch, trained_like_
+
+    m = trained_like_(UNOPose(default_model_cfg())).cuda().eval()
+    ep, _, _ = make_batch(3, S=224, device="cuda")
+    ep["coarse_rand"] = torch.rand(3, 18000, generator=torch.Generator().manual_seed(1)).cuda()
+    outs = []
+    for flag in (True, False):
+        mu.COARSE_SLOT = flag
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                o = m(dict(ep))
+        finally:
+            mu.COARSE_SLOT = True
+        outs.append((o["init_R"].clone(), o["init_t"].clone(), o["pred_R"].clone(), o["pred_t"].clone(), o["pred_pose_score"].clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))

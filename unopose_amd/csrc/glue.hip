@@ -297,13 +297,23 @@ __global__ __launch_bounds__(256) void scale_by_radius_kernel(const float *__res
   out[at] = mode ? x[at] * s : x[at] / s;
 }
 
+// ---- rows copied between strided places: dst row r = src row r (src rows `src_stride` bytes apart, 0 = the same row for every r: a
+//      background token put in front of every pair of a (2B, 1 + n, C) tensor without a concatenation), 4-byte words
+__global__ __launch_bounds__(256) void copy_rows_kernel(const uint32_t *__restrict__ src, long src_words, uint32_t *__restrict__ dst, long dst_words,
+                                                        int words) {
+  const size_t r = blockIdx.y;
+  for (int w = blockIdx.x * 256 + threadIdx.x; w < words; w += gridDim.x * 256) dst[r * dst_words + w] = src[r * src_words + w];
+}
+
 // overlap scores: out[b][j] = clamp(sigmoid(scores[b][1 + j]), 0, 1) for j < n1, scores[b][n1 + 2 + (j - n1)] for the second cloud
 // (oneref_predator_coarse_point_matching.py:68-76: the background tokens at 0 and n1 + 1 are dropped)
+//   `halves`: the score head ran over the two clouds as ONE batch of 2B (cloud 2 of pair b is batch B + b): scores is (2B, n1 + 1) then (n2 = n1)
 template <bool X_BF16>
-__global__ __launch_bounds__(256) void overlap_scores_kernel(const void *__restrict__ scores, int n_tot, int n1, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void overlap_scores_kernel(const void *__restrict__ scores, int n_tot, int n1, int halves, float *__restrict__ out) {
   const int n_out = n_tot - 2, j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n_out) return;
-  const size_t src = (size_t)blockIdx.y * n_tot + (j < n1 ? 1 + j : 2 + j);
+  const size_t src = halves ? ((size_t)(j < n1 ? blockIdx.y : gridDim.y + blockIdx.y) * (n1 + 1) + 1 + (j < n1 ? j : j - n1))
+                            : (size_t)blockIdx.y * n_tot + (j < n1 ? 1 + j : 2 + j);
   const float x = X_BF16 ? __uint_as_float((uint32_t) reinterpret_cast<const u16 *>(scores)[src] << 16) : reinterpret_cast<const float *>(scores)[src];
   const float y = 1.f / (1.f + expf(-x));
   out[(size_t)blockIdx.y * n_out + j] = fminf(fmaxf(y, 0.f), 1.f);
@@ -368,8 +378,8 @@ int unopose_gather_rows(const void *feats, int B, int N, int row_bytes, const vo
   UNOPOSE_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && J >= 1 && row_bytes >= 4 && row_bytes % 4 == 0 && (off == 0 || off == 1) && (prepend == 0 || prepend == 1),
                   "gather_rows: bad sizes (B=%d N=%d J=%d row_bytes=%d)", B, N, J, row_bytes);
   UNOPOSE_REQUIRE(alt || (off == 0 && prepend == 0), "gather_rows: off / prepend need the alternative row");
-  UNOPOSE_REQUIRE(!alt || (alt_stride_bytes >= row_bytes && alt_stride_bytes % 4 == 0 && alt_stride_bytes / 4 <= 0x7FFFFFFF),
-                  "gather_rows: alt rows must be >= row_bytes apart, a multiple of 4 (got %ld)", alt_stride_bytes);
+  UNOPOSE_REQUIRE(!alt || ((alt_stride_bytes == 0 || alt_stride_bytes >= row_bytes) && alt_stride_bytes % 4 == 0 && alt_stride_bytes / 4 <= 0x7FFFFFFF),
+                  "gather_rows: alt rows must be 0 (one row for all) or >= row_bytes apart, a multiple of 4 (got %ld)", alt_stride_bytes);
   const int words = row_bytes / 4, alt_words = (int)(alt_stride_bytes / 4);
   const dim3 grid((unsigned)std::min<long>(((long)(J + prepend) * words + 255) / 256, 4096), B);
   if (idx_is_i64)
@@ -446,14 +456,26 @@ int unopose_scale_by_radius(const float *x, int B, int n, const float *radius, f
   return check_launch("scale_by_radius");
 }
 
-int unopose_overlap_scores(const void *scores, int x_bf16, int B, int n_tot, int n1, float *out, unopose_stream_t stream) {
+int unopose_overlap_scores(const void *scores, int x_bf16, int B, int n_tot, int n1, int halves, float *out, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(scores && out, "overlap_scores: null pointer");
   UNOPOSE_REQUIRE(B >= 0 && B <= 65535 && n1 >= 1 && n_tot >= n1 + 3, "overlap_scores: needs two clouds behind their background tokens (n_tot=%d n1=%d)", n_tot, n1);
+  UNOPOSE_REQUIRE(!halves || n_tot == 2 * (n1 + 1), "overlap_scores: the two-halves form needs clouds of one size (n_tot=%d n1=%d)", n_tot, n1);
   if (B == 0) return UNOPOSE_OK;
   const dim3 grid(cdiv(n_tot - 2, 256), B);
-  if (x_bf16) hipLaunchKernelGGL(overlap_scores_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, scores, n_tot, n1, out);
-  else hipLaunchKernelGGL(overlap_scores_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, scores, n_tot, n1, out);
+  if (x_bf16) hipLaunchKernelGGL(overlap_scores_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, scores, n_tot, n1, halves, out);
+  else hipLaunchKernelGGL(overlap_scores_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, scores, n_tot, n1, halves, out);
   return check_launch("overlap_scores");
+}
+
+int unopose_copy_rows(const void *src, long src_stride_bytes, void *dst, long dst_stride_bytes, int rows, int row_bytes, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(src && dst, "copy_rows: null pointer");
+  UNOPOSE_REQUIRE(rows >= 0 && rows <= 65535 && row_bytes >= 4 && row_bytes % 4 == 0 && src_stride_bytes >= 0 && src_stride_bytes % 4 == 0 &&
+                      dst_stride_bytes >= row_bytes && dst_stride_bytes % 4 == 0,
+                  "copy_rows: bad sizes (rows=%d row_bytes=%d)", rows, row_bytes);
+  if (rows == 0) return UNOPOSE_OK;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(std::min(cdiv(row_bytes / 4, 256), 64), rows), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)src,
+                     src_stride_bytes / 4, (uint32_t *)dst, dst_stride_bytes / 4, row_bytes / 4);
+  return check_launch("copy_rows");
 }
 
 int unopose_rigid_rows_bf16(const float *p, int B, int N, const float *t, const float *R, void *out, unopose_stream_t stream) {

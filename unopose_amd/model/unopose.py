@@ -23,12 +23,25 @@ PE_UNDER_COARSE = True
 GEOM_UNDER_VIT = 1  # 1: FPS-196 / gathers, 2: + frames + embedding
 LRF_UNDER_VIT = True  # the two global frames on the side stream as well
 _SIDE_STREAMS = {}  # (device index, launch stream) -> its helper stream, for the life of the process
+COARSE_SLOT = True  # round 6: the coarse matcher's inputs gathered into one (2B, 1 + n, C) tensor with a slot for the background token (no concatenations); False: round 5's form
 TRAIN_PE_UNDER_COARSE = True  # training: both clouds' PE groups (forward and backward) on the side stream underneath the coarse stage
 
 
-def _scores(scores, n1):
-    """C:68-76 / Fi:91-99 -- only `score` is consumed at eval time."""
-    return ops.overlap_scores(scores, n1)
+def _scores(scores, n1, halves=False):
+    """C:68-76 / Fi:91-99 -- only `score` is consumed at eval time.  `halves`: the head's output over both clouds as one batch of 2B."""
+    return ops.overlap_scores(scores, n1, halves=halves)
+
+
+def _bg_row(mod, dtype):
+    """The background token of a matcher as ONE contiguous row of `dtype` (cached per parameter version: no cast launch per forward)."""
+    p = mod.bg_token
+    key = (p._version, p.data_ptr(), dtype)
+    c = getattr(mod, "_bg_cache", None)
+    if c is None or c[0] != key:
+        with torch.no_grad():
+            c = (key, p.detach().reshape(-1).to(dtype).contiguous())
+        mod._bg_cache = c
+    return c[1]
 
 
 def _block_outputs(out_proj, score_head, f1, f2, n1, temp):
@@ -78,20 +91,33 @@ class CoarsePointMatchingOneRef(nn.Module):
         end_points["init_R"], end_points["init_t"] = init_R, init_t
         return end_points
 
-    def forward(self, p1, f1, geo1, p2, f2, geo2, radius, end_points):
+    def forward(self, p1, f1, geo1, p2, f2, geo2, radius, end_points, slot=None):
         if self.training:
             return self.forward_train(p1, f1, geo1, p2, f2, geo2, radius, end_points)
         B, n1 = f1.shape[:2]
-        f1 = ops.linear(f1, self.in_proj)
-        f2 = ops.linear(f2, self.in_proj)
-        bg = self.bg_token.expand(B, -1, -1).to(f1.dtype)
-        f1 = torch.cat([bg, f1], dim=1)
-        f2 = torch.cat([bg, f2], dim=1)
+        if slot is not None and f1.is_cuda and torch.is_autocast_enabled():
+            # `slot` (2B, 1 + n, C_in): both clouds' sparse features behind an unused row per pair (UNOPose._forward_from gathers them that way).
+            # in_proj runs over all rows as ONE GEMM, the background token is then written into row 0 of every pair: no concatenation, and the
+            # halves of f are what the blocks' stacked self layers expect
+            f = ops.set_first_rows_(ops.linear(slot, self.in_proj), _bg_row(self, torch.bfloat16))
+            f1, f2 = f[:B], f[B:]
+        else:
+            f1 = ops.linear(f1, self.in_proj)
+            f2 = ops.linear(f2, self.in_proj)
+            bg = self.bg_token.expand(B, -1, -1).to(f1.dtype)
+            f1 = torch.cat([bg, f1], dim=1)
+            f2 = torch.cat([bg, f2], dim=1)
         for blk in self.transformers:
             f1, f2 = blk(f1, geo1, f2, geo2)
-        scores = ops.score_head(torch.cat((f1, f2), dim=1), self.score_heads[self.nblock - 1])
-        atten = ops.feature_similarity(ops.linear(f1, self.out_proj), ops.linear(f2, self.out_proj), self.cfg.temp)
-        score = _scores(scores, n1)
+        f = _adjacent(f1, f2)  # (the blocks' cross layers wrote the halves of one tensor)
+        if f is not None and f1.is_cuda:
+            score = _scores(ops.score_head(f, self.score_heads[self.nblock - 1]), n1, halves=True)
+            o = ops.linear(f, self.out_proj)
+            atten = ops.feature_similarity(o[:B], o[B:], self.cfg.temp)
+        else:
+            scores = ops.score_head(torch.cat((f1, f2), dim=1), self.score_heads[self.nblock - 1])
+            atten = ops.feature_similarity(ops.linear(f1, self.out_proj), ops.linear(f2, self.out_proj), self.cfg.temp)
+            score = _scores(scores, n1)
         if self.taps is not None:  # test probe: the tensors the reference's eval branch hands to the pose head
             self.taps.update(f1=f1, f2=f2, atten=atten, score=score)
         n1p, n2p = self.cfg.nproposal1, self.cfg.nproposal2
@@ -179,18 +205,18 @@ class FinePointMatchingOneRef(nn.Module):
                 pe = self.PE(torch.cat([p1_, p2], 0)) if pe2_groups is None else \
                     self.PE.project(torch.cat([self.PE.groups(p1_), pe2_groups], 0))
                 d = d + pe.to(d.dtype)
-            bg = self.bg_token.expand(2 * B, -1, -1).to(d.dtype)
-            idx_all = torch.cat([fps_idx1, fps_idx2], 0).long()
+            bg = _bg_row(self, d.dtype).reshape(1, 1, -1).expand(2 * B, -1, -1)  # (read in place by the first block's gather: stride 0 is not a row layout the kernel takes, so gather_rows copies it once)
+            idx_all = torch.cat([fps_idx1, fps_idx2], 0)
             for blk in self.transformers:
                 d, bg = blk.forward_stacked(d, bg, e_all, idx_all)
             f = torch.cat([bg, d], dim=1)
             f1, f2 = f[:B], f[B:]
             sc = ops.score_head(f, self.score_heads[self.nblock - 1])
-            scores = torch.cat((sc[:B], sc[B:]), dim=1)
             o = ops.linear(f, self.out_proj)
             if self.taps is None and ops.fine_pose_fused_ok(o[:B], o[B:]):  # the similarity is never materialised
-                R, t, s = ops.fine_pose_from_features(o[:B], o[B:], self.cfg.temp, _scores(scores, n1), p1, p2)
+                R, t, s = ops.fine_pose_from_features(o[:B], o[B:], self.cfg.temp, _scores(sc, n1, halves=True), p1, p2)
                 return self._finish(end_points, R, t, s, radius)
+            scores = torch.cat((sc[:B], sc[B:]), dim=1)
             atten = ops.feature_similarity(o[:B], o[B:], self.cfg.temp)
         else:
             if p1_.shape == p2.shape:  # both clouds through the fused PE kernels as one batch of 2B
@@ -240,6 +266,7 @@ class UNOPose(nn.Module):
         self.fine_point_matching = FinePointMatchingOneRef(cfg.fine_point_matching)
         self.taps = None  # assign a dict to receive the sampling intermediates of the next forward (tests)
         self.fixed_init = None  # assign (init_R, init_t) to start the fine stage of the next forwards from that coarse pose (tests)
+        self._zero_rows = {}  # (C, dtype, device) -> one zero row (the unused slot row of the coarse matcher's stacked input)
         # side-stream overlaps INSIDE one forward (geometry under the ViT, reference-cloud PE under the coarse stage): +3 % when
         # forwards run one at a time; pipeline.PipelinedForward switches them off (another forward fills those gaps better)
         self.internal_overlap = True
@@ -273,15 +300,23 @@ class UNOPose(nn.Module):
         with torch.cuda.stream(side):
             idx_o = ops.furthest_point_sample(tem_n, self.fine_npoint)
             dense_po = ops.gather_rows(tem_n, idx_o)
-            sel_choose = torch.gather(tem_choose, 1, idx_o.long())
+            sparse_up = (ops.sparse_upproj_ok(rgb) and idx_o.shape == choose.shape and net.out_dim == 256 and rgb.shape == tem_rgb.shape
+                         and tem_choose.dtype == choose.dtype and tem_choose.is_contiguous())
+            if sparse_up:  # query | reference pixel indices in ONE tensor: the reference half is written by the gather itself (8-byte rows)
+                both_choose = torch.empty(2 * choose.shape[0], choose.shape[1], dtype=choose.dtype, device=choose.device)
+                both_choose[:choose.shape[0]].copy_(choose)
+                sel_choose = ops.gather_rows(tem_choose.unsqueeze(-1), idx_o, out=both_choose[choose.shape[0]:].unsqueeze(-1)).squeeze(-1)
+            else:
+                sel_choose = torch.gather(tem_choose, 1, idx_o.long())
             for t in (idx_o, dense_po, sel_choose):
                 t.record_stream(main)
             plan = None
-            if ops.sparse_upproj_ok(rgb) and sel_choose.shape == choose.shape and net.out_dim == 256 and rgb.shape == tem_rgb.shape:
+            if sparse_up:
                 # which cells of the up-projected map the 2 x 2048 chosen pixels read: known before the ViT has run
                 sd = rgb.shape[-1] // 14
                 npre = net.vit.cls_token.shape[1] + net.vit.reg_token.shape[1]
-                plan = ops.upproj_plan(torch.cat([choose, sel_choose], 0), rgb.shape[-2], rgb.shape[-1], sd, npre, npre + sd * sd)
+                both_choose.record_stream(main)
+                plan = ops.upproj_plan(both_choose, rgb.shape[-2], rgb.shape[-1], sd, npre, npre + sd * sd)
                 for t in plan.values():
                     if torch.is_tensor(t):
                         t.record_stream(main)
@@ -508,14 +543,34 @@ class UNOPose(nn.Module):
                        sparse_po_lrf=ops.gather_rows(po_lrf, fps_idx_o))
         sparse_pm, sparse_po, sparse_pm_lrf, sparse_po_lrf = (pre[k] for k in ("sparse_pm", "sparse_po", "sparse_pm_lrf",
                                                                                   "sparse_po_lrf"))
-        sparse_fm = pre["sparse_fm"] if "sparse_fm" in pre else ops.gather_rows(dense_fm, fps_idx_m)
-        sparse_fo = pre["sparse_fo"] if "sparse_fo" in pre else ops.gather_rows(dense_fo, fps_idx_o)
+        slot = None
+        if ("sparse_fm" not in pre and "sparse_fo" not in pre and COARSE_SLOT and dense_fm.is_cuda and torch.is_autocast_enabled() and not ops.is_differentiable()
+                and dense_fm.dtype == dense_fo.dtype and dense_fm.shape[2:] == dense_fo.shape[2:] and fps_idx_m.shape == fps_idx_o.shape
+                and dense_fm.is_contiguous() and dense_fo.is_contiguous()):
+            # both clouds' sparse features gathered into ONE (2B, 1 + n, C) tensor behind an unused (zero) row per pair: the coarse matcher's
+            # in_proj then runs as one GEMM and puts its background token into that row (CoarsePointMatchingOneRef.forward, `slot`)
+            n, C = fps_idx_m.shape[1], dense_fm.shape[2]
+            slot = torch.empty(2 * B, n + 1, C, dtype=dense_fm.dtype, device=dense_fm.device)
+            zr = self._zero_row(C, dense_fm.dtype, dense_fm.device).expand(B, C)
+            ops.gather_rows(dense_fm, fps_idx_m, alt=zr, prepend=True, out=slot[:B])
+            ops.gather_rows(dense_fo, fps_idx_o, alt=zr, prepend=True, out=slot[B:])
+            sparse_fm, sparse_fo = slot[:B, 1:], slot[B:, 1:]
+        else:
+            sparse_fm = pre["sparse_fm"] if "sparse_fm" in pre else ops.gather_rows(dense_fm, fps_idx_m)
+            sparse_fo = pre["sparse_fo"] if "sparse_fo" in pre else ops.gather_rows(dense_fo, fps_idx_o)
         if "geo" in pre:
             geo = pre["geo"]
         else:
             geo = self._geo(bg_point, sparse_pm_lrf, sparse_po_lrf)
         return self._matching(end_points, geo, B, sparse_pm, sparse_fm, sparse_po, sparse_fo, fps_idx_m, fps_idx_o,
-                              dense_pm, dense_fm, dense_po, dense_fo, radius)
+                              dense_pm, dense_fm, dense_po, dense_fo, radius, slot=slot)
+
+    def _zero_row(self, C, dtype, device):
+        key = (C, dtype, str(device))
+        z = self._zero_rows.get(key)
+        if z is None:
+            z = self._zero_rows[key] = torch.zeros(C, dtype=dtype, device=device)
+        return z
 
     def _geo(self, bg_point, sparse_pm_lrf, sparse_po_lrf):
         # both clouds' embeddings from ONE launch into ONE buffer (the RPE self layers then run 2B at once)
@@ -523,7 +578,7 @@ class UNOPose(nn.Module):
                                              torch.cat([bg_point, sparse_po_lrf], dim=1)], dim=0))
 
     def _matching(self, end_points, geo, B, sparse_pm, sparse_fm, sparse_po, sparse_fo, fps_idx_m, fps_idx_o, dense_pm,
-                  dense_fm, dense_po, dense_fo, radius):
+                  dense_fm, dense_po, dense_fo, radius, slot=None):
         geo_m, geo_o = geo[:B], geo[B:]
         # The reference cloud's positional encoding (Fi:77-80) does not depend on the coarse pose: its two fused
         # group/MLP/max launches run on the side stream UNDER the coarse stage, whose 197-token kernels and
@@ -546,7 +601,7 @@ class UNOPose(nn.Module):
                     pe2 = PE.groups(dense_po)
                     pe2.record_stream(main)
         end_points = self.coarse_point_matching(sparse_pm, sparse_fm, geo_m, sparse_po, sparse_fo, geo_o, radius,
-                                                end_points)
+                                                end_points, slot=slot)
         if pe2 is not None:
             torch.cuda.current_stream().wait_stream(self._side_stream(dense_po.device))
         if self.fixed_init is not None:  # test hook: the fine stage starts from a GIVEN coarse pose (the model's own one goes to `taps`)

@@ -37,7 +37,7 @@ from .sampling import (  # noqa: F401
     bilinear_sample_native, sparse_upproj_ok, upproj_plan, sparse_pixel_features, bilinear_sample_pixels,
 )
 from .pose import (  # noqa: F401
-    overlap_scores, pose_score, rigid_rows, feature_similarity, soft_assignment, coarse_pose_torch, fine_pose_torch, _assign_labels,
+    overlap_scores, set_first_rows_, pose_score, rigid_rows, feature_similarity, soft_assignment, coarse_pose_torch, fine_pose_torch, _assign_labels,
     coarse_pose, fine_pose, fine_pose_fused_ok, normalize_rows_bf16, fine_pose_from_features,
 )
 from .train import (  # noqa: F401

@@ -105,11 +105,12 @@ def scale_by_radius(x, radius, multiply=False, eps=1e-6):
     return out
 
 
-def gather_rows(feats, idx, off=0, alt=None, prepend=False):
+def gather_rows(feats, idx, off=0, alt=None, prepend=False, out=None):
     """out[b,j,:] = feats[b, idx[b,j] - off, :]  (the (B,N,C)-layout twin of gather_operation; avoids the two transpose copies
     around every reference call, model_utils.py:146-149, transformer.py:658).  `alt` (B,1,C) / (B,C): the row taken where
     idx - off < 0, and -- with `prepend` -- an extra row 0 of the output: the background-token sampling of the sparse-to-dense
-    block in one launch (csrc/glue.hip; index cast + clamp + gather + compare + where + cat otherwise)."""
+    block in one launch (csrc/glue.hip; index cast + clamp + gather + compare + where + cat otherwise).  Rows are raw bytes: any
+    element type whose row is a multiple of 4 bytes (the int64 pixel indices of the FPS subset are gathered as 8-byte rows)."""
     B, N, C = feats.shape
     J = idx.shape[1]
     if (feats.is_cuda and not st._DIFF and not feats.requires_grad and feats.is_contiguous() and idx.is_contiguous() and idx.dtype in (torch.int32, torch.int64)
@@ -117,15 +118,21 @@ def gather_rows(feats, idx, off=0, alt=None, prepend=False):
         alt_stride = 0
         if alt is not None:
             alt = alt.reshape(B, C)
-            if alt.dtype != feats.dtype or alt.stride(1) != 1 or alt.stride(0) < C:  # (rows any distance apart are read in place: the
-                alt = _c(alt.to(feats.dtype))                                        #  background tokens as row 0 of a (B, 1 + n, C) tensor)
+            if alt.dtype != feats.dtype or alt.stride(1) != 1 or 0 < alt.stride(0) < C:  # (rows any distance apart are read in place: the background
+                alt = _c(alt.to(feats.dtype))                                            #  tokens as row 0 of a (B, 1 + n, C) tensor; distance 0 = one row for all)
             alt_stride = (alt.stride(0) if B > 1 else C) * feats.element_size()
             if alt_stride % 4:
                 alt, alt_stride = alt.contiguous(), C * feats.element_size()
-        out = torch.empty(B, J + int(prepend), C, dtype=feats.dtype, device=feats.device)
+        if out is None:
+            out = torch.empty(B, J + int(prepend), C, dtype=feats.dtype, device=feats.device)
+        else:  # a destination the caller names (one half of a stacked tensor): written in place
+            assert out.shape == (B, J + int(prepend), C) and out.dtype == feats.dtype and out.is_contiguous() and out.device == feats.device
         with on_device(feats.device):
             call("unopose_gather_rows", ptr(feats), B, N, C * feats.element_size(), ptr(idx), int(idx.dtype == torch.int64), J, int(off),
                  None if alt is None else ptr(alt), alt_stride, int(prepend), ptr(out), stream_ptr())
+        return out
+    if out is not None:
+        out.copy_(gather_rows(feats, idx, off, alt, prepend))
         return out
     if off == 0 and alt is None:
         return torch.gather(feats, 1, idx.long().unsqueeze(2).expand(-1, -1, C))

@@ -5,13 +5,23 @@ import torch.nn.functional as F
 
 from .._lib import call, check_f32, on_device, ptr, stream_ptr
 from . import _state as st
-from .common import _c, _own_f32, _own_glue
+from .common import _c, _own_f32, _own_glue, note_mutation
 from .geometry import pairwise_distance, weighted_procrustes
 from .dense import bmm_nt_f32
 
 
-def overlap_scores(scores, n1):
-    """clamp(sigmoid(.)) of the score heads' outputs (B, n_tot, 1) without the two background tokens -> (B, n_tot - 2) fp32"""
+def overlap_scores(scores, n1, halves=False):
+    """clamp(sigmoid(.)) of the score heads' outputs (B, n_tot, 1) without the two background tokens -> (B, n_tot - 2) fp32.
+    `halves`: scores is (2B, n1 + 1, 1), the head's output over both clouds as one batch of 2B (cloud 2 of pair b = batch B + b)."""
+    if halves:
+        B = scores.shape[0] // 2
+        if not (_own_glue(scores) and scores.dtype in (torch.float32, torch.bfloat16)):
+            return overlap_scores(torch.cat((scores[:B], scores[B:]), dim=1), n1)
+        sc = _c(scores)
+        out = torch.empty(B, 2 * n1, dtype=torch.float32, device=sc.device)
+        with on_device(sc.device):
+            call("unopose_overlap_scores", ptr(sc), int(sc.dtype == torch.bfloat16), B, 2 * (n1 + 1), n1, 1, ptr(out), stream_ptr())
+        return out
     if not (_own_glue(scores) and scores.dtype in (torch.float32, torch.bfloat16)):
         s1, s2 = scores[:, 1:(n1 + 1)], scores[:, (n1 + 2):]
         return torch.clamp(torch.sigmoid(torch.cat((s1, s2), dim=1).squeeze(-1).float()), 0, 1)
@@ -19,8 +29,21 @@ def overlap_scores(scores, n1):
     B, n_tot = sc.shape[0], sc.shape[1]
     out = torch.empty(B, n_tot - 2, dtype=torch.float32, device=sc.device)
     with on_device(sc.device):
-        call("unopose_overlap_scores", ptr(sc), int(sc.dtype == torch.bfloat16), B, n_tot, n1, ptr(out), stream_ptr())
+        call("unopose_overlap_scores", ptr(sc), int(sc.dtype == torch.bfloat16), B, n_tot, n1, 0, ptr(out), stream_ptr())
     return out
+
+
+def set_first_rows_(x, row):
+    """x[:, 0, :] = row for x (B, n, C) contiguous and ONE row (C,) of x's dtype (the background token in front of every pair), in place, one
+    launch (csrc/glue.hip copy_rows)."""
+    B, n, C = x.shape
+    note_mutation()
+    if not (_own_glue(x) and x.is_contiguous() and row.is_contiguous() and row.dtype == x.dtype and row.numel() == C and (C * x.element_size()) % 4 == 0 and B <= 65535):
+        x[:, 0, :] = row.reshape(1, C).to(x.dtype)
+        return x
+    with on_device(x.device):
+        call("unopose_copy_rows", ptr(row), 0, ptr(x), n * C * x.element_size(), B, C * x.element_size(), stream_ptr())
+    return x
 
 
 def pose_score(dis, w, thr):
