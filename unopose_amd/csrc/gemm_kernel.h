@@ -9,7 +9,7 @@ namespace unopose {
 #define GEMM_ABL 0  // scripts/ubench/gemm_var.py: 1 = no LDS-DMA in the K loop, 2 = no MFMAs, 3 = no fragment reads
 #endif
 #ifndef GEMM_EABL
-#define GEMM_EABL 0  // epilogue ablations: 1 = no global stores, 2 = no epilogue at all (accumulators kept live), 3 = no bias / activation math
+#define GEMM_EABL 0  // epilogue ablations: 1 = no global stores, 2 = no epilogue at all (accumulators kept live), 3 = no bias / activation math, 4 = EPI 5 without the loads of the old x
 #endif
 #ifndef GEMM_SAME
 #define GEMM_SAME 0  // probe: every tile streams the operands of tile (0, 0) -- an all-hit L2 stream under the full K loop
@@ -580,8 +580,13 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
       f32x4 rv[PF][4];
       auto load_round = [&](int r, f32x4(&dst)[4]) {  // round r = rows r * 16 .. + 15 of the wave's 128
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
+        for (int it = 0; it < 4; ++it) {
+          if (GEMM_EABL >= 4) {  // timing probes (wrong results): 4 = no loads of the old x (what an epilogue of stores alone costs); 5 = nor the fp32 store; 6 = nor the row sums; 7 = neither
+            dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            continue;
+          }
           dst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, x_v0 + (uint32_t)(r * 16 + it * 4) * x_rowb, 0, GEMM_XPOL));
+        }
       };
 #pragma unroll
       for (int r = 0; r < PF; ++r) load_round(r, rv[r]);
@@ -609,13 +614,15 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(127))) void 
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = a[e] + o[e];
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), x_rs, x_v0 + (uint32_t)(r * 16 + it * 4) * x_rowb, 0, GEMM_XPOL);
+          if (GEMM_EABL != 5 && GEMM_EABL != 7)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), x_rs, x_v0 + (uint32_t)(r * 16 + it * 4) * x_rowb, 0, GEMM_XPOL);
           typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
           const u32x2 pk = {cvt_pk_bf16_f32(v[0], v[1]), cvt_pk_bf16_f32(v[2], v[3])};
           if (nt_store)
             __builtin_amdgcn_raw_buffer_store_b64(pk, c_rs, c_v0 + (uint32_t)(r * 16 + it * 4) * c_rowb, 0, 2);
           else
             __builtin_amdgcn_raw_buffer_store_b64(pk, c_rs, c_v0 + (uint32_t)(r * 16 + it * 4) * c_rowb, 0, 0);
+          if (GEMM_EABL == 6 || GEMM_EABL == 7) continue;
           float a1 = (v[0] + v[1]) + (v[2] + v[3]), a2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
           a1 += dpp_f32<0x111, 0xF>(a1, 0.f);  // row_shr 1, 2, 4, 8: the 16 lanes of a DPP row hold one matrix row; the sum lands in lane 15
           a2 += dpp_f32<0x111, 0xF>(a2, 0.f);
