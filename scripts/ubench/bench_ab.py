@@ -13,8 +13,13 @@ if sys.argv[1] == "--one":
     from unopose_amd import ops
 
     name, val = sys.argv[2], sys.argv[3] == "True"
-    assert hasattr(ops, name), name
-    setattr(ops, name, val)
+    if name.startswith("model."):  # a module-level flag of unopose_amd.model.unopose (e.g. model.COARSE_SLOT)
+        import unopose_amd.model.unopose as mu
+        assert hasattr(mu, name[6:]), name
+        setattr(mu, name[6:], val)
+    else:
+        assert hasattr(ops, name), name
+        setattr(ops, name, val)
     sys.argv = ["bench.py", "--no-cpu-baseline", "--no-fp32", "--no-extra", "--no-roofline", "--steps", "20", "--warmup", "5"] + sys.argv[4:]
     buf = io.StringIO()
     with redirect_stdout(buf):

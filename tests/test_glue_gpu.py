@@ -334,12 +334,18 @@ def test_topk_smallest_and_coarse_pick_kernels():
         return {k: torch.from_numpy(z[k]).cuda() if z[k].ndim else z[k].item() for k in z.files}
 
     g = torch.Generator().manual_seed(5)
-    for B, n, k in ((3, 6000, 300), (2, 257, 257), (1, 5, 1), (4, 1000, 37)):
+    for B, n, k in ((3, 6000, 300), (2, 257, 257), (1, 5, 1), (4, 1000, 37), (2, 9000, 2048), (2, 6000, 2500), (33, 6000, 300)):  # (k > 2048: the counting kernel)
         x = torch.randn(B, n, generator=g).cuda()
         idx = torch.full((B, k), -1, dtype=torch.int64, device="cuda")
         call("unopose_topk_smallest", ptr(x), B, n, k, ptr(idx), stream_ptr())
         want = torch.topk(x, k, dim=1, largest=False)
         assert torch.equal(torch.gather(x, 1, idx), want[0]) and torch.equal(idx, want[1])  # (distinct values: one answer)
+    xt = torch.randint(0, 7, (3, 4000), generator=g).float().cuda()  # seven distinct values: ties everywhere, the stable order is the only answer
+    for k in (1, 300, 2048, 3000):
+        idx = torch.empty(3, k, dtype=torch.int64, device="cuda")
+        call("unopose_topk_smallest", ptr(xt), 3, 4000, k, ptr(idx), stream_ptr())
+        want = torch.sort(xt, dim=1, stable=True)[1][:, :k]
+        assert torch.equal(idx, want), k
     x = torch.tensor([[3.0, 1.0, float("nan"), 1.0, -0.0, 0.0, float("inf"), 1.0, -5.0, float("-inf")]]).cuda()
     idx = torch.empty(1, 10, dtype=torch.int64, device="cuda")
     call("unopose_topk_smallest", ptr(x), 1, 10, 10, ptr(idx), stream_ptr())

@@ -431,8 +431,8 @@ __global__ __launch_bounds__(256) void infonce_grad_kernel(const float *__restri
 }
 
 // ---- the k smallest of n values per row, ascending, ties by index (torch.topk(dis, k, largest=False, sorted=True) of model_utils.py:476;
-//      NaN counts as the largest value, as in torch): rank by counting.  One thread per element compares its key with the row's n keys
-//      in LDS (broadcast reads): 6000 x 6000 comparisons per pair are 6 us spread over the chip -- no sort, no library launch.
+//      NaN counts as the largest value, as in torch).  Large k: rank by counting -- one thread per element compares its key with the row's n
+//      keys in LDS (broadcast reads), no sort, no library launch; k <= TS_KMAX: the one-workgroup radix select below.
 __device__ __forceinline__ uint32_t topk_key(float v) {
   if (v != v) return 0xFFFFFFFFu;
   const uint32_t u = __float_as_uint(v);
@@ -454,6 +454,87 @@ __global__ __launch_bounds__(256) void topk_smallest_kernel(const float *__restr
     rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
   }
   if (rank < k) idx[(size_t)b * k + rank] = i;
+}
+
+// The same selection for k <= TS_KMAX with ONE workgroup per row (the counting kernel above spends n^2 comparisons per row on the whole chip --
+// 6.4 k CU-microseconds per 32 pairs, which a co-running stream pays for; this one ~0.5 k): radix select of the k-th smallest key (four 8-bit
+// histogram rounds over the keys in LDS), compaction of the keys below it in index order + the lowest-index ties, then the k chosen entries
+// ranked among themselves.
+constexpr int TS_KMAX = 2048;
+__device__ __forceinline__ int ts_block_excl_scan(int v, int *wtot, int tid) {  // exclusive prefix sum over the 256 threads; wtot: 4 ints of LDS
+  const int lane = tid & 63, wave = tid >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  __syncthreads();  // (wtot may still be read from the previous scan)
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wtot[w];
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(256) void topk_select_kernel(const float *__restrict__ x, int n, int k, int64_t *__restrict__ idx) {
+  extern __shared__ uint32_t tk_keys[];  // [n] keys, then [k] chosen keys, [k] chosen indices
+  __shared__ int hist[256], wtot[4], sh_bin, sh_need;
+  uint32_t *sel_key = tk_keys + n;
+  int *sel_idx = reinterpret_cast<int *>(sel_key + k);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *row = x + (size_t)b * n;
+  for (int j = tid; j < n; j += 256) tk_keys[j] = topk_key(row[j]);
+  // ---- the k-th smallest key T, and how many of the keys equal to it belong to the k
+  uint32_t prefix = 0u, mask = 0u;
+  int need = k;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[tid] = 0;
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) {
+      const uint32_t key = tk_keys[j];
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    const int c = hist[tid], excl = ts_block_excl_scan(c, wtot, tid);
+    if (excl < need && need <= excl + c) sh_bin = tid, sh_need = need - excl;  // exactly one thread
+    __syncthreads();
+    prefix |= (uint32_t)sh_bin << shift;
+    mask |= 0xFFu << shift;
+    need = sh_need;
+  }
+  const uint32_t T = prefix;
+  const int c_lt = k - need;  // keys strictly below T; `need` of the keys equal to T follow, lowest indices first
+  // ---- compaction in index order: thread t owns the indices [t chunk, (t + 1) chunk)
+  const int chunk = (n + 255) / 256, j0 = min(tid * chunk, n), j1 = min(j0 + chunk, n);
+  int a = 0, e = 0;
+  for (int j = j0; j < j1; ++j) {
+    const uint32_t key = tk_keys[j];
+    a += key < T;
+    e += key == T;
+  }
+  int a_off = ts_block_excl_scan(a, wtot, tid), e_off = ts_block_excl_scan(e, wtot, tid);
+  for (int j = j0; j < j1; ++j) {
+    const uint32_t key = tk_keys[j];
+    if (key < T) {
+      sel_key[a_off] = key, sel_idx[a_off] = j;
+      ++a_off;
+    } else if (key == T) {
+      if (e_off < need) idx[(size_t)b * k + c_lt + e_off] = j;  // the ties are already in their final places
+      ++e_off;
+    }
+  }
+  __syncthreads();
+  // ---- the c_lt entries below T, ranked among themselves (they sit in index order: position breaks ties)
+  for (int i = tid; i < c_lt; i += 256) {
+    const uint32_t ki = sel_key[i];
+    int rank = 0;
+    for (int m = 0; m < c_lt; ++m) {
+      const uint32_t km = sel_key[m];
+      rank += (km < ki || (km == ki && m < i)) ? 1 : 0;
+    }
+    idx[(size_t)b * k + rank] = sel_idx[i];
+  }
 }
 
 // ---- the winning hypothesis of a pair (model_utils.py:486-490: pose_score.max(1), then the gathers of R and t): the first maximum of
@@ -587,7 +668,10 @@ int unopose_topk_smallest(const float *x, int B, int n, int k, int64_t *idx, uno
   UNOPOSE_REQUIRE(x && idx, "topk_smallest: null pointer");
   UNOPOSE_REQUIRE(B >= 0 && B <= 65535 && n >= 1 && k >= 1 && k <= n && (size_t)n * 4 <= 64 * 1024, "topk_smallest: bad sizes (n=%d k=%d; n <= 16384)", n, k);
   if (B == 0) return UNOPOSE_OK;
-  hipLaunchKernelGGL(topk_smallest_kernel, dim3(cdiv(n, 256), B), dim3(256), (size_t)n * 4, (hipStream_t)stream, x, n, k, idx);
+  if (k <= TS_KMAX && (size_t)(n + 2 * k) * 4 <= 60 * 1024)  // one workgroup per row: radix select + a k x k ranking
+    hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(256), (size_t)(n + 2 * k) * 4, (hipStream_t)stream, x, n, k, idx);
+  else  // rank by counting over the whole row
+    hipLaunchKernelGGL(topk_smallest_kernel, dim3(cdiv(n, 256), B), dim3(256), (size_t)n * 4, (hipStream_t)stream, x, n, k, idx);
   return check_launch("topk_smallest");
 }
 
