@@ -102,8 +102,8 @@ class PipelinedForward:
         if run_ahead is None:
             run_ahead = 1 if self.depth > 1 else 0
         self._limit = self.depth + max(0, int(run_ahead))  # forwards the host may have enqueued and not yet seen finish
-        # stages: every forward is cut in two -- `forward_features` (the ViT) on one stream, `forward_matching` on a second,
-        # high-priority one -- so that ViTs never overlap each other and the latency-bound matcher of batch i always runs
+        # stages: every forward is cut in two -- `forward_features` (the ViT) on one stream, `forward_matching` on a second
+        # (same priority since round 6) -- so that ViTs never overlap each other and the latency-bound matcher of batch i always runs
         # beside the ViT of batch i + 1, instead of two whole forwards advancing side by side.  Measured (same box, pairs/s):
         # 518 x 518 crops 861 vs 832, 224 x 224 crops 1988 vs 2086 (there the matcher outlasts the ViT) -> "auto" cuts the
         # forward when the ViT sees >= 1024 tokens.  The in-forward side-stream overlaps stay on in this mode (+1.5 %).
@@ -134,7 +134,9 @@ class PipelinedForward:
         self.last_mode = "stages" if use_stages else "whole"  # what this submit chose (bench.py reports it)
         if use_stages:
             if self._stage_streams is None:
-                self._stage_streams = [_pool_streams(self.device, "features", 1)[0], _pool_streams(self.device, "matching", 1, priority=-1)[0]]
+                # (both at the default priority: the matching stream at high priority -- rounds 4-6 -- measures 0.7-0.9 % slower on two boxes, the
+                #  features stream above the matching stream 1 % slower with 1.5 x the latency: scripts/ubench/prio_ab.sh)
+                self._stage_streams = [_pool_streams(self.device, "features", 1)[0], _pool_streams(self.device, "matching0", 1)[0]]
             for ss in self._stage_streams:  # the caches the very first forward built (in EITHER mode) are ordered before this stream's first use
                 if self._warm is not None and ss.cuda_stream not in self._warm_seen:
                     ss.wait_event(self._warm)
