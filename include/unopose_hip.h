@@ -446,9 +446,11 @@ int unopose_scale_residual_layernorm(float *x, const void *y_bf16, const float *
                                      const float *bias, long rows, int C, float eps, void *out_bf16,
                                      unopose_stream_t stream);
 /* The same for fp32 data (no autocast: the reference's default precision): x += gamma * y with y float32 (y NULL: no update);
- * LayerNorm(x) is written in the split layout of unopose_linear_f32x3 (out_split NULL: residual update only).  C % 32 == 0. */
+ * LayerNorm(x) is written in the split layout of unopose_linear_f32x3 (out_split NULL: residual update only).  C % 32 == 0.
+ * out_ld_bytes: distance between output rows (0 = 4 C, dense): a column block of a wider split-layout matrix -- the four tap LayerNorms of
+ * ViT_AE (oneref_feature_extraction.py:207-213) side by side as the up-projection's K = 4 C operand, no concatenation. */
 int unopose_scale_residual_layernorm_f32(float *x, const float *y, const float *gamma, const float *w, const float *bias, long rows,
-                                         int C, float eps, void *out_split, unopose_stream_t stream);
+                                         int C, float eps, void *out_split, long out_ld_bytes, unopose_stream_t stream);
 
 /* x (rows,C) float32 += gamma (C) * y (rows,C) bfloat16, in place: the LayerScale residual of a
  * timm ViT block (x = x + ls(branch(x))). */

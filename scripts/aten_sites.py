@@ -8,12 +8,15 @@ from unopose_amd.model import UNOPose, default_model_cfg  # noqa: E402
 from unopose_amd.synthetic import make_batch, trained_like_  # noqa: E402
 
 img = int(sys.argv[1]) if len(sys.argv) > 1 else 518
+fp32 = len(sys.argv) > 2 and sys.argv[2] == "fp32"  # the reference's default precision (no autocast)
+import contextlib
+ac = contextlib.nullcontext if fp32 else (lambda: torch.autocast("cuda", dtype=torch.bfloat16))
 torch.set_grad_enabled(False)
 dev = torch.device("cuda")
 model = trained_like_(UNOPose(default_model_cfg(feature_extraction=dict(img_size=img)))).to(dev).eval()
 batch, _, _ = make_batch(32, 2048, 5000, img, seed=1, device=dev)
 batch["coarse_rand"] = torch.rand(32, 18000, device=dev)
-with torch.autocast("cuda", dtype=torch.bfloat16):
+with ac():
     model(dict(batch))
 sites = collections.defaultdict(lambda: [0, 0, set()])
 VIEW = ("aten.view", "aten.reshape", "aten.expand", "aten.slice", "aten.select", "aten.unsqueeze", "aten.squeeze", "aten.transpose", "aten.permute",
@@ -37,7 +40,7 @@ class Log(TorchDispatchMode):
         return out
 
 
-with torch.autocast("cuda", dtype=torch.bfloat16), Log():
+with ac(), Log():
     model(dict(batch))
 torch.cuda.synchronize()
 tot = sum(v[0] for v in sites.values())

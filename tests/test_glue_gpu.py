@@ -211,6 +211,12 @@ def test_scale_residual_layernorm_f32_kernel():
     assert torch.equal(xs2, x) and float((n_only - norm(x)).abs().max()) < 2e-5 * float(norm(x).abs().max())
     xs3 = x.clone()
     assert ops.scale_residual_layernorm_f32_(xs3, y, gamma, None) is xs3 and torch.equal(xs3, want_x)
+    # into column block 2 of a four-block-wide split matrix (the tap LayerNorms of the fp32 ViT side by side): that block equals the dense result
+    # bit for bit, the other blocks stay untouched
+    wide = torch.full((303, 2 * 4 * 768), 7.0, dtype=torch.bfloat16, device="cuda")
+    assert ops.scale_residual_layernorm_f32_(x.clone(), None, None, norm, wide=wide, block=2) is wide
+    dense = ops.scale_residual_layernorm_f32_(x.clone(), None, None, norm)
+    assert torch.equal(wide[:, 2 * 1536:3 * 1536], dense) and bool((wide[:, :2 * 1536] == 7.0).all()) and bool((wide[:, 3 * 1536:] == 7.0).all())
     # the layout is the split kernel's: the hi halves are the bf16 roundings of the values the pair encodes (lo < half an ulp of hi)
     hi = ns.reshape(-1, 24, 2, 32)[:, :, 0].float()
     assert float((hi - _unsplit(ns, 768).reshape(-1, 24, 32)).abs().max()) <= 2.0 ** -8 * float(hi.abs().max())

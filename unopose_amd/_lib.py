@@ -38,7 +38,7 @@ SIGNATURES = {
     "unopose_weighted_procrustes": [_P, _P, _P, _I, _I, _F, _F, _P, _P, _P],
     "unopose_assign_labels": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "unopose_linear_bf16_ld": [_P, _I, _P, _I, _P, _P, _I, ctypes.c_long, _I, _I, _I, _P],
-    "unopose_scale_residual_layernorm_f32": [_P, _P, _P, _P, _P, ctypes.c_long, _I, _F, _P, _P],
+    "unopose_scale_residual_layernorm_f32": [_P, _P, _P, _P, _P, ctypes.c_long, _I, _F, _P, _L, _P],
     "unopose_gather_rows": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _L, _I, _P, _P],
     "unopose_softmax_stats": [_P, _I, _I, _I, _P, _P],
     "unopose_infonce_grad": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void scale_residual_layernorm_kernel(float *__
 __global__ __launch_bounds__(256) void scale_residual_layernorm_f32_kernel(float *__restrict__ x, const float *__restrict__ y,
                                                                            const float *__restrict__ gamma, const float *__restrict__ w,
                                                                            const float *__restrict__ bias, long rows, int C, float eps,
-                                                                           char *__restrict__ out) {
+                                                                           char *__restrict__ out, long out_ld) {
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void scale_residual_layernorm_f32_kernel(float
       l.x = cvt_pk_bf16_f32(n0 - __uint_as_float(h.x << 16), n1 - __uint_as_float(h.x & 0xffff0000u));
       l.y = cvt_pk_bf16_f32(n2 - __uint_as_float(h.y << 16), n3 - __uint_as_float(h.y & 0xffff0000u));
       // channels c .. c+3 = half of the 8-element chunk c / 8 of 32-channel block c / 32: hi at +0, lo at +64 of the 128-byte line
-      char *line = out + (size_t)r * C * 4 + (size_t)(c >> 5) * 128 + ((c >> 3) & 3) * 16 + ((c >> 2) & 1) * 8;
+      char *line = out + (size_t)r * out_ld + (size_t)(c >> 5) * 128 + ((c >> 3) & 3) * 16 + ((c >> 2) & 1) * 8;
       *reinterpret_cast<uint2 *>(line) = h;
       *reinterpret_cast<uint2 *>(line + 64) = l;
     }
@@ -396,13 +396,14 @@ int unopose_scale_residual_layernorm(float *x, const void *y_bf16, const float *
   return check_launch("scale_residual_layernorm");
 }
 
-int unopose_scale_residual_layernorm_f32(float *x, const float *y, const float *gamma, const float *w, const float *bias, long rows, int C,
-                                         float eps, void *out_split, unopose_stream_t stream) {
+int unopose_scale_residual_layernorm_f32(float *x, const float *y, const float *gamma, const float *w, const float *bias, long rows, int C, float eps,
+                                         void *out_split, long out_ld_bytes, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(x && (y || out_split) && (!y || gamma) && (!out_split || (w && bias)), "scale_residual_layernorm_f32: null pointer");
   UNOPOSE_REQUIRE(rows >= 0 && C >= 32 && C % 32 == 0 && C <= 1024, "scale_residual_layernorm_f32: C must be a multiple of 32, <= 1024");
+  UNOPOSE_REQUIRE(out_ld_bytes == 0 || (out_ld_bytes >= (long)C * 4 && out_ld_bytes % 128 == 0), "scale_residual_layernorm_f32: output rows must be >= 4 C bytes apart, whole 128-byte lines (got %ld)", out_ld_bytes);
   if (rows == 0) return UNOPOSE_OK;
   hipLaunchKernelGGL(scale_residual_layernorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, gamma, w,
-                     bias, rows, C, eps, (char *)out_split);
+                     bias, rows, C, eps, (char *)out_split, out_ld_bytes ? out_ld_bytes : (long)C * 4);
   return check_launch("scale_residual_layernorm_f32");
 }
 

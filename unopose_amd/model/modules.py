@@ -119,6 +119,17 @@ class _PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(3, dim, patch, patch)
 
 
+F32_TAPS_SPLIT = True  # (module attribute for A/Bs) the no-autocast ViT's tap LayerNorms written side by side in the split layout; False: torch LayerNorm + cat + split pass
+
+
+class SplitTaps:
+    """The four tap LayerNorms of the no-autocast ViT side by side as ONE (B T, 2 K) bf16 matrix in the split layout of csrc/gemm_f32.hip
+    (K = 4 D fp32-equivalent columns; the 5 prefix tokens of every image stay in place)."""
+
+    def __init__(self, split, B, T, K):
+        self.split, self.B, self.T, self.K = split, B, T, K
+
+
 class ViT(nn.Module):
     """DINOv2 ViT (reg4, no_embed_class) with timm 0.9.12's state_dict keys; forward returns the four
     tapped, final-normed token maps like the reference subclass (F:24-42).  Accepts any S % 14 == 0 as
@@ -164,11 +175,18 @@ class ViT(nn.Module):
         if ops.vit_f32_fused_ok(x, self):
             x = x.contiguous()
             ns = ops.scale_residual_layernorm_f32_(x, None, None, self.blocks[0].norm1)
+            # taps side by side (round 6): the four tap LayerNorms go straight into the column blocks of ONE split-layout matrix, the K = 4 D operand
+            # of the up-projection -- no torch LayerNorm, no 1 GB concatenation, no split pass (4.3 GB of traffic per forward at B = 32, 518 x 518)
+            wide = torch.empty(x.shape[0] * x.shape[1], 2 * 4 * x.shape[2], dtype=torch.bfloat16, device=x.device) if taps_side_by_side and F32_TAPS_SPLIT else None
             for i, blk in enumerate(self.blocks):
                 x, ns = blk.forward_fused_f32(x, ns, self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None)
                 if i in taps:
-                    outs.append(self.norm(x))
-            return outs
+                    if wide is not None:
+                        ops.scale_residual_layernorm_f32_(x, None, None, self.norm, wide=wide, block=len(outs))
+                        outs.append(None)
+                    else:
+                        outs.append(self.norm(x))
+            return SplitTaps(wide, x.shape[0], x.shape[1], 4 * x.shape[2]) if wide is not None else outs
         for i, blk in enumerate(self.blocks):
             x = blk(x)
             if i in taps:
@@ -270,6 +288,11 @@ class ViT_AE(nn.Module):
 
     def upproject(self, outs, H, W):
         """The second half of `upprojected_tokens`, on what `self.vit(x, taps_side_by_side=True)` returned."""
+        if isinstance(outs, SplitTaps):  # fp32: the taps as one split-layout operand (prefix tokens in place, as on the autocast path)
+            lin = self.output_upscaling
+            c = ops._f32x3_weights(lin)
+            z = ops.linear_f32x3(outs.split, c[1], c[2], outs.B * outs.T, lin.weight.shape[0], outs.K)
+            return z.reshape(outs.B, outs.T, 4, 4, self.out_dim), (H, W), outs.T - (H // 14) * (W // 14)
         B = outs.shape[0] if torch.is_tensor(outs) else outs[0].shape[0]
         if torch.is_tensor(outs):
             z = ops.linear(outs, self.output_upscaling)

@@ -1,6 +1,8 @@
 """Dense linear layers on the hand-written GEMMs (csrc/gemm.hip, gemm_small.hip, gemm_f32.hip, bmm_f32.hip) and the row-wise glue around them
 (csrc/fused.hip, glue.hip): nn.Linear under autocast and in fp32 class, the ViT prologue, LayerNorm / LayerScale passes, the residual +
 LayerNorm fold, and the trainable form under autograd.  Each function cites the reference Python it replaces."""
+import ctypes
+
 import torch
 import torch.nn.functional as F
 
@@ -529,19 +531,27 @@ def scale_residual_(x, y, gamma):
     return x
 
 
-def scale_residual_layernorm_f32_(x, y, gamma, norm):
+def scale_residual_layernorm_f32_(x, y, gamma, norm, wide=None, block=0):
     """fp32 twin for the no-autocast path: x (fp32, contiguous) += gamma * y (fp32) in place (y None: no update); returns
-    LayerNorm(x) in the split layout of csrc/gemm_f32.hip as a (rows, 2C) bf16 tensor (norm None: residual update only, returns x)."""
+    LayerNorm(x) in the split layout of csrc/gemm_f32.hip as a (rows, 2C) bf16 tensor (norm None: residual update only, returns x).
+    `wide` (rows, 2 n C) bf16, `block`: the result goes into column block `block` of that wider split-layout matrix instead (the tap
+    LayerNorms of ViT_AE side by side: the K = n C operand of the up-projection without a concatenation or a split pass); returns wide."""
     note_mutation()
     assert x.dtype == torch.float32 and x.is_contiguous() and (y is None or y.dtype == torch.float32)
     C = x.shape[-1]
     rows = x.numel() // C
-    out = None if norm is None else torch.empty(rows, 2 * C, dtype=torch.bfloat16, device=x.device)
+    ld, dst = 0, None
+    if wide is not None:
+        assert norm is not None and wide.dtype == torch.bfloat16 and wide.is_contiguous() and wide.shape[0] == rows and wide.shape[1] % (2 * C) == 0
+        ld = wide.shape[1] * 2
+        assert 0 <= block < wide.shape[1] // (2 * C)
+        dst = ctypes.c_void_p(wide.data_ptr() + block * C * 4)
+    out = None if (norm is None or wide is not None) else torch.empty(rows, 2 * C, dtype=torch.bfloat16, device=x.device)
     with on_device(x.device):
         call("unopose_scale_residual_layernorm_f32", ptr(x), None if y is None else ptr(_c(y)), None if y is None else ptr(gamma),
              None if norm is None else ptr(norm.weight), None if norm is None else ptr(norm.bias), rows, C,
-             0.0 if norm is None else float(norm.eps), None if out is None else ptr(out), stream_ptr())
-    return x if norm is None else out
+             0.0 if norm is None else float(norm.eps), dst if wide is not None else (None if out is None else ptr(out)), ld, stream_ptr())
+    return x if norm is None else (wide if wide is not None else out)
 
 
 def vit_f32_fused_ok(x, vit):
