@@ -495,6 +495,12 @@ int unopose_patchify_bf16(const float *rgb_a, int na, const float *rgb_b, int nb
  * [prefix (npre,768) | patch (nimg,P,768) bf16 + pos (P,768)], n1 = LayerNorm(x) * ln_w + ln_b as bf16. */
 int unopose_vit_tokens_layernorm(const void *patch, const float *pos, const float *prefix, int npre, int P, int nimg, int C,
                                  const float *ln_w, const float *ln_b, float eps, float *x, void *n1, unopose_stream_t stream);
+/* The two steps above for the no-autocast forward (the reference's default precision): the patch matrix written in the split layout of
+ * unopose_linear_f32x3 (Kp % 32 == 0: 588 -> 608 zero-padded columns), and the token assembly on the float32 patch embedding with the
+ * first LayerNorm in the split layout. */
+int unopose_patchify_split(const float *rgb_a, int na, const float *rgb_b, int nb, int S, int Kp, void *out, unopose_stream_t stream);
+int unopose_vit_tokens_layernorm_f32(const float *patch, const float *pos, const float *prefix, int npre, int P, int nimg, int C,
+                                     const float *ln_w, const float *ln_b, float eps, float *x, void *n1_split, unopose_stream_t stream);
 /* out[r] = x[r,:] . w + b for 256-wide rows: the overlap-score heads nn.Linear(256, 1)
  * (oneref_predator_coarse_point_matching.py:66, ..._fine_point_matching.py:89). */
 int unopose_row_dot(const void *x, int x_bf16, const float *w, float b, long rows, int C, void *out, int out_bf16,
@@ -514,6 +520,8 @@ int unopose_normalize_rows_bf16(const void *x, int x_bf16, long rows, int C, flo
 int unopose_gather_rows(const void *feats, int B, int N, int row_bytes, const void *idx, int idx_is_i64, int J, int off,
                         const void *alt, long alt_stride_bytes, int prepend, void *out, unopose_stream_t stream);
 int unopose_transpose_pad_bf16(const void *v, long ld, int B, int m, int C, int pad, void *vt, unopose_stream_t stream);
+/* The same on float32 data: the value image of unopose_token_attention_f32 (transformer.py:386-405 at the reference's default precision). */
+int unopose_transpose_pad_f32(const float *v, long ld, int B, int m, int C, int pad, float *vt, unopose_stream_t stream);
 
 /* Small fp32 glue of the forward (round 5: the last torch reductions / elementwise kernels of the eval path).
  * cloud_radius: radius[b] = max_i |p_i - mean(p)| of pts (B,N,3) (oneref_grf_predator_pose_estimation_model.py: the normalisation radius).

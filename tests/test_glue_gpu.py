@@ -86,6 +86,10 @@ def test_row_dot_normalize_transpose_pad():
     import ctypes
     call("unopose_transpose_pad_bf16", ctypes.c_void_p(y.data_ptr() + 512 * 2), y.stride(1), 5, 197, 256, 256, ptr(vt), stream_ptr())
     assert torch.equal(vt[:, :, :197], y[..., 512:].transpose(1, 2)) and (vt[:, :, 197:] == 0).all()
+    y32 = torch.randn(5, 197, 512, generator=g).cuda()  # fp32: k | v side by side
+    vt32 = torch.full((5, 256, 224), 7.0, device="cuda")
+    call("unopose_transpose_pad_f32", ctypes.c_void_p(y32.data_ptr() + 256 * 4), y32.stride(1), 5, 197, 256, 224, ptr(vt32), stream_ptr())
+    assert torch.equal(vt32[:, :, :197], y32[..., 256:].transpose(1, 2)) and (vt32[:, :, 197:] == 0).all()
 
 
 @torch.no_grad()

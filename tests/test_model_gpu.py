@@ -845,3 +845,28 @@ def test_untamed_weights_forward_vs_reference_fixture(model):
         d = (ftaps[k][:, rows_f].float().cpu() - t(m + "_rows")).abs().amax(dim=2) / float(t(m + "_absmax"))
         assert float((d < 5e-3).float().mean()) > 0.9 and float(d.median()) < 3e-3 and float(d.max()) < 5e-2, (k, float(d.median()), float(d.max()))
     assert torch.isfinite(out["pred_R"]).all()
+
+@torch.no_grad()
+def test_fp32_vit_fused_front_end_and_side_by_side_taps(model):
+    """The no-autocast ViT through the fused fp32 prologue (patchify -> split layout, fp32-class patch embedding, tokens + first LayerNorm in one
+    pass) and with its four tap LayerNorms side by side in the split layout, against the op-by-op front end / torch LayerNorm + cat: the
+    up-projected token maps agree to fp32-class accuracy (same kernels for the blocks either way)."""
+    import unopose_amd.model.modules as mm
+
+    net = model.feature_extraction.rgb_net
+    g = torch.Generator().manual_seed(12)
+    xa, xb = torch.randn(2, 3, 224, 224, generator=g).cuda(), torch.randn(2, 3, 224, 224, generator=g).cuda()
+    outs = {}
+    for pro, taps in ((True, True), (False, True), (True, False), (False, False)):
+        mm.F32_PROLOGUE, mm.F32_TAPS_SPLIT = pro, taps
+        try:
+            acts = net.vit((xa, xb), taps_side_by_side=True)
+            assert isinstance(acts, mm.SplitTaps) == taps
+            z, (H, W), off = net.upproject(acts, 224, 224)
+        finally:
+            mm.F32_PROLOGUE = mm.F32_TAPS_SPLIT = True
+        outs[(pro, taps)] = z[:, off:].float().reshape(4, 256, -1)
+    ref = outs[(False, False)]
+    scale = ref.abs().max().item()
+    for k, v in outs.items():
+        assert v.shape == ref.shape and (v - ref).abs().max().item() < 2e-5 * scale, (k, (v - ref).abs().max().item(), scale)

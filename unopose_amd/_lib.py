@@ -89,10 +89,13 @@ SIGNATURES = {
     "unopose_linear_bf16_residual": [_P, _P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _P],
     "unopose_linear_bf16_lnfold": [_P, _P, _P, _P, _P, _I, _F, _P, ctypes.c_long, _I, _I, _I, _P],
     "unopose_patchify_bf16": [_P, _I, _P, _I, _I, _I, _P, _P],
+    "unopose_patchify_split": [_P, _I, _P, _I, _I, _I, _P, _P],
     "unopose_vit_tokens_layernorm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P],
+    "unopose_vit_tokens_layernorm_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P],
     "unopose_row_dot": [_P, _I, _P, _F, ctypes.c_long, _I, _P, _I, _P],
     "unopose_normalize_rows_bf16": [_P, _I, ctypes.c_long, _I, _F, _P, _I, _P],
     "unopose_transpose_pad_bf16": [_P, ctypes.c_long, _I, _I, _I, _I, _P, _P],
+    "unopose_transpose_pad_f32": [_P, _L, _I, _I, _I, _I, _P, _P],
     "unopose_cloud_radius": [_P, _I, _I, _P, _P],
     "unopose_scale_by_radius": [_P, _I, _I, _P, _F, _I, _P, _P],
     "unopose_overlap_scores": [_P, _I, _I, _I, _I, _I, _P, _P],

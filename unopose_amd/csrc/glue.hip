@@ -17,12 +17,15 @@ typedef unsigned short u16;
 
 // ---- (B,3,S,S) fp32 x 2 -> (2 B P, Kp) bf16, P = (S/14)^2, column = c * 196 + py * 14 + px, columns >= 588 zero.
 // One workgroup per (crop, patch row gy): the 3 x 14 x S strip is read with coalesced rows and written patch-major.
-__global__ __launch_bounds__(256) void patchify_bf16_kernel(const float *__restrict__ a, int na, const float *__restrict__ b, int S,
-                                                            int Kp, u16 *__restrict__ out) {
+//      SPLIT: the fp32 values in the split layout of csrc/gemm_f32.hip instead (per row and 32-column block one 128-byte line [hi (32 bf16) |
+//      lo (32 bf16)]; Kp % 32 == 0): the patch matrix of the no-autocast forward, no unfold copy / zero fill / split pass.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__ a, int na, const float *__restrict__ b, int S,
+                                                       int Kp, u16 *__restrict__ out) {
   const int g = S / 14;
   const int crop = blockIdx.x / g, gy = blockIdx.x - crop * g;
   const float *src = (crop < na ? a + (size_t)crop * 3 * S * S : b + (size_t)(crop - na) * 3 * S * S);
-  u16 *dst = out + ((size_t)crop * g * g + (size_t)gy * g) * Kp;
+  u16 *dst = out + ((size_t)crop * g * g + (size_t)gy * g) * Kp * (SPLIT ? 2 : 1);
   // element e of the strip: patch gx, column k (k < Kp); consecutive threads take consecutive (gx, k) pairs of the OUTPUT
   // (2-byte coalesced stores); the reads of one patch row segment (14 floats) stay inside a 56-byte window: L1-served
   const int total = g * (Kp / 2);
@@ -39,17 +42,28 @@ __global__ __launch_bounds__(256) void patchify_bf16_kernel(const float *__restr
         v[j] = 0.f;
       }
     }
-    *reinterpret_cast<uint32_t *>(dst + (size_t)gx * Kp + k2) = cvt_pk_bf16_f32(v[0], v[1]);
+    if (SPLIT) {
+      const uint32_t hi = cvt_pk_bf16_f32(v[0], v[1]);
+      const uint32_t lo = cvt_pk_bf16_f32(v[0] - __uint_as_float(hi << 16), v[1] - __uint_as_float(hi & 0xffff0000u));
+      u16 *line = dst + (size_t)gx * Kp * 2 + (size_t)(k2 >> 5) * 64 + (k2 & 31);  // (u16 units: 64 per 128-byte line, hi half first)
+      *reinterpret_cast<uint32_t *>(line) = hi;
+      *reinterpret_cast<uint32_t *>(line + 32) = lo;
+    } else {
+      *reinterpret_cast<uint32_t *>(dst + (size_t)gx * Kp + k2) = cvt_pk_bf16_f32(v[0], v[1]);
+    }
   }
 }
 
 // ---- tokens + first LayerNorm.  One wavefront per token row; C = 768 = 64 lanes x 12 (three float4 per lane).
 // x[r] (fp32, the residual stream) = prefix token (cls, reg0..) for t < npre, else patch[b, t - npre] (bf16) + pos[t - npre];
 // n1[r] (bf16) = LayerNorm(x[r]) * w + bias.
-__global__ __launch_bounds__(256) void vit_tokens_layernorm_kernel(const u16 *__restrict__ patch, const float *__restrict__ pos,
+//      F32 (the no-autocast forward): patch is fp32, n1 comes out in the split layout of csrc/gemm_f32.hip.
+template <bool F32>
+__global__ __launch_bounds__(256) void vit_tokens_layernorm_kernel(const void *__restrict__ patch_, const float *__restrict__ pos,
                                                                    const float *__restrict__ prefix, int npre, int P, long rows,
                                                                    const float *__restrict__ w, const float *__restrict__ bias, float eps,
                                                                    float *__restrict__ x, u16 *__restrict__ n1) {
+  const u16 *patch = reinterpret_cast<const u16 *>(patch_);
   constexpr int C = 768;
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -69,8 +83,13 @@ __global__ __launch_bounds__(256) void vit_tokens_layernorm_kernel(const u16 *__
     const float *ps = pos + (size_t)(t - npre) * C;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const uint2 h = *reinterpret_cast<const uint2 *>(pr + i * 256 + lane * 4);
       const float4 q = *reinterpret_cast<const float4 *>(ps + i * 256 + lane * 4);
+      if (F32) {
+        const float4 f = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(patch_) + ((size_t)bimg * P + (t - npre)) * C + i * 256 + lane * 4);
+        v[4 * i] = f.x + q.x, v[4 * i + 1] = f.y + q.y, v[4 * i + 2] = f.z + q.z, v[4 * i + 3] = f.w + q.w;
+        continue;
+      }
+      const uint2 h = *reinterpret_cast<const uint2 *>(pr + i * 256 + lane * 4);
       v[4 * i] = __uint_as_float(h.x << 16) + q.x;
       v[4 * i + 1] = __uint_as_float(h.x & 0xffff0000u) + q.y;
       v[4 * i + 2] = __uint_as_float(h.y << 16) + q.z;
@@ -92,7 +111,18 @@ __global__ __launch_bounds__(256) void vit_tokens_layernorm_kernel(const u16 *__
     const float4 ww = *reinterpret_cast<const float4 *>(w + c), bb = *reinterpret_cast<const float4 *>(bias + c);
     const float y0 = (v[4 * i] - mean) * rstd * ww.x + bb.x, y1 = (v[4 * i + 1] - mean) * rstd * ww.y + bb.y;
     const float y2 = (v[4 * i + 2] - mean) * rstd * ww.z + bb.z, y3 = (v[4 * i + 3] - mean) * rstd * ww.w + bb.w;
-    *reinterpret_cast<uint2 *>(n1 + (size_t)r * C + c) = make_uint2(cvt_pk_bf16_f32(y0, y1), cvt_pk_bf16_f32(y2, y3));
+    if (F32) {
+      uint2 h, l;
+      h.x = cvt_pk_bf16_f32(y0, y1);
+      h.y = cvt_pk_bf16_f32(y2, y3);
+      l.x = cvt_pk_bf16_f32(y0 - __uint_as_float(h.x << 16), y1 - __uint_as_float(h.x & 0xffff0000u));
+      l.y = cvt_pk_bf16_f32(y2 - __uint_as_float(h.y << 16), y3 - __uint_as_float(h.y & 0xffff0000u));
+      char *line = reinterpret_cast<char *>(n1) + (size_t)r * C * 4 + (size_t)(c >> 5) * 128 + ((c >> 3) & 3) * 16 + ((c >> 2) & 1) * 8;
+      *reinterpret_cast<uint2 *>(line) = h;
+      *reinterpret_cast<uint2 *>(line + 64) = l;
+    } else {
+      *reinterpret_cast<uint2 *>(n1 + (size_t)r * C + c) = make_uint2(cvt_pk_bf16_f32(y0, y1), cvt_pk_bf16_f32(y2, y3));
+    }
   }
 }
 
@@ -158,6 +188,23 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const u16 *__restric
   for (int i = threadIdx.x; i < 64 * (pad / 2); i += 256) {
     const int c = i / (pad / 2), j2 = (i - c * (pad / 2)) * 2;
     *reinterpret_cast<uint32_t *>(dst + (size_t)c * pad + j2) = (uint32_t)tile[c * tp + j2] | ((uint32_t)tile[c * tp + j2 + 1] << 16);
+  }
+}
+
+// the same for fp32 data (the value image of csrc/attn_f32.hip; 32 channels per workgroup)
+__global__ __launch_bounds__(256) void transpose_pad_f32_kernel(const float *__restrict__ v, long ld, int m, int C, int pad, float *__restrict__ vt) {
+  extern __shared__ float tile_f[];  // [32][pad + 1]
+  const int b = blockIdx.y, c0 = blockIdx.x * 32, tp = pad + 1;
+  const float *src = v + (size_t)b * m * ld + c0;
+  for (int i = threadIdx.x; i < 32 * pad; i += 256) {
+    const int j = i >> 5, c = i & 31;
+    tile_f[c * tp + j] = j < m ? src[(size_t)j * ld + c] : 0.f;
+  }
+  __syncthreads();
+  float *dst = vt + ((size_t)b * C + c0) * pad;
+  for (int i = threadIdx.x; i < 32 * pad; i += 256) {
+    const int c = i / pad, j = i - c * pad;
+    dst[(size_t)c * pad + j] = tile_f[c * tp + j];
   }
 }
 
@@ -394,8 +441,15 @@ int unopose_gather_rows(const void *feats, int B, int N, int row_bytes, const vo
 int unopose_patchify_bf16(const float *rgb_a, int na, const float *rgb_b, int nb, int S, int Kp, void *out, unopose_stream_t stream) {
   UNOPOSE_REQUIRE(rgb_a && out && (rgb_b || nb == 0), "patchify_bf16: null pointer");
   UNOPOSE_REQUIRE(na >= 1 && nb >= 0 && S >= 14 && S % 14 == 0 && Kp >= 588 && Kp % 2 == 0, "patchify_bf16: needs S %% 14 == 0 and an even Kp >= 588 (got S=%d Kp=%d)", S, Kp);
-  hipLaunchKernelGGL(patchify_bf16_kernel, dim3((na + nb) * (S / 14)), dim3(256), 0, (hipStream_t)stream, rgb_a, na, rgb_b, S, Kp, (u16 *)out);
+  hipLaunchKernelGGL(patchify_kernel<false>, dim3((na + nb) * (S / 14)), dim3(256), 0, (hipStream_t)stream, rgb_a, na, rgb_b, S, Kp, (u16 *)out);
   return check_launch("patchify_bf16");
+}
+
+int unopose_patchify_split(const float *rgb_a, int na, const float *rgb_b, int nb, int S, int Kp, void *out, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(rgb_a && out && (rgb_b || nb == 0), "patchify_split: null pointer");
+  UNOPOSE_REQUIRE(na >= 1 && nb >= 0 && S >= 14 && S % 14 == 0 && Kp >= 588 && Kp % 32 == 0, "patchify_split: needs S %% 14 == 0 and Kp >= 588, a multiple of 32 (got S=%d Kp=%d)", S, Kp);
+  hipLaunchKernelGGL(patchify_kernel<true>, dim3((na + nb) * (S / 14)), dim3(256), 0, (hipStream_t)stream, rgb_a, na, rgb_b, S, Kp, (u16 *)out);
+  return check_launch("patchify_split");
 }
 
 int unopose_vit_tokens_layernorm(const void *patch, const float *pos, const float *prefix, int npre, int P, int nimg, int C,
@@ -403,9 +457,19 @@ int unopose_vit_tokens_layernorm(const void *patch, const float *pos, const floa
   UNOPOSE_REQUIRE(patch && pos && prefix && ln_w && ln_b && x && n1, "vit_tokens_layernorm: null pointer");
   UNOPOSE_REQUIRE(C == 768 && npre >= 0 && P >= 1 && nimg >= 1, "vit_tokens_layernorm: built for C = 768 (got %d)", C);
   const long rows = (long)nimg * (npre + P);
-  hipLaunchKernelGGL(vit_tokens_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const u16 *)patch, pos,
+  hipLaunchKernelGGL(vit_tokens_layernorm_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, patch, pos,
                      prefix, npre, P, rows, ln_w, ln_b, eps, x, (u16 *)n1);
   return check_launch("vit_tokens_layernorm");
+}
+
+int unopose_vit_tokens_layernorm_f32(const float *patch, const float *pos, const float *prefix, int npre, int P, int nimg, int C,
+                                     const float *ln_w, const float *ln_b, float eps, float *x, void *n1_split, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(patch && pos && prefix && ln_w && ln_b && x && n1_split, "vit_tokens_layernorm_f32: null pointer");
+  UNOPOSE_REQUIRE(C == 768 && npre >= 0 && P >= 1 && nimg >= 1, "vit_tokens_layernorm_f32: built for C = 768 (got %d)", C);
+  const long rows = (long)nimg * (npre + P);
+  hipLaunchKernelGGL(vit_tokens_layernorm_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const void *)patch, pos,
+                     prefix, npre, P, rows, ln_w, ln_b, eps, x, (u16 *)n1_split);
+  return check_launch("vit_tokens_layernorm_f32");
 }
 
 int unopose_row_dot(const void *x, int x_bf16, const float *w, float b, long rows, int C, void *out, int out_bf16, unopose_stream_t stream) {
@@ -438,6 +502,13 @@ int unopose_transpose_pad_bf16(const void *v, long ld, int B, int m, int C, int 
   hipLaunchKernelGGL(transpose_pad_kernel, dim3(C / 64, B), dim3(256), (size_t)64 * (pad + 2) * 2, (hipStream_t)stream, (const u16 *)v, ld, m, C,
                      pad, (u16 *)vt);
   return check_launch("transpose_pad_bf16");
+}
+
+int unopose_transpose_pad_f32(const float *v, long ld, int B, int m, int C, int pad, float *vt, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(v && vt, "transpose_pad_f32: null pointer");
+  UNOPOSE_REQUIRE(B >= 1 && B <= 65535 && m >= 1 && m <= pad && pad <= 1024 && C % 32 == 0 && ld >= C, "transpose_pad_f32: bad shape (m=%d pad=%d C=%d)", m, pad, C);
+  hipLaunchKernelGGL(transpose_pad_f32_kernel, dim3(C / 32, B), dim3(256), (size_t)32 * (pad + 1) * 4, (hipStream_t)stream, v, ld, m, C, pad, vt);
+  return check_launch("transpose_pad_f32");
 }
 
 int unopose_cloud_radius(const float *pts, int B, int N, float *radius, unopose_stream_t stream) {

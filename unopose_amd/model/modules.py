@@ -119,6 +119,7 @@ class _PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(3, dim, patch, patch)
 
 
+F32_PROLOGUE = True  # (module attribute for A/Bs) the no-autocast ViT's patch unfolding / token assembly / first LayerNorm on the fused fp32 kernels; False: the op-by-op front end
 F32_TAPS_SPLIT = True  # (module attribute for A/Bs) the no-autocast ViT's tap LayerNorms written side by side in the split layout; False: torch LayerNorm + cat + split pass
 
 
@@ -155,6 +156,9 @@ class ViT(nn.Module):
         if ops.vit_prologue_ok(xa, self) and (xb is None or xb.shape[1:] == xa.shape[1:]):
             x, n1 = ops.vit_prologue(xa, xb, self, self.blocks[0].norm1)
             return self._fused_blocks(x, n1, taps_side_by_side)
+        if F32_PROLOGUE and ops.vit_prologue_f32_ok(xa, self) and (xb is None or xb.shape[1:] == xa.shape[1:]):
+            x, ns = ops.vit_prologue_f32(xa, xb, self, self.blocks[0].norm1)  # (round 6: the fp32 twin of the fused prologue)
+            return self._fused_blocks_f32(x, ns, taps_side_by_side)
         x = xa if xb is None else torch.cat([xa, xb], 0)
         B = x.shape[0]
         p = self.patch_size
@@ -174,25 +178,32 @@ class ViT(nn.Module):
             return self._fused_blocks(x, ops.add_layernorm(x, None, self.blocks[0].norm1, torch.bfloat16), taps_side_by_side)
         if ops.vit_f32_fused_ok(x, self):
             x = x.contiguous()
-            ns = ops.scale_residual_layernorm_f32_(x, None, None, self.blocks[0].norm1)
-            # taps side by side (round 6): the four tap LayerNorms go straight into the column blocks of ONE split-layout matrix, the K = 4 D operand
-            # of the up-projection -- no torch LayerNorm, no 1 GB concatenation, no split pass (4.3 GB of traffic per forward at B = 32, 518 x 518)
-            wide = torch.empty(x.shape[0] * x.shape[1], 2 * 4 * x.shape[2], dtype=torch.bfloat16, device=x.device) if taps_side_by_side and F32_TAPS_SPLIT else None
-            for i, blk in enumerate(self.blocks):
-                x, ns = blk.forward_fused_f32(x, ns, self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None)
-                if i in taps:
-                    if wide is not None:
-                        ops.scale_residual_layernorm_f32_(x, None, None, self.norm, wide=wide, block=len(outs))
-                        outs.append(None)
-                    else:
-                        outs.append(self.norm(x))
-            return SplitTaps(wide, x.shape[0], x.shape[1], 4 * x.shape[2]) if wide is not None else outs
+            return self._fused_blocks_f32(x, ops.scale_residual_layernorm_f32_(x, None, None, self.blocks[0].norm1), taps_side_by_side)
         for i, blk in enumerate(self.blocks):
             x = blk(x)
             if i in taps:
                 outs.append(ops.add_layernorm(x, None, self.norm)
                             if x.is_cuda and torch.is_autocast_enabled() and not ops.is_differentiable() else self.norm(x))
         return outs
+
+    def _fused_blocks_f32(self, x, ns, taps_side_by_side):
+        """The blocks of the no-autocast forward on the fp32-class GEMMs: x (B,T,D) fp32 residual stream (updated in place), ns = norm1(x) of
+        block 0 in the split layout."""
+        n = self.depth // 4
+        taps = {self.depth - 1, self.depth - n - 1, self.depth - 2 * n - 1, self.depth - 3 * n - 1}
+        outs = []
+        # taps side by side (round 6): the four tap LayerNorms go straight into the column blocks of ONE split-layout matrix, the K = 4 D operand
+        # of the up-projection -- no torch LayerNorm, no 1 GB concatenation, no split pass (4.3 GB of traffic per forward at B = 32, 518 x 518)
+        wide = torch.empty(x.shape[0] * x.shape[1], 2 * 4 * x.shape[2], dtype=torch.bfloat16, device=x.device) if taps_side_by_side and F32_TAPS_SPLIT else None
+        for i, blk in enumerate(self.blocks):
+            x, ns = blk.forward_fused_f32(x, ns, self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None)
+            if i in taps:
+                if wide is not None:
+                    ops.scale_residual_layernorm_f32_(x, None, None, self.norm, wide=wide, block=len(outs))
+                    outs.append(None)
+                else:
+                    outs.append(self.norm(x))
+        return SplitTaps(wide, x.shape[0], x.shape[1], 4 * x.shape[2]) if wide is not None else outs
 
 
 def _vit_fused_blocks(self, x, n1, taps_side_by_side):

@@ -19,7 +19,7 @@ from .common import (  # noqa: F401
 from .dense import (  # noqa: F401
     linear_backend, _bf16_weights, linear_bf16_hip, own_gemm_ok, bf16_linear_2d, f32x3_ok, split_f32, _f32x3_weights, linear_f32x3,
     linear_f32x3_bf16, linear_f32_raw, _transposed_weights, _LinearFn, _ZERO_BIAS, _zero_bias, linear_train, _lin, mlp, linear,
-    ffn_add_layernorm, linear_add_layernorm, patch_embed, vit_prologue_ok, vit_prologue, bmm_nt_f32, score_head, add_layernorm,
+    ffn_add_layernorm, linear_add_layernorm, patch_embed, vit_prologue_ok, vit_prologue, vit_prologue_f32_ok, vit_prologue_f32, bmm_nt_f32, score_head, add_layernorm,
     scale_residual_, scale_residual_layernorm_f32_, vit_f32_fused_ok, scale_residual_layernorm_, ln_fold_ok, _fold_producer_weights,
     _fold_consumer_weights, linear_residual_, linear_lnfold, _into,
 )

@@ -115,8 +115,13 @@ def _token_attention_hip_f32(x, mem, att, embed):
     _, w_q, b_q, w_kv, b_kv = cache
     yq = linear_f32_raw(x, w_q, b_q, att, "q")
     ykv = linear_f32_raw(mem, w_kv, b_kv, att, "kv")
-    vt = torch.zeros(B, C, _KEY_PAD, dtype=torch.float32, device=x.device)
-    vt[:, :, :m] = ykv[..., C:].transpose(1, 2)
+    if ykv.is_contiguous() and C % 32 == 0 and m <= _KEY_PAD:  # V^T, zero-padded to the kernel's key count: one launch (csrc/glue.hip)
+        vt = torch.empty(B, C, _KEY_PAD, dtype=torch.float32, device=x.device)
+        with on_device(x.device):
+            call("unopose_transpose_pad_f32", ctypes.c_void_p(ykv.data_ptr() + C * 4), ykv.stride(1), B, m, C, _KEY_PAD, ptr(vt), stream_ptr())
+    else:
+        vt = torch.zeros(B, C, _KEY_PAD, dtype=torch.float32, device=x.device)
+        vt[:, :, :m] = ykv[..., C:].transpose(1, 2)
     E = _c(embed.float()) if rpe else None
     out = torch.empty(B, n, C, dtype=torch.float32, device=x.device)
     qptr, kptr = yq.data_ptr(), ykv.data_ptr()

@@ -314,6 +314,8 @@ def ffn_add_layernorm(x, expand, squeeze, norm, out=None):
         c1, c2 = _f32x3_weights(expand), _f32x3_weights(squeeze)
         hs = linear_f32x3(split_f32(_c(x).reshape(rows, K1)), c1[1], c1[2], rows, N1, K1, relu=True, out="split")
         y = linear_f32x3(hs, c2[1], c2[2], rows, N2, K2).reshape(*x.shape[:-1], N2)
+        if out is not None and out.dtype == x.dtype and out.shape == x.shape and out.stride(-1) == 1 and out.is_contiguous():
+            return add_layernorm(y, x, norm, out=out)  # the LayerNorm kernel writes the caller's destination itself
         return _into(out, add_layernorm(y, x, norm))
     return linear_add_layernorm(linear(x, expand, relu=True), squeeze, x, norm, out=out)
 
@@ -349,6 +351,11 @@ def linear_add_layernorm(h, lin, x, norm, out=None):
                 call("unopose_linear_add_layernorm_bf16", ptr(hb), ptr(cache[1]), ptr(cache[3]), ptr(xb), ptr(norm.weight.detach()),
                      ptr(norm.bias.detach()), float(norm.eps), ptr(y), rows, K, stream_ptr())
         return out if direct else _into(out, y.reshape(*h.shape[:-1], N))
+    if out is not None and h.is_cuda and not st._DIFF and out.shape == x.shape and out.is_contiguous() and out.dtype in (torch.float32, torch.bfloat16):
+        y = linear(h, lin)
+        if y.dtype in (torch.float32, torch.bfloat16) and (out.dtype == (torch.bfloat16 if torch.is_autocast_enabled() else y.dtype)):
+            return add_layernorm(y, x, norm, out=out)
+        return _into(out, add_layernorm(y, x, norm))
     return _into(out, add_layernorm(linear(h, lin), x, norm))
 
 
@@ -431,6 +438,53 @@ def vit_prologue(xa, xb, vit, norm1):
         n1 = torch.empty(na + nb, npre + P, D, dtype=torch.bfloat16, device=dev)
         call("unopose_vit_tokens_layernorm", ptr(y), ptr(vit.pos_embed.detach().float().contiguous()), ptr(prefix), npre, P, na + nb, D,
              ptr(norm1.weight.detach()), ptr(norm1.bias.detach()), float(norm1.eps), ptr(x), ptr(n1), stream_ptr())
+    return x, n1
+
+
+def vit_prologue_f32_ok(xa, vit):
+    """The fused prologue of the no-autocast ViT (fp32-class GEMM on split operands), for ViT-B (768 wide)."""
+    if not (not st._DIFF and _no_autograd() and xa.is_cuda and not torch.is_autocast_enabled() and st.USE_F32X3 and xa.dtype == torch.float32
+            and vit.pos_embed.shape[-1] == 768 and xa.shape[-1] == xa.shape[-2] and xa.shape[-1] % 14 == 0
+            and vit.pos_embed.shape[1] == (xa.shape[-1] // 14) ** 2):
+        return False
+    rows = 2 * xa.shape[0] * (vit.pos_embed.shape[1] + 5)
+    return f32x3_ok(rows, 768, 608) and f32x3_ok(rows, 3 * 768, 768) and f32x3_ok(rows, 768, 4 * 768)
+
+
+def vit_prologue_f32(xa, xb, vit, norm1):
+    """`vit_prologue` at the reference's default precision: (x fp32 (n,T,768) residual stream, norm1(x) in the split layout of
+    csrc/gemm_f32.hip).  Patches straight into the split-layout patch matrix (K = 588 zero-padded to 608), the patch embedding on the
+    fp32-class GEMM, pos_embed / class + register tokens / first LayerNorm in one pass.  Replaces cat([rgb, tem_rgb]) + unfold copy + zeros +
+    copy + split pass + add + cat + LayerNorm (1.4 GB written per forward at 64 x 518 x 518)."""
+    conv = vit.patch_embed.proj
+    w = conv.weight.reshape(conv.weight.shape[0], -1)
+    D, K = w.shape
+    Kp = (K + 31) // 32 * 32
+    key = _params_key(conv, Kp, "f32", vit.cls_token._version, vit.reg_token._version, vit.pos_embed._version)
+    cache = getattr(conv, "_prologue_cache_f32", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            wp = torch.zeros(D, Kp, dtype=torch.float32, device=w.device)
+            wp[:, :K] = w.detach()
+            b = torch.zeros(D, device=w.device) if conv.bias is None else conv.bias.detach().float().contiguous()
+            prefix = torch.cat([vit.cls_token.detach().float().reshape(-1, D), vit.reg_token.detach().float().reshape(-1, D)], 0).contiguous()
+            cache = (key, split_f32(wp), b, prefix, vit.pos_embed.detach().float().contiguous())
+        conv._prologue_cache_f32 = cache
+    _, ws, b, prefix, pos = cache
+    na, nb = xa.shape[0], 0 if xb is None else xb.shape[0]
+    S = xa.shape[-1]
+    P = (S // 14) ** 2
+    npre = prefix.shape[0]
+    dev = xa.device
+    note_mutation()
+    with on_device(dev):
+        a = torch.empty((na + nb) * P, 2 * Kp, dtype=torch.bfloat16, device=dev)
+        call("unopose_patchify_split", ptr(_c(xa)), na, None if xb is None else ptr(_c(xb)), nb, S, Kp, ptr(a), stream_ptr())
+        y = linear_f32x3(a, ws, b, (na + nb) * P, D, Kp)
+        x = torch.empty(na + nb, npre + P, D, dtype=torch.float32, device=dev)
+        n1 = torch.empty((na + nb) * (npre + P), 2 * D, dtype=torch.bfloat16, device=dev)
+        call("unopose_vit_tokens_layernorm_f32", ptr(y), ptr(pos), ptr(prefix), npre, P, na + nb, D, ptr(norm1.weight.detach()),
+             ptr(norm1.bias.detach()), float(norm1.eps), ptr(x), ptr(n1), stream_ptr())
     return x, n1
 
 
