@@ -506,8 +506,9 @@ int unopose_vit_tokens_layernorm_f32(const float *patch, const float *pos, const
 int unopose_row_dot(const void *x, int x_bf16, const float *w, float b, long rows, int C, void *out, int out_bf16,
                     unopose_stream_t stream);
 /* out[r,:] = bf16( x[r,:] / max(||x[r,:]||_2, 1e-12) / temp ) for 256-wide rows: the operands of compute_feature_similarity
- * (core/unopose/utils/model_utils.py:260-282) as the fine assignment reads them; with out_f32 the same bf16-rounded values stored as
- * float32 (the operand type of unopose_bmm_f32, which forms the coarse similarity from them). */
+ * (core/unopose/utils/model_utils.py:260-282) as the fine assignment reads them; out_f32 = 1: the same bf16-rounded values stored as
+ * float32 (the operand type of unopose_bmm_f32, which forms the coarse similarity from them); out_f32 = 2: the unrounded float32 values
+ * (F.normalize at the reference's default precision). */
 int unopose_normalize_rows_bf16(const void *x, int x_bf16, long rows, int C, float temp, void *out, int out_f32,
                                 unopose_stream_t stream);
 /* vt (B, C, pad) bf16: vt[b,c,j] = v[b,j,c] (rows of v `ld` elements apart), zero for m <= j < pad: the value image of

@@ -80,6 +80,9 @@ def test_row_dot_normalize_transpose_pad():
         assert n.dtype == torch.bfloat16 and ((n.float() - ref).abs() <= ref.abs() * 2.0 ** -8 + 1e-6).all()
         n32 = ops.normalize_rows_bf16(x, 0.1, as_f32=True)  # the same bf16-rounded values, stored as fp32 (bmm_nt_f32's operand type)
         assert n32.dtype == torch.float32 and torch.equal(n32, n.float())
+    nf = ops.normalize_rows_f32(f)  # unrounded (the fp32 forward's F.normalize)
+    want = F.normalize(f, p=2, dim=2)
+    assert nf.dtype == torch.float32 and (nf - want).abs().max().item() < 2e-7
     assert torch.equal(ops.normalize_rows_bf16(torch.zeros(2, 3, 256, device="cuda"), 0.1), torch.zeros(2, 3, 256, device="cuda", dtype=torch.bfloat16))
     y = torch.randn(5, 197, 768, generator=g).cuda().bfloat16()  # q | k | v side by side, v = the last 256 columns
     vt = torch.full((5, 256, 256), 7.0, device="cuda", dtype=torch.bfloat16)

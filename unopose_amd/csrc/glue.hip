@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const void *__restrict__ x
 // ---- out[r, :] = bf16( x[r, :] / max(||x[r, :]||, 1e-12) / temp )   (F.normalize(f, p=2, dim=-1) / temp of
 //      compute_feature_similarity, model_utils.py:260-282), 256-wide rows, one wavefront per row
 //      OUT_F32: the same bf16-rounded values stored as fp32 (the operand type of csrc/bmm_f32.hip: no cast launch in between)
-template <bool X_BF16, bool OUT_F32>
+//      OUT_F32 == 2: the unrounded fp32 values (F.normalize(x) / temp at the reference's default precision)
+template <bool X_BF16, int OUT_F32>
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const void *__restrict__ x, long rows, float temp, void *__restrict__ outv) {
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -165,6 +166,10 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const void *__restr
   }
   const float nrm = fmaxf(sqrtf(wave_sum_f32((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w))), 1e-12f);
   const float y0 = v.x / nrm / temp, y1 = v.y / nrm / temp, y2 = v.z / nrm / temp, y3 = v.w / nrm / temp;
+  if (OUT_F32 == 2) {
+    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(outv) + (size_t)r * 256 + lane * 4) = make_float4(y0, y1, y2, y3);
+    return;
+  }
   const uint2 pk = make_uint2(cvt_pk_bf16_f32(y0, y1), cvt_pk_bf16_f32(y2, y3));
   if (OUT_F32)
     *reinterpret_cast<float4 *>(reinterpret_cast<float *>(outv) + (size_t)r * 256 + lane * 4) =
@@ -489,10 +494,13 @@ int unopose_normalize_rows_bf16(const void *x, int x_bf16, long rows, int C, flo
   UNOPOSE_REQUIRE(C == 256 && rows >= 1 && temp > 0.f, "normalize_rows_bf16: built for C = 256 (got %d)", C);
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (x_bf16 && out_f32) hipLaunchKernelGGL((normalize_rows_kernel<true, true>), grid, block, 0, s, x, rows, temp, out);
-  else if (x_bf16) hipLaunchKernelGGL((normalize_rows_kernel<true, false>), grid, block, 0, s, x, rows, temp, out);
-  else if (out_f32) hipLaunchKernelGGL((normalize_rows_kernel<false, true>), grid, block, 0, s, x, rows, temp, out);
-  else hipLaunchKernelGGL((normalize_rows_kernel<false, false>), grid, block, 0, s, x, rows, temp, out);
+  UNOPOSE_REQUIRE(out_f32 >= 0 && out_f32 <= 2, "normalize_rows_bf16: out_f32 is 0 (bf16), 1 (bf16-rounded values as float32) or 2 (unrounded float32)");
+  if (out_f32 == 2 && x_bf16) hipLaunchKernelGGL((normalize_rows_kernel<true, 2>), grid, block, 0, s, x, rows, temp, out);
+  else if (out_f32 == 2) hipLaunchKernelGGL((normalize_rows_kernel<false, 2>), grid, block, 0, s, x, rows, temp, out);
+  else if (x_bf16 && out_f32) hipLaunchKernelGGL((normalize_rows_kernel<true, 1>), grid, block, 0, s, x, rows, temp, out);
+  else if (x_bf16) hipLaunchKernelGGL((normalize_rows_kernel<true, 0>), grid, block, 0, s, x, rows, temp, out);
+  else if (out_f32) hipLaunchKernelGGL((normalize_rows_kernel<false, 1>), grid, block, 0, s, x, rows, temp, out);
+  else hipLaunchKernelGGL((normalize_rows_kernel<false, 0>), grid, block, 0, s, x, rows, temp, out);
   return check_launch("normalize_rows_bf16");
 }
 

@@ -38,7 +38,7 @@ from .sampling import (  # noqa: F401
 )
 from .pose import (  # noqa: F401
     overlap_scores, set_first_rows_, pose_score, rigid_rows, feature_similarity, soft_assignment, coarse_pose_torch, fine_pose_torch, _assign_labels,
-    coarse_pose, fine_pose, fine_pose_fused_ok, normalize_rows_bf16, fine_pose_from_features,
+    coarse_pose, fine_pose, fine_pose_fused_ok, normalize_rows_bf16, normalize_rows_f32, fine_pose_from_features,
 )
 from .train import (  # noqa: F401
     _InfoNCEFn, infonce_two_way, _BNReLUTrain, bn_relu, _BNReLUMaxPoolTrain, bn_relu_maxpool, _SaliencyFn, saliency_pair,

@@ -90,6 +90,10 @@ def feature_similarity(f1, f2, temp):
         # kernel (exact products, fp32 sums -- what the bf16 bmm with fp32 output computes up to summation order)
         with torch.autocast("cuda", enabled=False):
             return bmm_nt_f32(normalize_rows_bf16(f1, temp, as_f32=True), normalize_rows_bf16(f2, 1.0, as_f32=True))
+    if (_own_f32(f1) and not torch.is_autocast_enabled() and f1.dtype == torch.float32 and f2.dtype == torch.float32 and f1.shape[-1] == 256
+            and f2.shape[-1] == 256):
+        # fp32: both normalisations in one pass each (csrc/glue.hip, unrounded), 1 / temp in the product's epilogue
+        return bmm_nt_f32(normalize_rows_f32(f1), normalize_rows_f32(f2), alpha=1.0 / temp)
     a, b = F.normalize(f1.float(), p=2, dim=2), F.normalize(f2.float(), p=2, dim=2)
     if f1.is_cuda and torch.is_autocast_enabled() and not st.HIP_GEMM_ALL:
         with torch.autocast("cuda", enabled=False):
@@ -256,6 +260,15 @@ def normalize_rows_bf16(f, temp, as_f32=False):
     with on_device(f.device):
         call("unopose_normalize_rows_bf16", ptr(fc), int(f.dtype == torch.bfloat16), fc.numel() // 256, 256, float(temp), ptr(out), int(as_f32),
              stream_ptr())
+    return out
+
+
+def normalize_rows_f32(f):
+    """F.normalize(f, p=2, dim=-1) for fp32 f (...,256) in one pass (csrc/glue.hip, no rounding)."""
+    fc = _c(f)
+    out = torch.empty_like(fc)
+    with on_device(f.device):
+        call("unopose_normalize_rows_bf16", ptr(fc), 0, fc.numel() // 256, 256, 1.0, ptr(out), 2, stream_ptr())
     return out
 
 
