@@ -119,6 +119,7 @@ class _PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(3, dim, patch, patch)
 
 
+SPARSE_SINGLE_CROP = True  # (module attribute for A/Bs) ViT_AE.pixel_features of one crop batch through the sparse up-projection; False: dense GEMM + fp32 features
 F32_PROLOGUE = True  # (module attribute for A/Bs) the no-autocast ViT's patch unfolding / token assembly / first LayerNorm on the fused fp32 kernels; False: the op-by-op front end
 F32_TAPS_SPLIT = True  # (module attribute for A/Bs) the no-autocast ViT's tap LayerNorms written side by side in the split layout; False: torch LayerNorm + cat + split pass
 
@@ -313,6 +314,17 @@ class ViT_AE(nn.Module):
 
     def pixel_features(self, x, choose):
         if x.is_cuda and self.out_dim == 256 and not ops.is_differentiable():
+            if SPARSE_SINGLE_CROP and ops.sparse_upproj_ok(x) and x.shape[-1] == x.shape[-2] and x.shape[-1] % 14 == 0:
+                # one crop batch alone (a cached reference on the other side, or the reference being encoded): the sparse up-projection
+                # as in the two-crop forward -- only the cells the chosen pixels read, bf16 features (round 6; was the dense 3072 -> 4096 GEMM)
+                sd = x.shape[-1] // 14
+                npre = self.vit.cls_token.shape[1] + self.vit.reg_token.shape[1]
+                plan = ops.upproj_plan(choose, x.shape[-2], x.shape[-1], sd, npre, npre + sd * sd)
+                acts = self.vit(x, taps_side_by_side=True)
+                if torch.is_tensor(acts) and acts.shape[1] == plan["tok_stride"]:
+                    return ops.sparse_pixel_features(acts, self.output_upscaling, plan)
+                z, (H, W), off = self.upproject(acts, x.shape[-2], x.shape[-1])
+                return ops.bilinear_sample_native(z, choose, H, W, tok_offset=off)
             z, (H, W), off = self.upprojected_tokens(x)
             return ops.bilinear_sample_native(z, choose, H, W, tok_offset=off)
         low, (H, W) = self.lowres_map(x)

@@ -373,8 +373,7 @@ class UNOPose(nn.Module):
         idx_o = ops.furthest_point_sample(tem_n, self.fine_npoint)
         sel_choose = torch.gather(tem1_choose, 1, idx_o.long())
         net = self.feature_extraction.rgb_net
-        z, (H, W), off = net.upprojected_tokens(tem1_rgb)
-        return dict(ref_dense_po=ops.gather_rows(tem_n, idx_o), ref_dense_fo=ops.bilinear_sample_native(z, sel_choose, H, W, tok_offset=off),
+        return dict(ref_dense_po=ops.gather_rows(tem_n, idx_o), ref_dense_fo=net.pixel_features(tem1_rgb, sel_choose),
                     ref_radius=radius, ref_lrf=ops.lrf_global(tem1_pts, self.use_ref_rad))
 
     def _side_stream(self, device):
