@@ -540,6 +540,11 @@ int unopose_transpose_pad_f32(const float *v, long ld, int B, int m, int C, int 
 int unopose_cloud_radius(const float *pts, int B, int N, float *radius, unopose_stream_t stream);
 int unopose_scale_by_radius(const float *x, int B, int n, const float *radius, float eps, int multiply, float *out, unopose_stream_t stream);
 int unopose_overlap_scores(const void *scores, int x_bf16, int B, int n_tot, int n1, int halves, float *out, unopose_stream_t stream);
+/* The gradient hygiene of the training loop (core/unopose/engine/engine_utils.py:14-18: torch.nan_to_num(p.grad, nan=0, posinf=1e5, neginf=-1e5) for every
+ * parameter) over ALL gradients in one launch: ptrs_dev / sizes_dev are DEVICE arrays of n_tensors float32 pointers / int64 element counts, max_size the
+ * largest count.  In place; finite values are not rewritten. */
+int unopose_nan_to_num_multi(const void *ptrs_dev, const void *sizes_dev, int n_tensors, long max_size, float nan_value, float posinf_value,
+                             float neginf_value, unopose_stream_t stream);
 int unopose_copy_rows(const void *src, long src_stride_bytes, void *dst, long dst_stride_bytes, int rows, int row_bytes,
                       unopose_stream_t stream);
 int unopose_rigid_rows_bf16(const float *p, int B, int N, const float *t, const float *R, void *out, unopose_stream_t stream);

@@ -452,3 +452,37 @@ def test_geo_embedding_under_autograd_matches_the_composite_in_float64(B, n, red
         err = (got[k].double() - p.grad).abs().max().item()
         fro = ((got[k].double() - p.grad).norm() / p.grad.norm()).item()
         assert err < 1e-2 * scale + 1e-6 and fro < 3e-3, (k, err, scale, fro)
+
+
+def test_zero_nonfinite_grads_one_launch_equals_per_parameter_nan_to_num():
+    """train.zero_nonfinite_grads_ on the GPU (unopose_nan_to_num_multi: one launch over a device table of gradient pointers) against torch.nan_to_num
+    per parameter (engine_utils.py:14-18): NaN -> 0, +inf -> 1e5, -inf -> -1e5, everything else untouched; odd sizes, an empty and a strided gradient."""
+    from unopose_amd import train
+
+    g = torch.Generator().manual_seed(3)
+    shapes = [(257, 33), (1,), (4096, 257), (0,), (7, 5, 3), (100000,)]
+    m = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(s)) for s in shapes]).cuda()
+    want = []
+    for p in m:
+        gr = torch.randn(p.shape, generator=g).cuda()
+        if gr.numel():
+            flat = gr.view(-1)
+            idx = torch.randint(0, flat.numel(), (max(1, flat.numel() // 50),), generator=g).cuda()
+            flat[idx[0::3]] = float("nan")
+            flat[idx[1::3]] = float("inf")
+            flat[idx[2::3]] = -float("inf")
+        p.grad = gr.clone()
+        want.append(torch.nan_to_num(gr, nan=0.0, posinf=1e5, neginf=-1e5))
+    strided = torch.nn.Parameter(torch.zeros(6, 4, device="cuda"))
+    base = torch.full((6, 8), float("nan"), device="cuda")
+    strided.grad = base[:, ::2]  # not contiguous: the torch path
+    mod = torch.nn.Module()
+    mod.ps, mod.extra = m, torch.nn.ParameterList([strided])
+    train.zero_nonfinite_grads_(mod)
+    for p, w in zip(m, want):
+        assert torch.equal(p.grad, w)
+    assert bool((strided.grad == 0).all())
+    for _ in range(6):  # the staging ring comes round: still right
+        m[0].grad = torch.full((257, 33), float("inf"), device="cuda")
+        train.zero_nonfinite_grads_(mod)
+        assert bool((m[0].grad == 1e5).all())

@@ -100,6 +100,7 @@ SIGNATURES = {
     "unopose_scale_by_radius": [_P, _I, _I, _P, _F, _I, _P, _P],
     "unopose_overlap_scores": [_P, _I, _I, _I, _I, _I, _P, _P],
     "unopose_copy_rows": [_P, _L, _P, _L, _I, _I, _P],
+    "unopose_nan_to_num_multi": [_P, _P, _I, _L, _F, _F, _F, _P],
     "unopose_rigid_rows_bf16": [_P, _I, _I, _P, _P, _P, _P],
     "unopose_token_sum_bf16": [_P, _I, _I, _I, _P, _P],
     "unopose_pose_score": [_P, _P, _I, _I, _F, _P, _P],

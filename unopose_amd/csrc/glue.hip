@@ -357,6 +357,20 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const uint32_t *__restri
   for (int w = blockIdx.x * 256 + threadIdx.x; w < words; w += gridDim.x * 256) dst[r * dst_words + w] = src[r * src_words + w];
 }
 
+// ---- nan_to_num over a LIST of fp32 tensors in one launch (engine_utils.py:14-18 walks the parameters one torch.nan_to_num at a time: 303 launches per
+//      training step here): tensor t = ptrs[t][0 .. sizes[t]), blockIdx.y = t, grid-stride over its elements; only non-finite values are written back.
+__global__ __launch_bounds__(256) void nan_to_num_multi_kernel(float *const *__restrict__ ptrs, const long long *__restrict__ sizes, float nan_v, float pos_v,
+                                                               float neg_v) {
+  float *p = ptrs[blockIdx.y];
+  const long long n = sizes[blockIdx.y];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = p[i];
+    if (v != v) p[i] = nan_v;
+    else if (v == __builtin_huge_valf()) p[i] = pos_v;
+    else if (v == -__builtin_huge_valf()) p[i] = neg_v;
+  }
+}
+
 // overlap scores: out[b][j] = clamp(sigmoid(scores[b][1 + j]), 0, 1) for j < n1, scores[b][n1 + 2 + (j - n1)] for the second cloud
 // (oneref_predator_coarse_point_matching.py:68-76: the background tokens at 0 and n1 + 1 are dropped)
 //   `halves`: the score head ran over the two clouds as ONE batch of 2B (cloud 2 of pair b is batch B + b): scores is (2B, n1 + 1) then (n2 = n1)
@@ -571,6 +585,17 @@ int unopose_token_sum_bf16(const void *x, int B, int J, int C, float *out, unopo
   if (B == 0) return UNOPOSE_OK;
   hipLaunchKernelGGL(token_sum_bf16_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, (hipStream_t)stream, (const u16 *)x, J, C, out);
   return check_launch("token_sum_bf16");
+}
+
+int unopose_nan_to_num_multi(const void *ptrs_dev, const void *sizes_dev, int n_tensors, long max_size, float nan_value, float posinf_value,
+                             float neginf_value, unopose_stream_t stream) {
+  UNOPOSE_REQUIRE(n_tensors == 0 || (ptrs_dev && sizes_dev), "nan_to_num_multi: null pointer");
+  UNOPOSE_REQUIRE(n_tensors >= 0 && n_tensors <= 65535 && max_size >= 0, "nan_to_num_multi: bad sizes (%d tensors)", n_tensors);
+  if (n_tensors == 0 || max_size == 0) return UNOPOSE_OK;
+  const unsigned gx = (unsigned)std::min<long>((max_size + 255) / 256, 64);
+  hipLaunchKernelGGL(nan_to_num_multi_kernel, dim3(gx, n_tensors), dim3(256), 0, (hipStream_t)stream, (float *const *)ptrs_dev,
+                     (const long long *)sizes_dev, nan_value, posinf_value, neginf_value);
+  return check_launch("nan_to_num_multi");
 }
 
 int unopose_pose_score(const float *dis, const float *w, int B, int N, float thr, float *out, unopose_stream_t stream) {

@@ -29,6 +29,9 @@ def flat_and_anneal_factor(it, total_iters, warmup_iters=1000, warmup_factor=0.0
     return target_lr_factor
 
 
+MULTI_TENSOR_HYGIENE = True  # (module attribute for A/Bs) zero_nonfinite_grads_ as one launch over all gradients; False: torch.nan_to_num per parameter
+
+
 def build_optimizer(model, lr=1e-4, total_iters=188340, **sched):
     """Adam as configured (configs/main_cfg.py:97-110) over the trainable parameters + the flat-and-anneal schedule."""
     params = [p for p in model.parameters() if p.requires_grad]
@@ -56,11 +59,41 @@ def wrap_ddp(model, device=None):
     return DDP(model, device_ids=ids, broadcast_buffers=False, find_unused_parameters=False)
 
 
+_PINNED = {}  # device -> [ring of pinned int64 staging buffers, next slot]
+
+
+def _table_to_device(values, dev):
+    """A small int64 table on `dev` through a ring of four persistent pinned buffers (asynchronous copy, no allocation per step; train_step
+    synchronises with the device once per step, so a slot is never overwritten while its copy is still queued)."""
+    n = len(values)
+    ring = _PINNED.get(dev)
+    if ring is None or ring[0][0].numel() < n:
+        ring = _PINNED[dev] = [[torch.empty(max(n, 1024), dtype=torch.int64).pin_memory() for _ in range(4)], 0]
+    buf = ring[0][ring[1] % 4]
+    ring[1] += 1
+    buf[:n] = torch.tensor(values, dtype=torch.int64)
+    return buf[:n].to(dev, non_blocking=True)
+
+
 def zero_nonfinite_grads_(model):
-    """engine_utils.py:14-18: NaN -> 0, +inf -> 1e5, -inf -> -1e5, in place."""
-    for p in model.parameters():
-        if p.grad is not None:
-            torch.nan_to_num(p.grad, nan=0.0, posinf=1e5, neginf=-1e5, out=p.grad)
+    """engine_utils.py:14-18: NaN -> 0, +inf -> 1e5, -inf -> -1e5, in place.  On the GPU all fp32 contiguous gradients go through ONE launch
+    (csrc/glue.hip nan_to_num_multi: a device table of pointers / sizes, refilled every step -- the gradients are new tensors after zero_grad(set_to_none=True));
+    whatever does not fit that (other dtypes, strided or CPU gradients) keeps torch.nan_to_num."""
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    multi = {}
+    for g in grads:
+        if g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and MULTI_TENSOR_HYGIENE:
+            multi.setdefault(g.device, []).append(g)
+        else:
+            torch.nan_to_num(g, nan=0.0, posinf=1e5, neginf=-1e5, out=g)
+    for dev, gs in multi.items():
+        from ._lib import call, on_device, ptr, stream_ptr
+        gs = [g for g in gs if g.numel()]
+        for i in range(0, len(gs), 65535):
+            part = gs[i:i + 65535]
+            table = _table_to_device([g.data_ptr() for g in part] + [g.numel() for g in part], dev)
+            with on_device(dev):
+                call("unopose_nan_to_num_multi", ptr(table), ptr(table[len(part):]), len(part), max(g.numel() for g in part), 0.0, 1e5, -1e5, stream_ptr())
 
 
 def train_step(model, batch, optimizer, scheduler=None, clip_max_norm=None, amp_dtype=None):
