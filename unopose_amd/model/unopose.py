@@ -205,7 +205,7 @@ class FinePointMatchingOneRef(nn.Module):
                 pe = self.PE(torch.cat([p1_, p2], 0)) if pe2_groups is None else \
                     self.PE.project(torch.cat([self.PE.groups(p1_), pe2_groups], 0))
                 d = d + pe.to(d.dtype)
-            bg = _bg_row(self, d.dtype).reshape(1, 1, -1).expand(2 * B, -1, -1)  # (read in place by the first block's gather: stride 0 is not a row layout the kernel takes, so gather_rows copies it once)
+            bg = _bg_row(self, d.dtype).reshape(1, 1, -1).expand(2 * B, -1, -1)  # (one cached row for every pair: the first block's gather reads it with row distance 0)
             idx_all = torch.cat([fps_idx1, fps_idx2], 0)
             for blk in self.transformers:
                 d, bg = blk.forward_stacked(d, bg, e_all, idx_all)
